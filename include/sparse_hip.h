@@ -1,0 +1,171 @@
+/* sparse_hip.h -- C ABI of libsparse_hip.so: the MI355X (gfx950) kernels behind the
+ * neural-sparse (SPLADE) fine-tuning step of
+ * zhichao-aws/opensearch-sparse-model-tuning-sample (train_ir.py hot loop).
+ *
+ * The reference is pure Python: every arithmetic op on its hot path is an ATen /
+ * HF-transformers call.  Each entry point below names the reference call site
+ * (file:line in the reference repo; "hf:" = transformers/models/bert/modeling_bert.py)
+ * whose arithmetic it replaces.  The Python binding a maintainer would add is a
+ * ctypes stub; opensearch-sparse-model-tuning-sample_amd/sparse_hip/lib.py
+ * is that stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed from the caller (torch tensors'
+ *    data_ptr()); the library allocates nothing and keeps no state except a
+ *    thread-local error string;
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *    never synchronises the device;
+ *  - return value 0 = ok, <0 = error (sm_last_error() has the text); no exception
+ *    crosses the ABI;
+ *  - `dtype` selects the activation/weight storage type of the GEMM-side tensors
+ *    (SM_F32 parity mode, SM_BF16 production mode); accumulators, LayerNorm
+ *    statistics, sparse representations (rep) and losses are always fp32;
+ *  - row-major everywhere; `ld*` are leading dimensions in elements.
+ */
+#ifndef SPARSE_HIP_H_
+#define SPARSE_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_ABI_VERSION 1
+#define SM_F32 0
+#define SM_BF16 1
+
+#define SM_OK 0
+#define SM_ERR_INVALID (-1)
+#define SM_ERR_UNSUPPORTED (-2)
+
+const char* sm_last_error(void);
+int sm_abi_version(void);
+
+/* ---- dropout descriptor (torch.nn.Dropout inside hf:63,158,287,345) -----------
+ * mask = hash(seed, site, element index) >= p, regenerated identically in backward. */
+typedef struct sm_dropout {
+  float p;        /* 0 disables */
+  uint64_t seed;  /* per step */
+  uint32_t site;  /* distinct per call site */
+} sm_dropout;
+
+/* ---- GEMM, Y = epilogue(A[M,K] . B[N,K]^T) --------------------------------------
+ * replaces every nn.Linear forward (hf:175-177 QKV, :290 attn-out, :335 FFN-up,
+ * :348 FFN-down, :477 MLM transform) and, with pre-transposed weights, every
+ * input-gradient GEMM of their backward.  Epilogue order:
+ *   v = acc + bias[n]; if (preact) preact[m,n] = v; if (act==1) v = gelu_erf(v);
+ *   v = dropout(v); if (residual) v += residual[m,n];
+ *   if (gelu_grad_of) v *= gelu'(gelu_grad_of[m,n]);  C[m,n] = v                     */
+typedef struct sm_epilogue {
+  const float* bias;        /* [N] fp32 or NULL */
+  int act;                  /* 0 none, 1 exact-erf GELU (hf:336) */
+  void* preact;             /* [M,N] (ldc) dtype, or NULL */
+  sm_dropout drop;          /* hf:291/349 hidden dropout */
+  const void* residual;     /* [M,N] (ldc) dtype, or NULL (hf:292/350 residual add) */
+  const void* gelu_grad_of; /* [M,N] (ldc) dtype, or NULL (backward of hf:336) */
+} sm_epilogue;
+
+int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+               int M, int N, int K, const sm_epilogue* epi, void* stream);
+
+/* Weight gradient: C[N,Kc] += A[M,N]^T . B[M,Kc]  (fp32, atomically accumulated), and
+ * optionally colsum[N] += sum_m A[m,:] (the bias gradient).  Backward of every nn.Linear. */
+int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                   int M, int N, int Kc, float* colsum, void* stream);
+
+/* ---- LayerNorm (hf:106, :293, :351, :479) ---------------------------------------- */
+int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                     float* mean, float* rstd, int rows, int H, float eps, void* stream);
+/* dx = LN'(dy); dgamma/dbeta are atomically accumulated.  If dx_drop != NULL it also
+ * writes dx_drop = dropout_bwd(dx) for the branch that went through a hidden dropout. */
+int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, void* dx_drop, const sm_dropout* drop,
+                     float* dgamma, float* dbeta, int rows, int H, void* stream);
+
+/* ---- embeddings (hf:68-107): z = word[ids] + type[0] + pos[0:S]; y = dropout(LN(z)) --- */
+int sm_embed_fwd(int dtype, const int64_t* ids, const void* word /*dtype [*,H]*/, const float* pos,
+                 const float* type0, const float* gamma, const float* beta, void* z, void* y,
+                 float* mean, float* rstd, int B, int S, int H, float eps, const sm_dropout* drop,
+                 void* stream);
+/* dz[T,H] -> gword[ids] += , gpos[s] += , gtype0 += (fp32 atomics) */
+int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, float* gpos, float* gtype0,
+                 int B, int S, int H, void* stream);
+/* elementwise y = dropout_bwd(dy) (used for the embedding dropout backward) */
+int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const sm_dropout* drop, void* stream);
+
+/* ---- self-attention (hf:111-136 eager attention + hf:164-204) ------------------------
+ * qkv: [B*S, 3H] packed (q | k | v), heads are contiguous dh-slices; keymask: [B,S] 1 = attend.
+ * ctx: [B*S, H]; lse: [B, A, S] fp32 log-sum-exp of the scaled masked scores. */
+int sm_attention_fwd(int dtype, const void* qkv, const uint8_t* keymask, void* ctx, float* lse,
+                     int B, int S, int A, int dh, const sm_dropout* drop, void* stream);
+int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keymask, const void* ctx,
+                     const void* dctx, const float* lse, void* dqkv, int B, int S, int A, int dh,
+                     const sm_dropout* drop, void* stream);
+
+/* ---- fused MLM decoder + mask + seq-max + log1p(relu)  (hf:490-496 decoder ->
+ * scripts/model/sparse_encoders.py:108-114).  t: [B*S,H] dtype, E: [>=V,H] dtype (tied
+ * word embeddings), bias [V].  Writes rep[B,V] fp32 and argmax[B,V] (position of the max).
+ * Never materialises the [B,S,V] logits. */
+int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
+                       float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, void* stream);
+/* scripts/model/sparse_encoders.py:115-119 ratio prune, in place on rep */
+int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream);
+/* backward of the fused head: given grad_rep[B,V] produces dt[B*S,H] (dtype),
+ * dE[V,H] += (fp32), dbias[V] += .  Sparse: one non-zero logit gradient per (b,v). */
+int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax,
+                       const void* t, const void* E, void* dt, float* dE, float* dbias,
+                       int B, int S, int H, int V, int use_l0, void* stream);
+
+/* ---- inference-free query encoder (scripts/model/sparse_encoders.py:121-127) ----------- */
+int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,
+                    int n_special, int V, float* out, void* stream);
+int sm_inf_free_bwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,
+                    int n_special, int V, const float* grad_out, float* grad_idf, void* stream);
+
+/* ---- FLOPS / L0-masked FLOPS regulariser (scripts/train/trainer.py:61-73) ---------------
+ * rep: [rows, V] (rows = n*g); colmean: [g,V] workspace out; rowkeep: [rows] out (1/0);
+ * value: device scalar out.  thr < 0 = no threshold. */
+int sm_flops_fwd(const float* rep, int rows, int g, int V, int thr, float* colmean, float* rowkeep,
+                 float* value, void* stream);
+/* grad_rep[row0 + i, :] (+)= gscale * 2*colmean[j,:]/n * sign(rep) * rowkeep, for the local
+ * rows [row0, row0+nrows); `accumulate` 0 writes, 1 adds. */
+int sm_flops_bwd(const float* rep, const float* colmean, const float* rowkeep, const float* gscale,
+                 int rows, int g, int V, int row0, int nrows, float* grad_rep, int accumulate, void* stream);
+
+/* ---- score matrices (scripts/train/loss.py:28-37,92-101; bi_encoder_wrapper.py:124-131) --
+ * dense: scores[nq, nd] = q[nq,D] . d[nd,D]^T (fp32).  pairs == 0: all pairs (in-batch);
+ * pairs == 1: nd = nq*k and only the block diagonal [nq,k] is produced (torch.bmm form). */
+int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pairs, float* scores, void* stream);
+/* dq (+)= ds . d ; dd[row0:row0+nrows] (+)= ds^T . q, restricted to local doc rows */
+int sm_scores_bwd(const float* q, const float* d, const float* ds, int nq, int nd, int D, int pairs,
+                  float* dq, float* dd, int accumulate, void* stream);
+
+/* ---- ranking losses on a score matrix -----------------------------------------------------
+ * InfoNCE (loss.py:86-107): rows nq, cols nd = nq*k; positives at column i*k for row i;
+ * pairs==1 (no in-batch negatives) => scores is [nq,k] with the positive in column 0.
+ * loss = mean_i(logsumexp over {pos_i} U negs - s_pos); other queries' positives excluded. */
+int sm_infonce_fwd_bwd(const float* scores, int nq, int ncols, int k, int pairs, float* loss,
+                       float* dscores, void* stream);
+/* KL-div (loss.py:25-43): sum_j t*(log t - log_softmax(s/T)), row-sum, batch-mean */
+int sm_kldiv_fwd_bwd(const float* scores, const float* teacher, int nq, int ncols, float temperature,
+                     float* loss, float* dscores, void* stream);
+/* MarginMSE (loss.py:57-77) */
+int sm_marginmse_fwd_bwd(const float* scores, const float* teacher, int nq, int ncols, float temperature,
+                         float* loss, float* dscores, void* stream);
+/* teacher ensemble normalisation (bi_encoder_wrapper.py:133-146): acc (+)= rowminmax(s)*scale/n */
+int sm_minmax_accumulate(const float* scores, int nq, int ncols, float weight, float* acc, int accumulate,
+                         void* stream);
+
+/* ---- optimiser + weight staging (train_ir.py:85-107: torch AdamW, wd on all params) ------ */
+int sm_adamw(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1, float beta2,
+             float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* fp32 master [rows,cols] -> dtype copy (ld_out >= cols) and optional transposed copy [cols,rows] */
+int sm_cast_weight(int dtype, const float* w, int rows, int cols, void* out, int ld_out, void* out_t,
+                   int ld_out_t, void* stream);
+/* scalar helpers on device: out = a*x + b*y (all device scalars or arrays of n) */
+int sm_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSE_HIP_H_ */

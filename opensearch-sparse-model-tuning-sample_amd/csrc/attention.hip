@@ -1,0 +1,410 @@
+// Self-attention forward / backward for BERT-sized sequences on gfx950 (hf:111-136 eager
+// attention).  One workgroup (4 waves) per (document, head); K/V (and for the backward Q/dO
+// plus their transposes) live in LDS for the whole block; all S x S work stays in MFMA
+// accumulators, nothing of size S x S ever touches HBM.
+//
+// Orientation trick: the forward computes S^T = K.Q^T so a 16x16 accumulator tile holds
+// (rows = keys, col = query) -- the softmax reduction over keys is then in-lane plus two
+// xor-shuffles, and the probability tile is *already* the B operand (k = key) of the
+// O^T = V^T.P^T product, with the k-order permutation absorbed by how V^T is read.
+// The backward runs two phases: per query block (S^T orientation) for dQ, per key block
+// (S orientation) for dK/dV; both recompute P from the saved log-sum-exp, so there are no
+// cross-wave reductions and no atomics.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct AT;
+template <> struct AT<bf16> {
+  static constexpr int KSTEP = 32;
+  using Frag = bf16x8;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct AT<float> {
+  static constexpr int KSTEP = 4;
+  using Frag = float;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// fragment (contraction over the head dim) of row `row` of a row-major [rows][DH] LDS image
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag row_frag(const char* base, int rs, int row, int ks, int g);
+template <>
+__device__ __forceinline__ bf16x8 row_frag<bf16>(const char* base, int rs, int row, int ks, int g) {
+  return *reinterpret_cast<const bf16x8*>(base + row * rs + (ks * 32 + 8 * g) * 2);
+}
+template <>
+__device__ __forceinline__ float row_frag<float>(const char* base, int rs, int row, int ks, int g) {
+  return *reinterpret_cast<const float*>(base + row * rs + (ks * 4 + g) * 4);
+}
+// same, straight from global memory (row-major, `ld` elements)
+template <typename T>
+__device__ __forceinline__ typename AT<T>::Frag grow_frag(const T* base, size_t ld, int row, int ks, int g);
+template <>
+__device__ __forceinline__ bf16x8 grow_frag<bf16>(const bf16* base, size_t ld, int row, int ks, int g) {
+  return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + ks * 32 + 8 * g);
+}
+template <>
+__device__ __forceinline__ float grow_frag<float>(const float* base, size_t ld, int row, int ks, int g) {
+  return base[(size_t)row * ld + ks * 4 + g];
+}
+
+// acc (16 x 16) = sum over the head dim of A-rows (LDS row-major) x B frags
+template <typename T, int DH>
+__device__ __forceinline__ f32x4 dh_product(const char* abase, int rs, int arow, int g,
+                                            const typename AT<T>::Frag (&fb)[DH / AT<T>::KSTEP]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DH / AT<T>::KSTEP; ++ks) acc = AT<T>::mma(row_frag<T>(abase, rs, arow, ks, g), fb[ks], acc);
+  return acc;
+}
+
+// acc (16 x 16) = sum over the sequence dim: A = rows of a transposed [DH][S] LDS image,
+// B = accumulator-layout tiles p[0..nt) (rows = sequence index, col = lane & 15).
+template <typename T, int NT> struct SeqProd;
+template <int NT> struct SeqProd<bf16, NT> {
+  __device__ static __forceinline__ f32x4 run(const char* tbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t2 = 0; t2 < NT / 2; ++t2) {
+      if (2 * t2 < nt) {
+        const char* a = tbase + trow * rs;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(a + ((2 * t2) * 16 + 4 * g) * 2);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(a + ((2 * t2 + 1) * 16 + 4 * g) * 2);
+        bf16x8 fa, fb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fa[j] = lo[j];
+          fa[4 + j] = hi[j];
+          fb[j] = (bf16)p[2 * t2][j];
+          fb[4 + j] = (bf16)p[2 * t2 + 1][j];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+      }
+    }
+    return acc;
+  }
+};
+template <int NT> struct SeqProd<float, NT> {
+  __device__ static __forceinline__ f32x4 run(const char* tbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = *reinterpret_cast<const float*>(tbase + trow * rs + (t * 16 + 4 * g + r) * 4);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[t][r], acc, 0, 0, 0);
+        }
+      }
+    }
+    return acc;
+  }
+};
+
+// cooperative staging of a [S][DH] slice (row stride `ld` elements in global) into LDS:
+// row-major image (stride rs bytes) and / or transposed image [DH][S] (stride rst bytes)
+template <typename T, int DH>
+__device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int S, char* rowimg, int rs, char* timg, int rst) {
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int CPR = DH / EPC;             // chunks per row
+  for (int idx = threadIdx.x; idx < S * CPR; idx += blockDim.x) {
+    const int r = idx / CPR, c = idx % CPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * EPC);
+    if (rowimg) *reinterpret_cast<uint4*>(rowimg + r * rs + c * 16) = v;
+    if (timg) {
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) *reinterpret_cast<T*>(timg + (c * EPC + j) * rst + r * (int)sizeof(T)) = e[j];
+    }
+  }
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* dst, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* dst, f32x4 v) { *reinterpret_cast<f32x4*>(dst) = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+  *reinterpret_cast<bf16x4*>(dst) = o;
+}
+
+template <typename T, int DH>
+struct Lay {  // LDS strides (bytes); +16 keeps 16-byte alignment and rotates banks per row
+  static constexpr int RS = DH * (int)sizeof(T) + 16;
+  __host__ __device__ static int rst(int S) { return S * (int)sizeof(T) + 16; }
+};
+
+// ------------------------------------------------------------------------------------
+template <typename T, int DH, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+                                                       T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = Lay<T, DH>;
+  constexpr int NKS = DH / AT<T>::KSTEP;
+  const int H = A * DH;
+  const size_t ld = 3 * (size_t)H;
+  const int b = blockIdx.x / A, h = blockIdx.x % A;
+  const int nkt = S / 16;
+  char* sK = smem;                          // [S][DH] row-major
+  char* sVt = sK + S * L::RS;               // [DH][S] transposed
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + DH * L::rst(S));
+  const T* base = qkv + (size_t)b * S * ld + h * DH;
+  stage<T, DH>(base + H, ld, S, sK, L::RS, nullptr, 0);
+  stage<T, DH>(base + 2 * H, ld, S, nullptr, 0, sVt, L::rst(S));
+  for (int i = threadIdx.x; i < S; i += blockDim.x) sM[i] = keymask[(size_t)b * S + i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const float scale = rsqrtf((float)DH);
+  for (int qb = w; qb < nkt; qb += 4) {
+    typename AT<T>::Frag fq[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) fq[ks] = grow_frag<T>(base, ld, qb * 16 + li, ks, g);
+    f32x4 p[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+        p[kt] = dh_product<T, DH>(sK, L::RS, kt * 16 + li, g, fq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s = sM[kt * 16 + 4 * g + r] ? p[kt][r] * scale : -INFINITY;
+          p[kt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      } else {
+        p[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt < nkt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = mx == -INFINITY ? 0.f : __expf(p[kt][r] - mx);
+          p[kt][r] = e;
+          sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    const int q = qb * 16 + li;
+    const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt < nkt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p[kt][r] * inv;
+          if (drop.thresh16) v = drop_keep1(drop, ebase + kt * 16 + 4 * g + r) ? v * drop.scale : 0.f;
+          p[kt][r] = v;
+        }
+    if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::rst(S), dt * 16 + li, g, p, nkt);
+      store4<T>(ctx + ((size_t)b * S + q) * H + h * DH + dt * 16 + 4 * g, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T, int DH, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+                                                       const T* __restrict__ ctx, const T* __restrict__ dctx,
+                                                       const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = Lay<T, DH>;
+  constexpr int NKS = DH / AT<T>::KSTEP;
+  const int H = A * DH;
+  const size_t ld = 3 * (size_t)H;
+  const int b = blockIdx.x / A, h = blockIdx.x % A;
+  const int nt = S / 16;
+  const int rst = L::rst(S);
+  char* sQ = smem;
+  char* sK = sQ + S * L::RS;
+  char* sV = sK + S * L::RS;
+  char* sDO = sV + S * L::RS;
+  char* sQt = sDO + S * L::RS;
+  char* sKt = sQt + DH * rst;
+  char* sDOt = sKt + DH * rst;
+  float* sLse = reinterpret_cast<float*>(sDOt + DH * rst);
+  float* sDelta = sLse + S;
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
+  const T* base = qkv + (size_t)b * S * ld + h * DH;
+  const T* dob = dctx + (size_t)b * S * H + h * DH;
+  const T* ob = ctx + (size_t)b * S * H + h * DH;
+  stage<T, DH>(base, ld, S, sQ, L::RS, sQt, rst);
+  stage<T, DH>(base + H, ld, S, sK, L::RS, sKt, rst);
+  stage<T, DH>(base + 2 * H, ld, S, sV, L::RS, nullptr, 0);
+  stage<T, DH>(dob, H, S, sDO, L::RS, sDOt, rst);
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    sM[i] = keymask[(size_t)b * S + i];
+    sLse[i] = lse[(size_t)(b * A + h) * S + i];
+    float d = 0.f;
+    for (int c = 0; c < DH; ++c) d += to_f32<T>(dob[(size_t)i * H + c]) * to_f32<T>(ob[(size_t)i * H + c]);
+    sDelta[i] = d;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const float scale = rsqrtf((float)DH);
+  T* dq_out = dqkv + (size_t)b * S * ld + h * DH;
+
+  // ---- phase A: per query block, S^T orientation (rows = keys, col = query) -> dQ ----
+  for (int qb = w; qb < nt; qb += 4) {
+    const int q = qb * 16 + li;
+    typename AT<T>::Frag fq[NKS], fdo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      fq[ks] = row_frag<T>(sQ, L::RS, q, ks, g);
+      fdo[ks] = row_frag<T>(sDO, L::RS, q, ks, g);
+    }
+    const float lq = sLse[q], dl = sDelta[q];
+    const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nt) {
+        const f32x4 s = dh_product<T, DH>(sK, L::RS, kt * 16 + li, g, fq);
+        const f32x4 dp = dh_product<T, DH>(sV, L::RS, kt * 16 + li, g, fdo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float pv = sM[key] ? __expf(s[r] * scale - lq) : 0.f;
+          float dpv = dp[r];
+          if (drop.thresh16) dpv = drop_keep1(drop, ebase + key) ? dpv * drop.scale : 0.f;
+          ds[kt][r] = pv * (dpv - dl) * scale;
+        }
+      } else {
+        ds[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 o = SeqProd<T, NKT>::run(sKt, rst, dt * 16 + li, g, ds, nt);
+      store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, o);
+    }
+  }
+
+  // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
+  for (int kb = w; kb < nt; kb += 4) {
+    const int key = kb * 16 + li;
+    typename AT<T>::Frag fk[NKS], fv[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      fk[ks] = row_frag<T>(sK, L::RS, key, ks, g);
+      fv[ks] = row_frag<T>(sV, L::RS, key, ks, g);
+    }
+    const bool kvalid = sM[key] != 0;
+    f32x4 pd[NKT], ds[NKT];
+#pragma unroll
+    for (int qt = 0; qt < NKT; ++qt) {
+      if (qt < nt) {
+        const f32x4 s = dh_product<T, DH>(sQ, L::RS, qt * 16 + li, g, fk);
+        const f32x4 dp = dh_product<T, DH>(sDO, L::RS, qt * 16 + li, g, fv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * g + r;
+          const float pv = kvalid ? __expf(s[r] * scale - sLse[q]) : 0.f;
+          float keepf = 1.f;
+          if (drop.thresh16)
+            keepf = drop_keep1(drop, ((uint64_t)(b * A + h) * S + q) * (uint64_t)S + key) ? drop.scale : 0.f;
+          pd[qt][r] = pv * keepf;
+          ds[qt][r] = pv * (dp[r] * keepf - sDelta[q]) * scale;
+        }
+      } else {
+        pd[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 dv = SeqProd<T, NKT>::run(sDOt, rst, dt * 16 + li, g, pd, nt);
+      const f32x4 dk = SeqProd<T, NKT>::run(sQt, rst, dt * 16 + li, g, ds, nt);
+      store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv);
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk);
+    }
+  }
+}
+
+template <typename T, int DH>
+size_t fwd_lds(int S) { return (size_t)S * Lay<T, DH>::RS + (size_t)DH * Lay<T, DH>::rst(S) + S; }
+template <typename T, int DH>
+size_t bwd_lds(int S) { return 4 * (size_t)S * Lay<T, DH>::RS + 3 * (size_t)DH * Lay<T, DH>::rst(S) + 8 * (size_t)S + S; }
+
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <typename T, int DH, int NKT>
+int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B, int S, int A, const DropCfg& d, hipStream_t st) {
+  const size_t lds = fwd_lds<T, DH>(S);
+  SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
+  auto kern = attn_fwd_kernel<T, DH, NKT>;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d);
+  return SM_OK;
+}
+template <typename T, int DH, int NKT>
+int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+               int B, int S, int A, const DropCfg& d, hipStream_t st) {
+  const size_t lds = bwd_lds<T, DH>(S);
+  SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
+  auto kern = attn_bwd_kernel<T, DH, NKT>;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d);
+  return SM_OK;
+}
+
+int check_shape(const char* who, int dtype, int B, int S, int A, int dh) {
+  SM_REQUIRE(B > 0 && A > 0, "%s: empty batch", who);
+  SM_REQUIRE(dh == 32 || dh == 64, "%s: head dim %d unsupported (32 or 64)", who, dh);
+  SM_REQUIRE(S % 32 == 0 && S >= 32 && S <= 256, "%s: S=%d must be a multiple of 32 in [32, 256] (pad the batch)", who, S);
+  SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "%s: bad dtype %d", who, dtype);
+  return SM_OK;
+}
+
+}  // namespace
+
+#define ATT_DISPATCH(FN, ...)                                                                   \
+  do {                                                                                          \
+    int rc;                                                                                     \
+    if (dtype == SM_BF16) {                                                                     \
+      if (dh == 32) rc = S <= 128 ? FN<bf16, 32, 8>(__VA_ARGS__) : FN<bf16, 32, 16>(__VA_ARGS__); \
+      else rc = S <= 128 ? FN<bf16, 64, 8>(__VA_ARGS__) : FN<bf16, 64, 16>(__VA_ARGS__);        \
+    } else {                                                                                    \
+      if (dh == 32) rc = S <= 128 ? FN<float, 32, 8>(__VA_ARGS__) : FN<float, 32, 16>(__VA_ARGS__); \
+      else rc = S <= 128 ? FN<float, 64, 8>(__VA_ARGS__) : FN<float, 64, 16>(__VA_ARGS__);      \
+    }                                                                                           \
+    if (rc != SM_OK) return rc;                                                                 \
+  } while (0)
+
+extern "C" int sm_attention_fwd(int dtype, const void* qkv, const uint8_t* keymask, void* ctx, float* lse, int B, int S,
+                                int A, int dh, const sm_dropout* drop, void* stream) {
+  int rc = check_shape("sm_attention_fwd", dtype, B, S, A, dh);
+  if (rc != SM_OK) return rc;
+  const DropCfg d = make_drop(drop);
+  hipStream_t st = (hipStream_t)stream;
+  ATT_DISPATCH(launch_fwd, qkv, keymask, ctx, lse, B, S, A, d, st);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keymask, const void* ctx, const void* dctx,
+                                const float* lse, void* dqkv, int B, int S, int A, int dh, const sm_dropout* drop,
+                                void* stream) {
+  int rc = check_shape("sm_attention_bwd", dtype, B, S, A, dh);
+  if (rc != SM_OK) return rc;
+  const DropCfg d = make_drop(drop);
+  hipStream_t st = (hipStream_t)stream;
+  ATT_DISPATCH(launch_bwd, qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, st);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

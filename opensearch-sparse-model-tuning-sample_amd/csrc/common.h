@@ -1,0 +1,120 @@
+// Shared device/host helpers for the gfx950 (MI355X) neural-sparse training kernels.
+// Wave = 64 lanes everywhere in this library (CDNA4); no 32-wide idioms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sparse_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) -------------------------------------------------
+void sm_set_error(const char* fmt, ...);
+#define SM_HIP_CHECK(expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      sm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -(int)_e - 1000;                                                     \
+    }                                                                             \
+  } while (0)
+#define SM_REQUIRE(cond, ...)                \
+  do {                                       \
+    if (!(cond)) {                           \
+      sm_set_error(__VA_ARGS__);             \
+      return SM_ERR_INVALID;                 \
+    }                                        \
+  } while (0)
+#define SM_LAUNCH_CHECK() SM_HIP_CHECK(hipGetLastError())
+
+static inline int sm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- scalar conversions ------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+// ---- wave (64-lane) reductions ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x = 256 (4 waves); `red` is >= 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- exact-erf GELU (HF hidden_act="gelu") -----------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- counter-based dropout mask -------------------------------------------------
+// keep(element) = hash16(seed, site, element index) >= round(p * 65536).  Forward and
+// backward regenerate the same mask from (seed, site, element index), so no mask
+// tensor is ever stored.  The hash is two murmur3 finalisers (about 12 integer ops per
+// element) -- counter based like Philox, cheap enough to sit in a GEMM epilogue.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+struct DropCfg {
+  uint32_t key;       // fmix32(seed_lo + site * golden) ^ seed_hi
+  uint32_t thresh16;  // 0 => dropout disabled
+  float scale;        // 1 / (1 - p_effective)
+};
+
+__device__ __forceinline__ bool drop_keep1(const DropCfg& d, uint64_t elem) {
+  uint32_t h = fmix32((uint32_t)elem ^ d.key);
+  h ^= (uint32_t)(elem >> 32) * 0x7FEB352Du;
+  h = (h ^ (h >> 15)) * 0x846CA68Bu;
+  h ^= h >> 16;
+  return (h & 0xFFFFu) >= d.thresh16;
+}
+
+static inline uint32_t sm_fmix32_host(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+static inline DropCfg make_drop(const sm_dropout* s) {
+  DropCfg d;
+  d.key = 0; d.thresh16 = 0; d.scale = 1.f;
+  if (s == nullptr || s->p <= 0.f) return d;
+  d.key = sm_fmix32_host((uint32_t)s->seed + s->site * 0x9E3779B9u) ^ (uint32_t)(s->seed >> 32);
+  uint32_t t = (uint32_t)(s->p * 65536.0f + 0.5f);
+  if (t > 65535u) t = 65535u;
+  d.thresh16 = t;
+  d.scale = 1.0f / (1.0f - (float)t / 65536.0f);
+  return d;
+}

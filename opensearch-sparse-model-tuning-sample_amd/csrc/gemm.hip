@@ -1,0 +1,472 @@
+// MFMA GEMM kernels for gfx950: NT (forward / input-gradient), TN (weight gradient) and the
+// fused MLM-decoder + seq-max + log1p(relu) head.  One kernel body per shape class, templated
+// on the storage type: bf16 uses v_mfma_f32_16x16x32_bf16, fp32 (parity mode) uses the exact
+// v_mfma_f32_16x16x4_f32.  Both share the 16x16 C/D fragment layout
+// (col = lane & 15, row = (lane >> 4) * 4 + reg), so every epilogue is written once.
+//
+// Block tile 128 x 128, 256 threads = 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles.
+// LDS stage rows are 128 bytes of K (64 bf16 / 32 fp32), XOR-swizzled in 16-byte chunks
+// (chunk ^= row & 7) so ds_read_b128 fragment reads are bank-conflict free; two stages.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int TILE_BYTES = 128 * 128;  // one operand stage
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  static constexpr int KSTEP = 32, BK = 64;
+  using Frag = bf16x8;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // NT operand fragment: 8 consecutive k of row `row` (k = 32*ks + 8*g + j)
+  __device__ static __forceinline__ Frag load_nt(const char* tile, int row, int ks, int g) {
+    const int chunk = ks * 4 + g;
+    return *reinterpret_cast<const Frag*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KSTEP = 4, BK = 32;
+  using Frag = float;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ Frag load_nt(const char* tile, int row, int ks, int g) {
+    return *reinterpret_cast<const float*>(tile + row * 128 + ((ks ^ (row & 7)) << 4) + g * 4);
+  }
+};
+
+// global -> registers: a [128 rows][BK] K-contiguous stage, 4 x 16 B per thread
+template <typename T>
+__device__ __forceinline__ void g2r_nt(const T* __restrict__ base, int ld, int row0, int nrows, int k0, uint4 regs[4]) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + r0 + 32 * i;
+    if (row < nrows)
+      regs[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + k0 + c * (16 / (int)sizeof(T)));
+    else
+      regs[i] = make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void r2s_nt(char* tile, const uint4 regs[4]) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + 32 * i;
+    *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = regs[i];
+  }
+}
+
+// acc[i][j] += A[m0.., :] . B[n0.., :]^T over the whole K; smem = 4 * TILE_BYTES
+template <typename T>
+__device__ __forceinline__ void nt_mainloop(const T* __restrict__ A, int lda, int M, int m0,
+                                            const T* __restrict__ B, int ldb, int N, int n0, int K,
+                                            char* smem, f32x4 acc[4][4]) {
+  using MM = Mma<T>;
+  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
+  char* const sA = smem;                   // two stages of A, then two stages of B
+  char* const sB = smem + 2 * TILE_BYTES;
+  uint4 ra[4], rb[4];
+  const int nk = K / BK;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+
+  g2r_nt(A, lda, m0, M, 0, ra);
+  g2r_nt(B, ldb, n0, N, 0, rb);
+  r2s_nt(sA, ra);
+  r2s_nt(sB, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      g2r_nt(A, lda, m0, M, (kt + 1) * BK, ra);
+      g2r_nt(B, ldb, n0, N, (kt + 1) * BK, rb);
+    }
+    const char* a = sA + (kt & 1) * TILE_BYTES;
+    const char* b = sB + (kt & 1) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
+        fb[i] = MM::load_nt(b, wn * 64 + i * 16 + li, ks, g);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      r2s_nt(sA + ((kt + 1) & 1) * TILE_BYTES, ra);
+      r2s_nt(sB + ((kt + 1) & 1) * TILE_BYTES, rb);
+    }
+    __syncthreads();
+  }
+}
+
+struct EpiArgs {
+  const float* bias;
+  int act;
+  void* preact;
+  DropCfg drop;
+  const void* residual;
+  const void* gelu_grad_of;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+                                                           T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  T* preact = reinterpret_cast<T*>(e.preact);
+  const T* residual = reinterpret_cast<const T*>(e.residual);
+  const T* ggo = reinterpret_cast<const T*>(e.gelu_grad_of);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + li;
+    if (col >= N) continue;
+    const float bv = e.bias ? e.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
+        if (row >= M) continue;
+        const size_t off = (size_t)row * ldc + col;
+        float v = acc[i][j][r] + bv;
+        if (preact) preact[off] = from_f32<T>(v);
+        if (e.act == 1) v = gelu_f(v);
+        if (e.drop.thresh16) v = drop_keep1(e.drop, (uint64_t)row * (uint64_t)N + col) ? v * e.drop.scale : 0.f;
+        if (residual) v += to_f32<T>(residual[off]);
+        if (ggo) v *= gelu_grad_f(to_f32<T>(ggo[off]));
+        C[off] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused MLM decoder + mask + max over the sequence + log1p(relu): rep[b,v], argmax[b,v].
+// grid.x = vocab tiles (128 columns); grid.y = 128-row token tiles (S <= 128, 128 % S == 0:
+// a tile holds 128/S whole documents) or documents (S % 128 == 0: the block walks the S/128
+// tiles of its document keeping a running max).  The [B,S,V] logits never exist in memory.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __restrict__ Tn, const T* __restrict__ E,
+                                                                   const float* __restrict__ bias, const uint8_t* __restrict__ mask,
+                                                                   float* __restrict__ rep, uint16_t* __restrict__ argmax,
+                                                                   int Bdocs, int S, int H, int V, int use_l0) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  // the per-group reduction scratch overlays the (then idle) staging buffers
+  float* redv = reinterpret_cast<float*>(smem);  // [8 groups][128 cols]
+  int* redi = reinterpret_cast<int*>(redv + 8 * 128);
+  const int Ttot = Bdocs * S;
+  const int n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  const bool long_doc = S > 128;
+  const int ntile = long_doc ? S / 128 : 1;
+  float run_v = -INFINITY;
+  int run_i = 0;
+
+  for (int mt = 0; mt < ntile; ++mt) {
+    const int m0 = long_doc ? blockIdx.y * S + mt * 128 : blockIdx.y * 128;
+    // mask bytes of this lane's 16 rows (4 consecutive rows per MFMA tile); B*S % 16 == 0
+    uint32_t mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + g * 4;
+      mrow[i] = row < Ttot ? *reinterpret_cast<const uint32_t*>(mask + row) : 0u;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    nt_mainloop<T>(Tn, H, Ttot, m0, E, H, V, n0, H, smem, acc);  // ends with a barrier: staging is idle
+
+    // per 16-row group max (value, row-in-tile) for each of this lane's columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bv = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rt = wm * 64 + i * 16 + g * 4 + r;
+          const float v = ((mrow[i] >> (8 * r)) & 0xFFu) ? acc[i][j][r] : -INFINITY;
+          if (v > bv) { bv = v; bi = rt; }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (g == 0) {
+          redv[(wm * 4 + i) * 128 + wn * 64 + j * 16 + li] = bv;
+          redi[(wm * 4 + i) * 128 + wn * 64 + j * 16 + li] = bi;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int col = n0 + threadIdx.x;
+      if (long_doc) {
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+          const float v = redv[grp * 128 + threadIdx.x];
+          if (v > run_v) { run_v = v; run_i = mt * 128 + redi[grp * 128 + threadIdx.x]; }
+        }
+      } else {
+        const int gper = S / 16, ndoc = 128 / S;
+        for (int dd = 0; dd < ndoc; ++dd) {
+          const int b = m0 / S + dd;
+          float bv = -INFINITY;
+          int bi = dd * S;
+          for (int grp = dd * gper; grp < (dd + 1) * gper; ++grp) {
+            const float v = redv[grp * 128 + threadIdx.x];
+            if (v > bv) { bv = v; bi = redi[grp * 128 + threadIdx.x]; }
+          }
+          if (b < Bdocs && col < V) {
+            float y = fmaxf(bv + bias[col], 0.f);
+            y = log1pf(y);
+            if (use_l0) y = log1pf(y);
+            rep[(size_t)b * V + col] = y;
+            argmax[(size_t)b * V + col] = (uint16_t)(bi - dd * S);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (long_doc && threadIdx.x < 128) {
+    const int col = n0 + threadIdx.x, b = blockIdx.y;
+    if (col < V) {
+      float y = fmaxf(run_v + bias[col], 0.f);
+      y = log1pf(y);
+      if (use_l0) y = log1pf(y);
+      rep[(size_t)b * V + col] = y;
+      argmax[(size_t)b * V + col] = (uint16_t)run_i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// TN (weight gradient): C[N,Kc] += sum_m A[m,N]^T B[m,Kc], split over m across grid.z and
+// atomically accumulated in fp32.  Both operands are staged row-major [m][cols] exactly as
+// they sit in HBM (coalesced) and the MFMA fragments (8 consecutive m per lane) come out of
+// LDS through the gfx950 transposing read ds_read_b64_tr_b16.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Tn;
+template <> struct Tn<bf16> {
+  static constexpr int BKM = 64, RS = 128 * 2 + 16;  // rows of m per stage, padded row stride (bytes)
+  __device__ static __forceinline__ bf16x8 load(const char* tile, int ks, int colbase, int g, int li) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const int q = li >> 2, p = li & 3;
+    const char* a0 = tile + (ks * 32 + 8 * g + q) * RS + (colbase + 4 * p) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * RS));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+  }
+};
+template <> struct Tn<float> {
+  static constexpr int BKM = 32, RS = 128 * 4 + 16;
+  __device__ static __forceinline__ float load(const char* tile, int ks, int colbase, int g, int li) {
+    return *reinterpret_cast<const float*>(tile + (ks * 4 + g) * RS + (colbase + li) * 4);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void g2r_tn(const T* __restrict__ base, int ld, int m0, int mend, int c0, int ncols, uint4 regs[4]) {
+  constexpr int CH = 128 * (int)sizeof(T) / 16, RSTEP = NTHREADS / CH, EPC = 16 / (int)sizeof(T);
+  const int c = threadIdx.x % CH, r0 = threadIdx.x / CH;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + r0 + RSTEP * i, col = c0 + c * EPC;
+    if (row < mend && col < ncols)
+      regs[i] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + col);
+    else
+      regs[i] = make_uint4(0, 0, 0, 0);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void r2s_tn(char* tile, const uint4 regs[4]) {
+  constexpr int CH = 128 * (int)sizeof(T) / 16, RSTEP = NTHREADS / CH;
+  const int c = threadIdx.x % CH, r0 = threadIdx.x / CH;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + (r0 + RSTEP * i) * Tn<T>::RS + c * 16) = regs[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int N, int Kc,
+                                                           int rows_per_split, float* __restrict__ colsum) {
+  using MM = Mma<T>;
+  constexpr int BKM = Tn<T>::BKM, RS = Tn<T>::RS, NS = BKM / MM::KSTEP;
+  constexpr int STAGE = BKM * RS;
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];
+  char* const sA = smem;
+  char* const sB = smem + 2 * STAGE;
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  const int mbeg = blockIdx.z * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  if (mbeg >= mend) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = colsum != nullptr && blockIdx.x == 0;
+  float csum = 0.f;
+  uint4 ra[4], rb[4];
+  const int nst = (mend - mbeg + BKM - 1) / BKM;
+  g2r_tn<T>(A, lda, mbeg, mend, n0, N, ra);
+  g2r_tn<T>(B, ldb, mbeg, mend, k0, Kc, rb);
+  r2s_tn<T>(sA, ra);
+  r2s_tn<T>(sB, rb);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    if (st + 1 < nst) {
+      g2r_tn<T>(A, lda, mbeg + (st + 1) * BKM, mend, n0, N, ra);
+      g2r_tn<T>(B, ldb, mbeg + (st + 1) * BKM, mend, k0, Kc, rb);
+    }
+    const char* a = sA + (st & 1) * STAGE;
+    const char* b = sB + (st & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = Tn<T>::load(a, ks, wm * 64 + i * 16, g, li);
+        fb[i] = Tn<T>::load(b, ks, wn * 64 + i * 16, g, li);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (do_colsum && threadIdx.x < 128) {
+      for (int m = 0; m < BKM; ++m) csum += to_f32<T>(*reinterpret_cast<const T*>(a + m * RS + threadIdx.x * sizeof(T)));
+    }
+    if (st + 1 < nst) {
+      r2s_tn<T>(sA + ((st + 1) & 1) * STAGE, ra);
+      r2s_tn<T>(sB + ((st + 1) & 1) * STAGE, rb);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = k0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + wm * 64 + i * 16 + g * 4 + r;
+        if (row < N && col < Kc) atomicAdd(&C[(size_t)row * ldc + col], acc[i][j][r]);
+      }
+    }
+  if (do_colsum && threadIdx.x < 128 && n0 + threadIdx.x < N) atomicAdd(&colsum[n0 + threadIdx.x], csum);
+}
+
+template <typename T>
+int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                   const sm_epilogue* epi, hipStream_t st) {
+  EpiArgs e;
+  e.bias = epi ? epi->bias : nullptr;
+  e.act = epi ? epi->act : 0;
+  e.preact = epi ? epi->preact : nullptr;
+  e.drop = make_drop(epi ? &epi->drop : nullptr);
+  e.residual = epi ? epi->residual : nullptr;
+  e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  dim3 grid(sm_cdiv(N, BN), sm_cdiv(M, BM));
+  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+  return 0;
+}
+
+template <typename T>
+int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc,
+                   float* colsum, hipStream_t st) {
+  const int tiles = sm_cdiv(N, 128) * sm_cdiv(Kc, 128);
+  constexpr int BKM = Tn<T>::BKM;
+  int nsplit = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU in flight
+  const int max_split = (M + 4 * BKM - 1) / (4 * BKM);         // at least 4 stages per split
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int rows_per_split = ((M + nsplit - 1) / nsplit + BKM - 1) / BKM * BKM;
+  nsplit = (M + rows_per_split - 1) / rows_per_split;
+  dim3 grid(sm_cdiv(Kc, 128), sm_cdiv(N, 128), nsplit);
+  hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, Kc,
+                     rows_per_split, colsum);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
+                          int K, const sm_epilogue* epi, void* stream) {
+  SM_REQUIRE(M > 0 && N > 0 && K > 0, "sm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  SM_REQUIRE(K % 64 == 0, "sm_gemm_nt: K=%d must be a multiple of 64", K);
+  const int esz = dtype == SM_BF16 ? 2 : 4;
+  SM_REQUIRE((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "sm_gemm_nt: lda/ldb rows must be 16-byte aligned");
+  SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_nt: A/B must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SM_BF16) launch_gemm_nt<bf16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else if (dtype == SM_F32) launch_gemm_nt<float>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M,
+                              int N, int Kc, float* colsum, void* stream) {
+  SM_REQUIRE(M > 0 && N > 0 && Kc > 0, "sm_gemm_tn_acc: empty problem");
+  const int esz = dtype == SM_BF16 ? 2 : 4;
+  const int epc = 16 / esz;
+  SM_REQUIRE(N % epc == 0 && Kc % epc == 0, "sm_gemm_tn_acc: N=%d and Kc=%d must be multiples of %d", N, Kc, epc);
+  SM_REQUIRE((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "sm_gemm_tn_acc: lda/ldb rows must be 16-byte aligned");
+  SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_tn_acc: A/B must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SM_BF16) launch_gemm_tn<bf16>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
+  else if (dtype == SM_F32) launch_gemm_tn<float>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
+  else SM_REQUIRE(false, "sm_gemm_tn_acc: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
+                                  float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, void* stream) {
+  SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_fwd: empty problem");
+  SM_REQUIRE(H % 64 == 0, "sm_sparse_head_fwd: H=%d must be a multiple of 64", H);
+  SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0),
+             "sm_sparse_head_fwd: S=%d must be 16/32/64/128 or a multiple of 128 (pad the batch)", S);
+  SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
+  hipStream_t st = (hipStream_t)stream;
+  const long T = (long)B * S;
+  dim3 grid(sm_cdiv(V, BN), S > 128 ? B : sm_cdiv(T, 128));
+  if (dtype == SM_BF16)
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
+  else if (dtype == SM_F32)
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
+  else SM_REQUIRE(false, "sm_sparse_head_fwd: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

@@ -1,0 +1,548 @@
+// [B,V]-shaped kernels of the neural-sparse training step on gfx950 (all HBM-bound):
+// backward of the fused MLM head, ratio prune, inference-free query encoder, FLOPS / L0
+// regulariser, dense score matrices, ranking losses, teacher ensemble normalisation.
+// Every reduction is a 64-lane wave reduction; every global access is coalesced along V.
+#include "common.h"
+
+namespace {
+
+// d rep / d logit as a function of rep itself (rep = log1p(y), or log1p(log1p(y)) with L0)
+__device__ __forceinline__ float head_fprime(float r, int use_l0) {
+  if (!(r > 0.f)) return 0.f;
+  return use_l0 ? __expf(-r - expm1f(r)) : __expf(-r);
+}
+
+// ---- backward of the fused head, part 1: dt[b,l,:] = sum_{v: argmax[b,v]=l} g[b,v] E[v,:] ----
+// grid (B, H/CW), CW = 64*CPL columns; the [S][CW] fp32 slice of dt accumulates in LDS (ds_add_f32).
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void head_dt_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
+                                                      const uint16_t* __restrict__ argmax, const T* __restrict__ E,
+                                                      T* __restrict__ dt, int S, int H, int V, int use_l0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CW = 64 * CPL;
+  float* acc = reinterpret_cast<float*>(smem);  // [S][CW]
+  const int b = blockIdx.x, hc = blockIdx.y * CW;
+  for (int i = threadIdx.x; i < S * CW; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t rb = (size_t)b * V;
+  for (int v0 = w * 64; v0 < V; v0 += 256) {
+    const int v = v0 + lane;
+    float gv = 0.f;
+    int l = 0;
+    if (v < V) {
+      const float r = rep[rb + v];
+      gv = grad_rep[rb + v] * head_fprime(r, use_l0);
+      l = argmax[rb + v];
+    }
+    unsigned long long nz = __ballot(gv != 0.f);
+    while (nz) {
+      const int i = __ffsll((long long)nz) - 1;
+      nz &= nz - 1;
+      const float gi = __shfl(gv, i, 64);
+      const int li = __shfl(l, i, 64);
+      const T* er = E + (size_t)(v0 + i) * H + hc + lane * CPL;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) atomicAdd(&acc[li * CW + lane * CPL + c], gi * to_f32<T>(er[c]));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S * CW; i += 256) {
+    const int l = i / CW, c = i % CW;
+    dt[((size_t)b * S + l) * H + hc + c] = from_f32<T>(acc[i]);
+  }
+}
+
+// ---- part 2: dE[v,:] += sum_b g[b,v] t[b, argmax[b,v], :],  dbias[v] += sum_b g[b,v] ----
+// block = 16 vocab rows (4 per wave); g / argmax tiles for 256 documents at a time in LDS.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_de_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
+                                                      const uint16_t* __restrict__ argmax, const T* __restrict__ t,
+                                                      float* __restrict__ dE, float* __restrict__ dbias, int B, int S, int H,
+                                                      int V, int use_l0) {
+  __shared__ float sg[256][16];
+  __shared__ uint16_t sl[256][16];
+  const int v0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc[4][NC];
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[k][c] = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 256 * 16; idx += 256) {
+      const int bb = idx >> 4, vi = idx & 15;
+      float gv = 0.f;
+      uint16_t l = 0;
+      if (b0 + bb < B && v0 + vi < V) {
+        const size_t o = (size_t)(b0 + bb) * V + v0 + vi;
+        gv = grad_rep[o] * head_fprime(rep[o], use_l0);
+        l = argmax[o];
+      }
+      sg[bb][vi] = gv;
+      sl[bb][vi] = l;
+    }
+    __syncthreads();
+    const int nb = min(256, B - b0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int vi = w * 4 + k;
+      for (int bb = 0; bb < nb; ++bb) {
+        const float gv = sg[bb][vi];
+        if (gv != 0.f) {
+          gsum[k] += gv;
+          const T* tr = t + ((size_t)(b0 + bb) * S + sl[bb][vi]) * H;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[k][c] += gv * to_f32<T>(tr[lane + 64 * c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int v = v0 + w * 4 + k;
+    if (v < V) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dE[(size_t)v * H + lane + 64 * c] += acc[k][c];
+      if (lane == 0) dbias[v] += gsum[k];
+    }
+  }
+}
+
+// ---- ratio prune: rep *= (rep > ratio * rowmax) -----------------------------------------
+__global__ __launch_bounds__(256) void prune_kernel(float* __restrict__ rep, int V, float ratio) {
+  __shared__ float red[4];
+  float* r = rep + (size_t)blockIdx.x * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, r[v]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * ratio;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float x = r[v];
+    r[v] = x > thr ? x : 0.f;
+  }
+}
+
+// ---- inference-free query encoder --------------------------------------------------------
+__global__ void inf_free_fwd_kernel(const int64_t* __restrict__ ids, int n, int sq, const float* __restrict__ idf,
+                                    const int32_t* __restrict__ special, int n_special, int V, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  if (id < 0 || id >= V) return;
+  for (int k = 0; k < n_special; ++k)
+    if (special[k] == id) return;
+  out[(size_t)(i / sq) * V + id] = fmaxf(idf[id], 0.f);
+}
+__global__ void inf_free_bwd_kernel(const int64_t* __restrict__ ids, int n, int sq, const float* __restrict__ idf,
+                                    const int32_t* __restrict__ special, int n_special, int V,
+                                    const float* __restrict__ grad_out, float* __restrict__ grad_idf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  if (id < 0 || id >= V) return;
+  for (int k = 0; k < n_special; ++k)
+    if (special[k] == id) return;
+  const int b = i / sq, s = i % sq;
+  for (int p = 0; p < s; ++p)
+    if (ids[b * sq + p] == id) return;  // a token counts once per query
+  if (idf[id] > 0.f) atomicAdd(&grad_idf[id], grad_out[(size_t)b * V + id]);
+}
+
+// ---- FLOPS / L0 regulariser ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void flops_rowkeep_kernel(const float* __restrict__ rep, int V, int thr, float* __restrict__ rowkeep) {
+  __shared__ float red[4];
+  const float* r = rep + (size_t)blockIdx.x * V;
+  int cnt = 0;
+  for (int v = threadIdx.x; v < V; v += 256) cnt += r[v] != 0.f;
+  const float tot = block_sum_256((float)cnt, red);
+  if (threadIdx.x == 0) rowkeep[blockIdx.x] = tot > (float)thr ? 1.f : 0.f;
+}
+// grid (ceil(V/256), g): colmean[j,v] = sum_i keep * |rep[i*g+j, v]| / n ; value += sum colmean^2
+__global__ __launch_bounds__(256) void flops_colmean_kernel(const float* __restrict__ rep, const float* __restrict__ rowkeep,
+                                                            int n, int g, int V, float* __restrict__ colmean, float* __restrict__ value) {
+  __shared__ float red[4];
+  const int v = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  float s = 0.f;
+  if (v < V) {
+    for (int i = 0; i < n; ++i) {
+      const int row = i * g + j;
+      const float k = rowkeep ? rowkeep[row] : 1.f;
+      s += k * fabsf(rep[(size_t)row * V + v]);
+    }
+    s /= (float)n;
+    colmean[(size_t)j * V + v] = s;
+  }
+  const float tot = block_sum_256(v < V ? s * s : 0.f, red);
+  if (threadIdx.x == 0) atomicAdd(value, tot);
+}
+__global__ __launch_bounds__(256) void flops_bwd_kernel(const float* __restrict__ rep, const float* __restrict__ colmean,
+                                                        const float* __restrict__ rowkeep, const float* __restrict__ gscale,
+                                                        int n, int g, int V, int row0, float* __restrict__ grad, int accumulate) {
+  const int lr = blockIdx.y, row = row0 + lr, j = row % g;
+  const float coef = gscale[0] * 2.f / (float)n * (rowkeep ? rowkeep[row] : 1.f);
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+    const float x = rep[(size_t)row * V + v];
+    const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    const float gv = coef * colmean[(size_t)j * V + v] * sg;
+    const size_t o = (size_t)lr * V + v;
+    grad[o] = accumulate ? grad[o] + gv : gv;
+  }
+}
+
+// ---- dense score matrices -----------------------------------------------------------------
+// all pairs: 16 x 16 score tile per block, q / d chunks of 64 columns staged in LDS
+__global__ __launch_bounds__(256) void scores_all_kernel(const float* __restrict__ q, const float* __restrict__ d, int nq,
+                                                         int nd, int D, float* __restrict__ scores) {
+  __shared__ float sq_[16][65], sd_[16][65];
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < D; c0 += 64) {
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      sq_[r][c] = (i0 + r < nq && c0 + c < D) ? q[(size_t)(i0 + r) * D + c0 + c] : 0.f;
+      sd_[r][c] = (j0 + r < nd && c0 + c < D) ? d[(size_t)(j0 + r) * D + c0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) acc += sq_[ti][c] * sd_[tj][c];
+    __syncthreads();
+  }
+  if (i0 + ti < nq && j0 + tj < nd) scores[(size_t)(i0 + ti) * nd + j0 + tj] = acc;
+}
+// block diagonal (torch.bmm form): one wave per (query, its jj-th doc)
+__global__ __launch_bounds__(256) void scores_pairs_kernel(const float* __restrict__ q, const float* __restrict__ d, int nq,
+                                                           int k, int D, float* __restrict__ scores) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= nq * k) return;
+  const float* qr = q + (size_t)(pair / k) * D;
+  const float* dr = d + (size_t)pair * D;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) acc += qr[c] * dr[c];
+  acc = wave_sum(acc);
+  if (lane == 0) scores[pair] = acc;
+}
+// out[i, c] (+)= sum_j w[i,j] x[j,c]   (i in a tile of 16 rows, c across threads); w element (i,j)
+// is read as w[i*ws_i + j*ws_j] so the same kernel serves dq = ds.d and dd = ds^T.q
+__global__ __launch_bounds__(256) void wsum_rows_kernel(const float* __restrict__ w, long ws_i, long ws_j, const float* __restrict__ x,
+                                                        int ni, int nj, int D, float* __restrict__ out, int accumulate) {
+  __shared__ float sw[16][64];
+  const int i0 = blockIdx.y * 16;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j0 = 0; j0 < nj; j0 += 64) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int r = idx >> 6, jj = idx & 63;
+      sw[r][jj] = (i0 + r < ni && j0 + jj < nj) ? w[(size_t)(i0 + r) * ws_i + (size_t)(j0 + jj) * ws_j] : 0.f;
+    }
+    __syncthreads();
+    if (c < D) {
+      const int jn = min(64, nj - j0);
+      for (int jj = 0; jj < jn; ++jj) {
+        const float xv = x[(size_t)(j0 + jj) * D + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sw[r][jj] * xv;
+      }
+    }
+  }
+  if (c < D)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (i0 + r < ni) {
+        const size_t o = (size_t)(i0 + r) * D + c;
+        out[o] = accumulate ? out[o] + acc[r] : acc[r];
+      }
+}
+// pairs backward: dq[i,c] (+)= sum_jj ds[i,jj] d[i*k+jj,c];  dd[i*k+jj,c] (+)= ds[i,jj] q[i,c]
+__global__ __launch_bounds__(256) void scores_pairs_bwd_kernel(const float* __restrict__ q, const float* __restrict__ d,
+                                                               const float* __restrict__ ds, int nq, int k, int D,
+                                                               float* __restrict__ dq, float* __restrict__ dd, int accumulate) {
+  const int i = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const float qv = q[(size_t)i * D + c];
+  float acc = 0.f;
+  for (int jj = 0; jj < k; ++jj) {
+    const float s = ds[i * k + jj];
+    const size_t o = (size_t)(i * k + jj) * D + c;
+    acc += s * d[o];
+    if (dd) dd[o] = accumulate ? dd[o] + s * qv : s * qv;
+  }
+  if (dq) {
+    const size_t o = (size_t)i * D + c;
+    dq[o] = accumulate ? dq[o] + acc : acc;
+  }
+}
+
+// ---- ranking losses: one wave per score row ------------------------------------------------
+__global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ scores, int nq, int ncols, int k, int pairs,
+                                                      float* __restrict__ loss, float* __restrict__ dscores) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nq) return;
+  const float* s = scores + (size_t)i * ncols;
+  float* g = dscores ? dscores + (size_t)i * ncols : nullptr;
+  const int pos = pairs ? 0 : i * k;
+  float mx = -INFINITY;
+  for (int c = lane; c < ncols; c += 64) {
+    const bool in = pairs || c == pos || (c % k) != 0;
+    if (in) mx = fmaxf(mx, s[c]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < ncols; c += 64) {
+    const bool in = pairs || c == pos || (c % k) != 0;
+    if (in) sum += __expf(s[c] - mx);
+  }
+  sum = wave_sum(sum);
+  const float lse = mx + __logf(sum);
+  if (lane == 0) atomicAdd(loss, (lse - s[pos]) / (float)nq);
+  if (g) {
+    const float inv = 1.f / (float)nq;
+    for (int c = lane; c < ncols; c += 64) {
+      const bool in = pairs || c == pos || (c % k) != 0;
+      float v = in ? __expf(s[c] - lse) : 0.f;
+      if (c == pos) v -= 1.f;
+      g[c] = v * inv;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void kldiv_kernel(const float* __restrict__ scores, const float* __restrict__ teacher, int nq,
+                                                    int ncols, float tau, float* __restrict__ loss, float* __restrict__ dscores) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nq) return;
+  const float* s = scores + (size_t)i * ncols;
+  const float* t = teacher + (size_t)i * ncols;
+  const float it = 1.f / tau;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int c = lane; c < ncols; c += 64) { ms = fmaxf(ms, s[c] * it); mt = fmaxf(mt, t[c] * it); }
+  ms = wave_max(ms);
+  mt = wave_max(mt);
+  float ss = 0.f, st = 0.f;
+  for (int c = lane; c < ncols; c += 64) { ss += __expf(s[c] * it - ms); st += __expf(t[c] * it - mt); }
+  ss = wave_sum(ss);
+  st = wave_sum(st);
+  const float lses = ms + __logf(ss), lset = mt + __logf(st);
+  float acc = 0.f;
+  for (int c = lane; c < ncols; c += 64) {
+    const float lt = t[c] * it - lset, ls = s[c] * it - lses;
+    const float pt = __expf(lt);
+    if (pt > 0.f) acc += pt * (lt - ls);
+    if (dscores) dscores[(size_t)i * ncols + c] = (__expf(ls) - pt) * it / (float)nq;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(loss, acc / (float)nq);
+}
+__global__ __launch_bounds__(256) void marginmse_kernel(const float* __restrict__ scores, const float* __restrict__ teacher, int nq,
+                                                        int ncols, float tau, float* __restrict__ loss, float* __restrict__ dscores) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nq) return;
+  const float* s = scores + (size_t)i * ncols;
+  const float* t = teacher + (size_t)i * ncols;
+  const float it = 1.f / tau;
+  const float cnt = (float)nq * (float)(ncols - 1);
+  const float s0 = s[0], t0 = t[0];
+  float acc = 0.f, g0 = 0.f;
+  for (int c = 1 + lane; c < ncols; c += 64) {
+    const float e = (s0 - s[c]) * it - (t0 - t[c]) * it;
+    acc += e * e;
+    const float gv = 2.f * e * it / cnt;
+    g0 += gv;
+    if (dscores) dscores[(size_t)i * ncols + c] = -gv;
+  }
+  acc = wave_sum(acc);
+  g0 = wave_sum(g0);
+  if (lane == 0) {
+    atomicAdd(loss, acc / cnt);
+    if (dscores) dscores[(size_t)i * ncols] = g0;
+  }
+}
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ scores, int nq, int ncols, float weight,
+                                                     float* __restrict__ accb, int accumulate) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nq) return;
+  const float* s = scores + (size_t)i * ncols;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int c = lane; c < ncols; c += 64) { mx = fmaxf(mx, s[c]); mn = fminf(mn, s[c]); }
+  mx = wave_max(mx);
+  mn = -wave_max(-mn);
+  const float inv = weight / (mx - mn + 1e-6f);
+  for (int c = lane; c < ncols; c += 64) {
+    const size_t o = (size_t)i * ncols + c;
+    const float v = (s[c] - mn) * inv;
+    accb[o] = accumulate ? accb[o] + v : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t,
+                                  const void* E, void* dt, float* dE, float* dbias, int B, int S, int H, int V, int use_l0,
+                                  void* stream) {
+  SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_bwd: empty problem");
+  SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
+  SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const int cpl = (H % 128 == 0) ? 2 : 1;
+  const int cw = 64 * cpl;
+  const size_t lds = (size_t)S * cw * 4;
+  SM_REQUIRE(lds <= 160 * 1024, "sm_sparse_head_bwd: S=%d too long for the LDS accumulator", S);
+#define LAUNCH_DT(T, CPL)                                                                                           \
+  do {                                                                                                              \
+    auto kern = head_dt_kernel<T, CPL>;                                                                             \
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL(kern, dim3(B, H / cw), dim3(256), lds, st, grad_rep, rep, argmax, (const T*)E, (T*)dt, S, H, V, use_l0); \
+  } while (0)
+  if (dtype == SM_BF16) { if (cpl == 2) LAUNCH_DT(bf16, 2); else LAUNCH_DT(bf16, 1); }
+  else { if (cpl == 2) LAUNCH_DT(float, 2); else LAUNCH_DT(float, 1); }
+#undef LAUNCH_DT
+  SM_LAUNCH_CHECK();
+  const int nc = H / 64;
+  dim3 grid(sm_cdiv(V, 16));
+#define LAUNCH_DE(T, NC) \
+  hipLaunchKernelGGL((head_de_kernel<T, NC>), grid, dim3(256), 0, st, grad_rep, rep, argmax, (const T*)t, dE, dbias, B, S, H, V, use_l0)
+#define DISPATCH_NC(T)                                                         \
+  switch (nc) {                                                                \
+    case 1: LAUNCH_DE(T, 1); break;                                            \
+    case 2: LAUNCH_DE(T, 2); break;                                            \
+    case 4: LAUNCH_DE(T, 4); break;                                            \
+    case 6: LAUNCH_DE(T, 6); break;                                            \
+    case 8: LAUNCH_DE(T, 8); break;                                            \
+    case 12: LAUNCH_DE(T, 12); break;                                          \
+    case 16: LAUNCH_DE(T, 16); break;                                          \
+    default: SM_REQUIRE(false, "sm_sparse_head_bwd: H=%d unsupported", H);     \
+  }
+  if (dtype == SM_BF16) { DISPATCH_NC(bf16) } else { DISPATCH_NC(float) }
+#undef DISPATCH_NC
+#undef LAUNCH_DE
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream) {
+  SM_REQUIRE(B > 0 && V > 0, "sm_prune_rows: empty problem");
+  hipLaunchKernelGGL(prune_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rep, V, prune_ratio);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special, int n_special,
+                               int V, float* out, void* stream) {
+  SM_REQUIRE(bs > 0 && sq > 0 && V > 0, "sm_inf_free_fwd: empty problem");
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)bs * V * sizeof(float), st));
+  const int n = bs * sq;
+  hipLaunchKernelGGL(inf_free_fwd_kernel, dim3(sm_cdiv(n, 256)), dim3(256), 0, st, ids, n, sq, idf, special, n_special, V, out);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_inf_free_bwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special, int n_special,
+                               int V, const float* grad_out, float* grad_idf, void* stream) {
+  SM_REQUIRE(bs > 0 && sq > 0 && V > 0, "sm_inf_free_bwd: empty problem");
+  const int n = bs * sq;
+  hipLaunchKernelGGL(inf_free_bwd_kernel, dim3(sm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, sq, idf, special,
+                     n_special, V, grad_out, grad_idf);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_flops_fwd(const float* rep, int rows, int g, int V, int thr, float* colmean, float* rowkeep, float* value,
+                            void* stream) {
+  SM_REQUIRE(rows > 0 && g > 0 && rows % g == 0 && V > 0, "sm_flops_fwd: rows=%d must be a positive multiple of g=%d", rows, g);
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipMemsetAsync(value, 0, sizeof(float), st));
+  const float* keep = nullptr;
+  if (thr >= 0) {
+    SM_REQUIRE(rowkeep != nullptr, "sm_flops_fwd: rowkeep workspace required with a threshold");
+    hipLaunchKernelGGL(flops_rowkeep_kernel, dim3(rows), dim3(256), 0, st, rep, V, thr, rowkeep);
+    keep = rowkeep;
+  }
+  hipLaunchKernelGGL(flops_colmean_kernel, dim3(sm_cdiv(V, 256), g), dim3(256), 0, st, rep, keep, rows / g, g, V, colmean, value);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_flops_bwd(const float* rep, const float* colmean, const float* rowkeep, const float* gscale, int rows, int g,
+                            int V, int row0, int nrows, float* grad_rep, int accumulate, void* stream) {
+  SM_REQUIRE(rows > 0 && g > 0 && rows % g == 0 && nrows > 0 && row0 >= 0 && row0 + nrows <= rows, "sm_flops_bwd: bad row range");
+  int gx = sm_cdiv(V, 256);
+  if (gx > 32) gx = 32;
+  hipLaunchKernelGGL(flops_bwd_kernel, dim3(gx, nrows), dim3(256), 0, (hipStream_t)stream, rep, colmean, rowkeep, gscale, rows / g,
+                     g, V, row0, grad_rep, accumulate);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pairs, float* scores, void* stream) {
+  SM_REQUIRE(nq > 0 && nd > 0 && D > 0, "sm_scores_fwd: empty problem");
+  hipStream_t st = (hipStream_t)stream;
+  if (pairs) {
+    SM_REQUIRE(nd % nq == 0, "sm_scores_fwd: nd=%d must be a multiple of nq=%d", nd, nq);
+    hipLaunchKernelGGL(scores_pairs_kernel, dim3(sm_cdiv(nd, 4)), dim3(256), 0, st, q, d, nq, nd / nq, D, scores);
+  } else {
+    hipLaunchKernelGGL(scores_all_kernel, dim3(sm_cdiv(nd, 16), sm_cdiv(nq, 16)), dim3(256), 0, st, q, d, nq, nd, D, scores);
+  }
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_scores_bwd(const float* q, const float* d, const float* ds, int nq, int nd, int D, int pairs, float* dq,
+                             float* dd, int accumulate, void* stream) {
+  SM_REQUIRE(nq > 0 && nd > 0 && D > 0, "sm_scores_bwd: empty problem");
+  hipStream_t st = (hipStream_t)stream;
+  if (pairs) {
+    SM_REQUIRE(nd % nq == 0, "sm_scores_bwd: nd=%d must be a multiple of nq=%d", nd, nq);
+    hipLaunchKernelGGL(scores_pairs_bwd_kernel, dim3(sm_cdiv(D, 256), nq), dim3(256), 0, st, q, d, ds, nq, nd / nq, D, dq, dd, accumulate);
+  } else {
+    if (dq) hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nq, 16)), dim3(256), 0, st, ds, (long)nd, 1L, d, nq, nd, D, dq, accumulate);
+    if (dd) hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nd, 16)), dim3(256), 0, st, ds, 1L, (long)nd, q, nd, nq, D, dd, accumulate);
+  }
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_infonce_fwd_bwd(const float* scores, int nq, int ncols, int k, int pairs, float* loss, float* dscores,
+                                  void* stream) {
+  SM_REQUIRE(nq > 0 && ncols > 0 && k > 0, "sm_infonce_fwd_bwd: empty problem");
+  SM_REQUIRE(pairs ? ncols == k : ncols == nq * k, "sm_infonce_fwd_bwd: ncols=%d inconsistent with nq=%d k=%d pairs=%d", ncols, nq, k, pairs);
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st));
+  hipLaunchKernelGGL(infonce_kernel, dim3(sm_cdiv(nq, 4)), dim3(256), 0, st, scores, nq, ncols, k, pairs, loss, dscores);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_kldiv_fwd_bwd(const float* scores, const float* teacher, int nq, int ncols, float temperature, float* loss,
+                                float* dscores, void* stream) {
+  SM_REQUIRE(nq > 0 && ncols > 0 && temperature > 0.f, "sm_kldiv_fwd_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st));
+  hipLaunchKernelGGL(kldiv_kernel, dim3(sm_cdiv(nq, 4)), dim3(256), 0, st, scores, teacher, nq, ncols, temperature, loss, dscores);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_marginmse_fwd_bwd(const float* scores, const float* teacher, int nq, int ncols, float temperature, float* loss,
+                                    float* dscores, void* stream) {
+  SM_REQUIRE(nq > 0 && ncols > 1 && temperature > 0.f, "sm_marginmse_fwd_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), st));
+  hipLaunchKernelGGL(marginmse_kernel, dim3(sm_cdiv(nq, 4)), dim3(256), 0, st, scores, teacher, nq, ncols, temperature, loss, dscores);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_minmax_accumulate(const float* scores, int nq, int ncols, float weight, float* acc, int accumulate, void* stream) {
+  SM_REQUIRE(nq > 0 && ncols > 0, "sm_minmax_accumulate: empty problem");
+  hipLaunchKernelGGL(minmax_kernel, dim3(sm_cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, scores, nq, ncols, weight, acc, accumulate);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

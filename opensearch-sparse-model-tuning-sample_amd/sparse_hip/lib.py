@@ -1,0 +1,130 @@
+"""ctypes binding of libsparse_hip.so (C ABI: include/sparse_hip.h).
+
+This is the stub a maintainer of the reference would add next to ``scripts/``: every
+function takes raw device pointers (``tensor.data_ptr()``) plus sizes and the current HIP
+stream.  There is NO fallback: if the shared object is missing or a call fails the
+binding raises, so a silently slower/incorrect path can never be taken.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
+
+SM_F32, SM_BF16 = 0, 1
+
+
+class SmDropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32)]
+
+
+class SmEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p),
+        ("act", C.c_int),
+        ("preact", C.c_void_p),
+        ("drop", SmDropout),
+        ("residual", C.c_void_p),
+        ("gelu_grad_of", C.c_void_p),
+    ]
+
+
+_p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+# name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
+SIGNATURES = {
+    "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
+    "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
+    "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
+    "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _p],
+    "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "sm_dropout_bwd": [_i, _p, _p, _l, C.POINTER(SmDropout), _p],
+    "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
+    "sm_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
+    "sm_sparse_head_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sm_prune_rows": [_p, _i, _i, _f, _p],
+    "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
+    "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],
+    "sm_flops_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    "sm_flops_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "sm_scores_fwd": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "sm_scores_bwd": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
+    "sm_infonce_fwd_bwd": [_p, _i, _i, _i, _i, _p, _p, _p],
+    "sm_kldiv_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p],
+    "sm_marginmse_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p],
+    "sm_minmax_accumulate": [_p, _i, _i, _f, _p, _i, _p],
+    "sm_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
+    "sm_cast_weight": [_i, _p, _i, _i, _p, _i, _p, _i, _p],
+    "sm_axpby": [_f, _p, _f, _p, _p, _l, _p],
+}
+
+_lib = None
+
+
+class SparseHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise SparseHipError(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    lib.sm_last_error.restype = C.c_char_p
+    lib.sm_last_error.argtypes = []
+    lib.sm_abi_version.restype = C.c_int
+    lib.sm_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return ["sm_last_error", "sm_abi_version"] + list(SIGNATURES)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return SM_F32
+    if dt == torch.bfloat16:
+        return SM_BF16
+    raise SparseHipError(f"unsupported compute dtype {dt}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SparseHipError("sparse_hip kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise SparseHipError("sparse_hip kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def dropout(p: float = 0.0, seed: int = 0, site: int = 0) -> SmDropout:
+    return SmDropout(float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFF)
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise SparseHipError(f"{name} failed (rc={rc}): {lib.sm_last_error().decode()}")

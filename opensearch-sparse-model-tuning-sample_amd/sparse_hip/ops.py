@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (one function per kernel entry point).
+
+torch is used only to own device memory and the stream; all arithmetic happens inside
+libsparse_hip.so.  Every wrapper raises if a tensor is not on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+Tensor = torch.Tensor
+
+
+def _new(shape, dtype, like: Tensor) -> Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _drop_ref(drop):
+    return C.byref(drop) if drop is not None else None
+
+
+# ---------------------------------------------------------------- GEMMs
+def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
+            drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
+            gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None) -> Tensor:
+    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables)."""
+    M, K = A.shape
+    N = B.shape[0] if n is None else n
+    assert B.shape[1] == K and A.dtype == B.dtype
+    if out is None:
+        out = _new((M, N), A.dtype, A)
+    epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
+                       L.ptr(residual), L.ptr(gelu_grad_of))
+    L.call("sm_gemm_nt", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
+           out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())
+    return out
+
+
+def gemm_tn_acc(A: Tensor, B: Tensor, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
+    """out[N,Kc] += A[M,N]^T @ B[M,Kc] (fp32 accumulate); colsum[N] += A.sum(0)."""
+    M, N = A.shape
+    Kc = B.shape[1]
+    assert B.shape[0] == M and out.dtype == torch.float32 and tuple(out.shape) == (N, Kc)
+    L.call("sm_gemm_tn_acc", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
+           out.stride(0), M, N, Kc, L.ptr(colsum), L.stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------- LayerNorm / embeddings
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+    rows, H = x.shape
+    y = torch.empty_like(x)
+    mean = _new((rows,), torch.float32, x)
+    rstd = _new((rows,), torch.float32, x)
+    L.call("sm_layernorm_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+           L.ptr(rstd), rows, H, float(eps), L.stream_ptr())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
+                  drop: Optional[L.SmDropout] = None, want_drop: bool = False):
+    rows, H = x.shape
+    dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if want_drop else None
+    L.call("sm_layernorm_bwd", L.dtype_code(x.dtype), L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+           L.ptr(dx), L.ptr(dx_drop), _drop_ref(drop), L.ptr(dgamma), L.ptr(dbeta), rows, H, L.stream_ptr())
+    return dx, dx_drop
+
+
+def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tensor, beta: Tensor, eps: float,
+              drop: Optional[L.SmDropout] = None):
+    B, S = ids.shape
+    H = word.shape[1]
+    z = _new((B * S, H), word.dtype, word)
+    y = torch.empty_like(z)
+    mean = _new((B * S,), torch.float32, word)
+    rstd = _new((B * S,), torch.float32, word)
+    L.call("sm_embed_fwd", L.dtype_code(word.dtype), L.ptr(ids), L.ptr(word), L.ptr(pos), L.ptr(type0), L.ptr(gamma),
+           L.ptr(beta), L.ptr(z), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, S, H, float(eps), _drop_ref(drop),
+           L.stream_ptr())
+    return z, y, mean, rstd
+
+
+def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tensor):
+    B, S = ids.shape
+    H = dz.shape[1]
+    L.call("sm_embed_bwd", L.dtype_code(dz.dtype), L.ptr(dz), L.ptr(ids), L.ptr(gword), L.ptr(gpos), L.ptr(gtype0),
+           B, S, H, L.stream_ptr())
+
+
+def dropout_bwd(dy: Tensor, drop: L.SmDropout) -> Tensor:
+    dx = torch.empty_like(dy)
+    L.call("sm_dropout_bwd", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(dx), dy.numel(), C.byref(drop), L.stream_ptr())
+    return dx
+
+
+# ---------------------------------------------------------------- attention
+def attention_fwd(qkv: Tensor, keymask: Tensor, B: int, S: int, A: int, drop: Optional[L.SmDropout] = None):
+    H = qkv.shape[1] // 3
+    ctx = _new((B * S, H), qkv.dtype, qkv)
+    lse = _new((B, A, S), torch.float32, qkv)
+    L.call("sm_attention_fwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(keymask), L.ptr(ctx), L.ptr(lse), B, S, A,
+           H // A, _drop_ref(drop), L.stream_ptr())
+    return ctx, lse
+
+
+def attention_bwd(qkv: Tensor, keymask: Tensor, ctx: Tensor, dctx: Tensor, lse: Tensor, B: int, S: int, A: int,
+                  drop: Optional[L.SmDropout] = None) -> Tensor:
+    H = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    L.call("sm_attention_bwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(keymask), L.ptr(ctx), L.ptr(dctx),
+           L.ptr(lse), L.ptr(dqkv), B, S, A, H // A, _drop_ref(drop), L.stream_ptr())
+    return dqkv
+
+
+# ---------------------------------------------------------------- fused sparse head
+def sparse_head_fwd(t: Tensor, E: Tensor, bias: Tensor, mask: Tensor, B: int, S: int, V: int, use_l0: bool):
+    H = t.shape[1]
+    rep = _new((B, V), torch.float32, t)
+    argmax = _new((B, V), torch.int16, t)  # u16 payload
+    L.call("sm_sparse_head_fwd", L.dtype_code(t.dtype), L.ptr(t), L.ptr(E), L.ptr(bias), L.ptr(mask), L.ptr(rep),
+           L.ptr(argmax), B, S, H, V, int(use_l0), L.stream_ptr())
+    return rep, argmax
+
+
+def prune_rows(rep: Tensor, ratio: float) -> Tensor:
+    L.call("sm_prune_rows", L.ptr(rep), rep.shape[0], rep.shape[1], float(ratio), L.stream_ptr())
+    return rep
+
+
+def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E: Tensor, dE: Tensor, dbias: Tensor,
+                    B: int, S: int, V: int, use_l0: bool) -> Tensor:
+    H = t.shape[1]
+    dt = torch.empty_like(t)
+    L.call("sm_sparse_head_bwd", L.dtype_code(t.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(t), L.ptr(E),
+           L.ptr(dt), L.ptr(dE), L.ptr(dbias), B, S, H, V, int(use_l0), L.stream_ptr())
+    return dt
+
+
+# ---------------------------------------------------------------- [B,V] kernels
+def inf_free_fwd(ids: Tensor, idf: Tensor, special: Tensor) -> Tensor:
+    bs, sq = ids.shape
+    V = idf.shape[0]
+    out = _new((bs, V), torch.float32, idf)
+    L.call("sm_inf_free_fwd", L.ptr(ids), bs, sq, L.ptr(idf), L.ptr(special), special.numel(), V, L.ptr(out),
+           L.stream_ptr())
+    return out
+
+
+def inf_free_bwd(ids: Tensor, idf: Tensor, special: Tensor, grad_out: Tensor, grad_idf: Tensor):
+    bs, sq = ids.shape
+    L.call("sm_inf_free_bwd", L.ptr(ids), bs, sq, L.ptr(idf), L.ptr(special), special.numel(), idf.shape[0],
+           L.ptr(grad_out), L.ptr(grad_idf), L.stream_ptr())
+
+
+def flops_fwd(rep: Tensor, g: int, thr: Optional[int]):
+    rows, V = rep.shape
+    colmean = _new((g, V), torch.float32, rep)
+    rowkeep = _new((rows,), torch.float32, rep) if thr is not None else None
+    value = _new((1,), torch.float32, rep)
+    L.call("sm_flops_fwd", L.ptr(rep), rows, g, V, -1 if thr is None else int(thr), L.ptr(colmean), L.ptr(rowkeep),
+           L.ptr(value), L.stream_ptr())
+    return value, colmean, rowkeep
+
+
+def flops_bwd(rep: Tensor, colmean: Tensor, rowkeep: Optional[Tensor], gscale: Tensor, g: int, row0: int, nrows: int,
+              grad: Tensor, accumulate: bool):
+    rows, V = rep.shape
+    L.call("sm_flops_bwd", L.ptr(rep), L.ptr(colmean), L.ptr(rowkeep), L.ptr(gscale), rows, g, V, row0, nrows,
+           L.ptr(grad), int(accumulate), L.stream_ptr())
+
+
+def scores_fwd(q: Tensor, d: Tensor, pairs: bool) -> Tensor:
+    nq, D = q.shape
+    nd = d.shape[0]
+    out = _new((nq, nd // nq) if pairs else (nq, nd), torch.float32, q)
+    L.call("sm_scores_fwd", L.ptr(q), L.ptr(d), nq, nd, D, int(pairs), L.ptr(out), L.stream_ptr())
+    return out
+
+
+def scores_bwd(q: Tensor, d: Tensor, ds: Tensor, pairs: bool, dq: Optional[Tensor], dd: Optional[Tensor], accumulate: bool):
+    nq, D = q.shape
+    L.call("sm_scores_bwd", L.ptr(q), L.ptr(d), L.ptr(ds), nq, d.shape[0], D, int(pairs), L.ptr(dq), L.ptr(dd),
+           int(accumulate), L.stream_ptr())
+
+
+def infonce(scores: Tensor, k: int, pairs: bool, want_grad: bool = True):
+    nq, ncols = scores.shape
+    loss = _new((1,), torch.float32, scores)
+    ds = torch.empty_like(scores) if want_grad else None
+    L.call("sm_infonce_fwd_bwd", L.ptr(scores), nq, ncols, k, int(pairs), L.ptr(loss), L.ptr(ds), L.stream_ptr())
+    return loss, ds
+
+
+def kldiv(scores: Tensor, teacher: Tensor, temperature: float, want_grad: bool = True):
+    nq, ncols = scores.shape
+    loss = _new((1,), torch.float32, scores)
+    ds = torch.empty_like(scores) if want_grad else None
+    L.call("sm_kldiv_fwd_bwd", L.ptr(scores), L.ptr(teacher), nq, ncols, float(temperature), L.ptr(loss), L.ptr(ds),
+           L.stream_ptr())
+    return loss, ds
+
+
+def marginmse(scores: Tensor, teacher: Tensor, temperature: float, want_grad: bool = True):
+    nq, ncols = scores.shape
+    loss = _new((1,), torch.float32, scores)
+    ds = torch.empty_like(scores) if want_grad else None
+    L.call("sm_marginmse_fwd_bwd", L.ptr(scores), L.ptr(teacher), nq, ncols, float(temperature), L.ptr(loss), L.ptr(ds),
+           L.stream_ptr())
+    return loss, ds
+
+
+def minmax_accumulate(scores: Tensor, weight: float, acc: Tensor, accumulate: bool):
+    nq, ncols = scores.shape
+    L.call("sm_minmax_accumulate", L.ptr(scores), nq, ncols, float(weight), L.ptr(acc), int(accumulate), L.stream_ptr())
+
+
+# ---------------------------------------------------------------- optimiser / staging
+def adamw(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, step: int, grad_scale: float = 1.0):
+    L.call("sm_adamw", L.ptr(param), L.ptr(grad), L.ptr(m), L.ptr(v), param.numel(), float(lr), float(beta1),
+           float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), L.stream_ptr())
+
+
+def cast_weight(w: Tensor, out: Optional[Tensor], out_t: Optional[Tensor]):
+    rows, cols = w.shape
+    ref = out if out is not None else out_t
+    L.call("sm_cast_weight", L.dtype_code(ref.dtype), L.ptr(w), rows, cols, L.ptr(out),
+           out.stride(0) if out is not None else 0, L.ptr(out_t), out_t.stride(0) if out_t is not None else 0,
+           L.stream_ptr())
+
+
+def axpby(a: float, x: Optional[Tensor], b: float, y: Optional[Tensor], out: Tensor):
+    L.call("sm_axpby", float(a), L.ptr(x), float(b), L.ptr(y), L.ptr(out), out.numel(), L.stream_ptr())
