@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/sec of the neural-sparse fine-tuning step
+(BASELINE.json configs[1]: config_infonce.yaml recipe, v2-mini-shaped encoder, synthetic
+MS-MARCO triples, bs=32 x (1 pos + 15 negs), seq 128, bf16, dropout on, fused AdamW included).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimisation step over one batch per rank; batches are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with
+two extra objects: "roofline" (dominant kernel, timed live with HIP events on the launch
+stream) and "cpu_baseline" (the CPU oracle timed on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "opensearch-sparse-model-tuning-sample_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--bs", type=int, default=32)
+    ap.add_argument("--negs", type=int, default=15)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    return ap.parse_args()
+
+
+def build_trainer(args, device, rank):
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+
+    p = 0.0 if args.no_dropout else 0.1
+    cfg = BertConfigLite(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12,
+                         intermediate_size=1536, max_position_embeddings=512, hidden_dropout_prob=p,
+                         attention_probs_dropout_prob=p)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device=device, init_seed=0)
+    g = torch.Generator().manual_seed(7)
+    idf = torch.exp(torch.rand(cfg.vocab_size, generator=g) * (torch.log(torch.tensor(15.6 / 0.02))) + torch.log(torch.tensor(0.02)))
+    model = SparseModel(bb, idf=idf, use_l0=False)
+    k = args.negs + 1
+    n_batches = 4
+    ds = SyntheticTriplesDataset(args.bs * n_batches, k, args.seq, 32, cfg.vocab_size, seed=1234 + rank)
+    coll = PreTokenizedCollator()
+    margs = ModelArguments(model_name_or_path="random-init-v2-mini-shape", inf_free=True)
+    dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=200,
+                                  sample_num_one_query=args.negs, max_seq_length=args.seq, data_type="posnegs")
+    targs = TrainingArguments(output_dir="/tmp/sm_bench", per_device_train_batch_size=args.bs, max_steps=2000,
+                              learning_rate=2e-5, weight_decay=0.01, warmup_steps=200, logging_steps=10 ** 9, bf16=True)
+    trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
+                                 loss_functions=[LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1)])
+    batches = [trainer._prepare_inputs(coll([ds[b * args.bs + i] for i in range(args.bs)])) for b in range(n_batches)]
+    return trainer, cfg, batches
+
+
+class KernelTimer:
+    """HIP events around one kernel entry point, recorded on the stream it is launched on."""
+
+    def __init__(self, module, name):
+        self.module, self.name = module, name
+        self.orig = getattr(module, name)
+        self.events = []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(*a, **kw):
+            if not self.enabled:
+                return self.orig(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(*a, **kw)
+            e1.record()
+            self.events.append((e0, e1))
+            return out
+        setattr(self.module, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.module, self.name, self.orig)
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+
+
+def cpu_baseline(args):
+    """CPU oracle (the 'port') on a bounded sample of the same workload: the same model
+    shape, sequence length and 16 docs per query, but 2 queries per step so one step is
+    ~10-30 s of host work.  Forward + backward + AdamW, fp32, dropout on, all host threads."""
+    from oracle import sparse_oracle as O  # baseline leg only
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    oc = O.BertShape()
+    params = {k: v.requires_grad_(True) for k, v in O.init_params(oc, seed=0).items()}
+    g = torch.Generator().manual_seed(7)
+    idf = torch.exp(torch.rand(oc.vocab_size, generator=g) * 6.66 - 3.9)
+    nq, k = 2, args.negs + 1
+    ds = SyntheticTriplesDataset(nq, k, args.seq, 32, oc.vocab_size, seed=1234)
+    batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
+    lc = O.LossConfig(loss_types=("infonce",), use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=200)
+    m = {n: torch.zeros_like(v) for n, v in params.items()}
+    v2 = {n: torch.zeros_like(v) for n, v in params.items()}
+    q, d = batch["query"][0], batch["docs"][0]
+    times = []
+    for step in range(2):
+        t0 = time.perf_counter()
+        loss = O.compute_loss(params, oc, idf, [0, 100, 101, 102, 103], q["input_ids"], q["attention_mask"], d["input_ids"],
+                              d["attention_mask"], None, lc, step, dropout_p=0.1, gen=g)[0]
+        loss.backward()
+        with torch.no_grad():
+            for n, p in params.items():
+                if p.grad is not None:
+                    O.adamw_step(p, p.grad, m[n], v2[n], step + 1, 2e-5)
+                    p.grad = None
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return {"value": nq / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (torch fp32), same model/seq/docs-per-query, {nq} queries x {k} docs per step "
+                      f"(1/{args.bs // nq} of the GPU batch), best of 2 steps, {t:.1f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from sparse_hip import ops
+    trainer, cfg, batches = build_trainer(args, device, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with KernelTimer(ops, "sparse_head_fwd") as kt:
+        for i in range(args.warmup):
+            trainer.training_step(batches[i % len(batches)])
+        barrier()
+        kt.enabled = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.training_step(batches[i % len(batches)])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        head_ms = kt.mean_ms()
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    k = args.negs + 1
+    T = args.bs * k * args.seq
+    H, V = cfg.hidden_size, cfg.vocab_size
+    head_flops = 2.0 * T * H * V  # algorithmic FLOPs of one fused decoder launch (2THV)
+    achieved = head_flops / (head_ms * 1e-3)
+    peak = MFMA_PEAK[args.dtype]
+    result = {
+        "metric": "training samples/sec (q+1pos+15neg, seq128)",
+        "value": world * args.bs * args.steps / elapsed,
+        "unit": "samples/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic MS-MARCO-shaped triples, random-init weights",
+        "config": {"workload": "configs[1]: config_infonce.yaml recipe, v2-mini-shaped encoder (6L/384H/12A/1536I/V30522), "
+                               f"bs={args.bs} x (1 pos + {args.negs} negs), seq {args.seq}, inference-free queries, "
+                               "InfoNCE in-batch negatives + FLOPS, dropout " + ("off" if args.no_dropout else "0.1") + ", fused AdamW",
+                   "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"kernel": "sparse_head_fwd_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
+                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel_ms": head_ms},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

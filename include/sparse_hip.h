@@ -93,6 +93,9 @@ int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, fl
 /* elementwise y = dropout_bwd(dy) (used for the embedding dropout backward) */
 int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const sm_dropout* drop, void* stream);
 
+/* dx = dy * gelu'(x): backward of the MLM transform activation (hf:478) */
+int sm_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, long n, void* stream);
+
 /* ---- self-attention (hf:111-136 eager attention + hf:164-204) ------------------------
  * qkv: [B*S, 3H] packed (q | k | v), heads are contiguous dh-slices; keymask: [B,S] 1 = attend.
  * ctx: [B*S, H]; lse: [B, A, S] fp32 log-sum-exp of the scaled masked scores. */
@@ -164,6 +167,8 @@ int sm_cast_weight(int dtype, const float* w, int rows, int cols, void* out, int
                    int ld_out_t, void* stream);
 /* scalar helpers on device: out = a*x + b*y (all device scalars or arrays of n) */
 int sm_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
+/* x[i] *= s[0] * c with s a DEVICE scalar (autograd's upstream gradient): no host sync */
+int sm_scale_by(float* x, const float* s, float c, long n, void* stream);
 
 #ifdef __cplusplus
 }

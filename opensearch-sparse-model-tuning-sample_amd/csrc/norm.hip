@@ -166,6 +166,12 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
   }
 }
 
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_grad_f(to_f32<T>(x[i])));
+}
+
 inline int row_grid(int rows) {
   int g = sm_cdiv(rows, 4);
   return g > 2048 ? 2048 : g;
@@ -240,6 +246,17 @@ extern "C" int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const
   if (grid > 4096) grid = 4096;
   SM_DISPATCH(dtype, "sm_dropout_bwd",
               hipLaunchKernelGGL(dropout_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)dy, (T*)dx, n, d));
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, long n, void* stream) {
+  SM_REQUIRE(n > 0, "sm_gelu_bwd: n=%ld", n);
+  hipStream_t st = (hipStream_t)stream;
+  int grid = sm_cdiv(n, 256);
+  if (grid > 4096) grid = 4096;
+  SM_DISPATCH(dtype, "sm_gelu_bwd",
+              hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, (T*)dx, n));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -65,7 +65,21 @@ __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, cons
     out[i] = a * (x ? x[i] : 0.f) + b * (y ? y[i] : 0.f);
 }
 
+__global__ void scale_by_kernel(float* __restrict__ x, const float* __restrict__ s, float c, long n) {
+  const float f = s[0] * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= f;
+}
+
 }  // namespace
+
+extern "C" int sm_scale_by(float* x, const float* s, float c, long n, void* stream) {
+  SM_REQUIRE(n > 0, "sm_scale_by: n=%ld", n);
+  int grid = sm_cdiv(n, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scale_by_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, s, c, n);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
 
 extern "C" int sm_adamw(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, void* stream) {

@@ -1,0 +1,134 @@
+"""Configuration surface of the training entry point: the same three argument groups and
+the same flat YAML keys as the reference (scripts/args.py:16-96).  TrainingArguments is a
+small local dataclass with the HF fields this path reads, so no transformers import is
+needed on the hot path; unknown YAML keys (eval/BEIR options) are kept in ``extra``.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import List, Optional, Union
+
+import yaml
+
+
+@dataclass
+class DataTrainingArguments:
+    max_seq_length: int = 512
+    eval_max_seq_length: int = 512
+    train_file: Optional[str] = None
+    train_file_dir: Optional[str] = None
+    data_type: Optional[str] = "kd"
+    loss_types: List[str] = field(default_factory=lambda: ["kldiv"])
+    sample_num_one_query: int = 2
+    use_in_batch_negatives: bool = False
+    flops_d_lambda: float = 1e-3
+    flops_d_T: float = 10000
+    flops_q_lambda: Optional[float] = None
+    flops_q_T: Optional[float] = None
+    ranking_loss_weight: float = 1
+    kd_ensemble_teacher_kwargs: Optional[Union[dict, str]] = field(default_factory=dict)
+    idf_lr: Optional[float] = None
+    first_rank_thresh: int = 10000
+    flops_threshold: Optional[int] = None
+    swap_times: float = 0
+    temperature: float = 1.0
+    score_scale: float = 1.0
+    # synthetic-data knobs (no reference equivalent; used when train_file == "synthetic")
+    synthetic_samples: int = 4096
+    synthetic_query_len: int = 32
+
+
+@dataclass
+class ModelArguments:
+    inf_free: bool = True
+    model_name_or_path: Optional[str] = None
+    tokenizer_name: Optional[str] = None
+    idf_path: Optional[str] = None
+    idf_requires_grad: Optional[bool] = False
+    prune_ratio: Optional[float] = None
+    preprocess_func: Optional[str] = None
+    use_l0: bool = False
+
+    def __post_init__(self):
+        if self.tokenizer_name is None:
+            self.tokenizer_name = self.model_name_or_path
+        if self.idf_path == "null":
+            self.idf_path = None
+        if self.preprocess_func == "null":
+            self.preprocess_func = None
+
+
+@dataclass
+class TrainingArguments:
+    """The transformers.TrainingArguments fields the training step reads."""
+
+    output_dir: str = "output/test"
+    per_device_train_batch_size: int = 8
+    max_steps: int = 1000
+    learning_rate: float = 5e-5
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    lr_scheduler_type: str = "linear"
+    warmup_steps: int = 0
+    max_grad_norm: Optional[float] = None
+    logging_steps: int = 500
+    save_strategy: str = "steps"
+    save_steps: int = 500
+    save_safetensors: bool = True
+    seed: int = 42
+    fp16: bool = False
+    bf16: bool = False
+    dataloader_drop_last: bool = False
+    dataloader_num_workers: int = 0
+    log_level: str = "info"
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def compute_dtype(self):
+        import torch
+        # the reference's fp16 autocast maps to bf16 on MI355X (no loss scaler needed)
+        return torch.bfloat16 if (self.fp16 or self.bf16) else torch.float32
+
+    def get_process_log_level(self):
+        import logging
+        return getattr(logging, str(self.log_level).upper(), logging.INFO)
+
+
+def _split(raw: dict):
+    groups = []
+    used = set()
+    for cls in (ModelArguments, DataTrainingArguments, TrainingArguments):
+        names = {f.name for f in dataclasses.fields(cls)} - {"extra"}
+        kw = {k: raw[k] for k in raw if k in names}
+        used |= set(kw)
+        groups.append(kw)
+    groups[2]["extra"] = {k: v for k, v in raw.items() if k not in used}
+    return ModelArguments(**groups[0]), DataTrainingArguments(**groups[1]), TrainingArguments(**groups[2])
+
+
+def parse_yaml_file(path: str):
+    with open(path) as f:
+        raw = yaml.safe_load(f) or {}
+    return _split(raw)
+
+
+def parse_args(argv=None):
+    """``train_ir.py cfg.yaml`` or ``--key value`` pairs (reference: scripts/args.py:81-96)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) == 1 and argv[0].endswith((".yaml", ".yml")):
+        model_args, data_args, training_args = parse_yaml_file(os.path.abspath(argv[0]))
+    else:
+        raw = {}
+        it = iter(argv)
+        for tok in it:
+            if not tok.startswith("--"):
+                raise ValueError(f"unexpected argument {tok!r}")
+            raw[tok[2:]] = yaml.safe_load(next(it))
+        model_args, data_args, training_args = _split(raw)
+    os.makedirs(training_args.output_dir, exist_ok=True)
+    return model_args, data_args, training_args

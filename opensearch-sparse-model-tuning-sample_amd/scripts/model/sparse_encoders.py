@@ -1,0 +1,121 @@
+"""SparseModel: the neural-sparse (SPLADE-family) encoder of the reference
+(scripts/model/sparse_encoders.py:42-127) with its arithmetic on MI355X kernels.
+
+Same constructor arguments, attributes (``backbone``, ``tokenizer``, ``special_token_ids``,
+``vocab_size``, ``idf_vector``, ``idf_requires_grad``, ``prune_ratio``, ``use_l0``) and
+``forward(inf_free=False, **features) -> float32 [B, V]`` contract.  ``model_id`` is either
+a local HF checkpoint directory (config.json + weights [+ tokenizer files]) or an already
+built ``HipBertMLM`` backbone (random-init benchmarks).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional
+
+import torch
+
+from sparse_hip import functional as F
+from sparse_hip.encoder import HipBertMLM
+
+logger = logging.getLogger(__name__)
+
+BERT_SPECIAL_IDS = [100, 102, 0, 101, 103]  # [UNK] [SEP] [PAD] [CLS] [MASK] of bert-base-uncased
+
+
+class TextPreProcessors:
+    @staticmethod
+    def to_lower(texts):
+        return [t.lower() for t in texts]
+
+    @staticmethod
+    def blank_prefix(texts):
+        return [" " + t for t in texts]
+
+    @staticmethod
+    def blank_prefix_lower(texts):
+        return [" " + t.lower() for t in texts]
+
+
+class TokenizerWithProcessing:
+    def __init__(self, original, process=None):
+        self._original = original
+        self.process = process
+
+    def __call__(self, text, **kwargs):
+        if self.process is not None:
+            text = self.process(list(text))
+        return self._original(text, **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self._original, name)
+
+
+def _load_tokenizer(tokenizer_id):
+    if tokenizer_id is None or not isinstance(tokenizer_id, str):
+        return tokenizer_id
+    has_files = os.path.isdir(tokenizer_id) and any(
+        os.path.exists(os.path.join(tokenizer_id, f)) for f in ("vocab.txt", "tokenizer.json", "tokenizer_config.json"))
+    if not has_files:
+        return None
+    import transformers  # host-side text plumbing only
+
+    return transformers.AutoTokenizer.from_pretrained(tokenizer_id)
+
+
+class SparseModel(torch.nn.Module):
+    def __init__(self, model_id, idf=None, tokenizer_id=None, idf_requires_grad=False, prune_ratio=None,
+                 preprocess_func=None, use_l0=True, compute_dtype: Optional[torch.dtype] = None, device=None):
+        super().__init__()
+        compute_dtype = compute_dtype or torch.bfloat16
+        if isinstance(model_id, HipBertMLM):
+            self.backbone = model_id
+        else:
+            self.backbone = HipBertMLM.from_pretrained(model_id, compute_dtype=compute_dtype, device=device)
+        if tokenizer_id is None and not isinstance(model_id, HipBertMLM):
+            tokenizer_id = model_id
+        self.tokenizer = _load_tokenizer(tokenizer_id)
+        if preprocess_func is not None and self.tokenizer is not None:
+            self.tokenizer = TokenizerWithProcessing(self.tokenizer, getattr(TextPreProcessors, preprocess_func))
+
+        if self.tokenizer is not None:
+            self.special_token_ids = [self.tokenizer.vocab[t] for t in self.tokenizer.special_tokens_map.values()]
+            self.vocab_size = len(self.tokenizer.vocab)
+        else:  # token-id-only operation (synthetic / pre-tokenised data)
+            self.special_token_ids = list(BERT_SPECIAL_IDS)
+            self.vocab_size = self.backbone.config.vocab_size
+        emb_vocab = self.backbone.config.vocab_size
+        if emb_vocab != self.vocab_size:
+            logger.info("reset the vocab size from %d to %d", self.vocab_size, emb_vocab)
+            self.vocab_size = emb_vocab
+
+        idf_vector = torch.ones(self.vocab_size)
+        if idf is not None:
+            if isinstance(idf, dict):
+                if self.tokenizer is None:
+                    raise ValueError("an idf dict needs a tokenizer; pass a tensor/list indexed by token id instead")
+                for token, weight in idf.items():
+                    idf_vector[self.tokenizer._convert_token_to_id_with_added_voc(token)] = weight
+            else:
+                idf_vector = torch.as_tensor(idf, dtype=torch.float32).clone()
+        self.idf_vector = torch.nn.Parameter(idf_vector.to(self.backbone.device), requires_grad=bool(idf_requires_grad))
+        self.idf_requires_grad = idf_requires_grad
+        self.prune_ratio = prune_ratio
+        self.use_l0 = use_l0
+        self.register_buffer("_special", torch.tensor(self.special_token_ids, dtype=torch.int32,
+                                                      device=self.backbone.device), persistent=False)
+        logger.info("model prune ratio: %s, use l0: %s", self.prune_ratio, self.use_l0)
+
+    def forward(self, inf_free=False, **kwargs):
+        if inf_free:
+            return self._encode_inf_free(**kwargs)
+        return self._encode(**kwargs)
+
+    def _encode(self, **kwargs):
+        # reference: logits -> * mask -> max over seq -> log1p(relu) [-> log1p] [-> prune]; here
+        # one fused decoder kernel, the [B,S,V] logits are never materialised
+        return self.backbone.encode(kwargs["input_ids"], kwargs["attention_mask"], use_l0=self.use_l0,
+                                    prune_ratio=self.prune_ratio)
+
+    def _encode_inf_free(self, **kwargs):
+        return F.inf_free_encode(kwargs["input_ids"], self.idf_vector, self._special)

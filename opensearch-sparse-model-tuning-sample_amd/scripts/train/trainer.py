@@ -1,0 +1,343 @@
+"""ModelWrapper and SparseModelTrainer with the reference's surface
+(scripts/train/trainer.py:18-218) driving the MI355X kernels.
+
+The reference subclasses ``transformers.Trainer``; the step it executes
+(hf trainer.py:1740-1800: H2D copy -> compute_loss -> backward (+ DDP all-reduce) ->
+optimizer.step -> scheduler.step -> zero_grad -> log/save) is restated here as a small
+loop so that (i) the data-parallel gradient all-reduce runs on a side HIP stream over
+contiguous slices of the flat gradient buffer, overlapped with the rest of backward,
+(ii) AdamW is one fused kernel over the flat parameter buffer, and (iii) no step performs
+a device->host sync (the reference's per-step ``.item()`` at trainer.py:121 is replaced by
+a device-side moving average that is only read when a log line is due).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from sparse_hip import functional as F
+from sparse_hip import ops
+from ..utils import gather_rep
+
+logger = logging.getLogger(__name__)
+
+
+class ModelWrapper(torch.nn.Module):
+    """One dict in, (d_rep, q_rep) out -- reference trainer.py:18-49."""
+
+    def __init__(self, sparse_model, inf_free=True):
+        super().__init__()
+        self.sparse_model = sparse_model
+        self.inf_free = inf_free
+
+    def forward(self, inputs):
+        d_rep = self.sparse_model(inf_free=False, input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"])
+        q_rep = self.sparse_model(inf_free=self.inf_free, input_ids=inputs["q_input_ids"],
+                                  attention_mask=inputs["q_attention_mask"])
+        return d_rep, q_rep
+
+    def save(self, output_dir, **kwargs):
+        kwargs.pop("state_dict", None)
+        self.sparse_model.backbone.save_pretrained(output_dir, **kwargs)
+        tok = self.sparse_model.tokenizer
+        if tok is not None:
+            tok.save_pretrained(output_dir)
+        if self.sparse_model.idf_requires_grad:
+            idf_vector = self.sparse_model.idf_vector.detach().cpu()
+            idf_json = {}
+            for idx in idf_vector.nonzero().flatten().tolist():
+                key = tok._convert_id_to_token(idx) if tok is not None else str(idx)
+                idf_json[key] = float(idf_vector[idx])
+            with open(os.path.join(output_dir, "idf.json"), "w") as f:
+                json.dump(idf_json, f)
+
+
+class TrainerState:
+    def __init__(self):
+        self.global_step = 0
+
+
+class ProcessInfo:
+    """The slice of accelerate.Accelerator the reference reads (num_processes,
+    local_process_index, is_main_process, gather, unwrap_model)."""
+
+    def __init__(self, device):
+        on = dist.is_available() and dist.is_initialized()
+        self.num_processes = dist.get_world_size() if on else 1
+        self.process_index = dist.get_rank() if on else 0
+        self.local_process_index = int(os.environ.get("LOCAL_RANK", self.process_index)) if on else 0
+        # single-node launch: the reference indexes the gathered tensor by the LOCAL rank
+        if on and self.local_process_index != self.process_index:
+            raise RuntimeError("multi-node runs are not supported (gather_rep indexes by local rank, utils.py:21)")
+        self.is_main_process = self.process_index == 0
+        self.device = device
+
+    def gather(self, t):
+        return gather_rep(t.detach(), self)
+
+    def unwrap_model(self, model):
+        return model
+
+
+def linear_schedule_lr(step: int, base_lr: float, warmup: int, total: int) -> float:
+    """transformers.get_linear_schedule_with_warmup (train_ir.py:103-107) at optimiser step `step`."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    return base_lr * max(0.0, (total - step) / max(1, total - warmup))
+
+
+class SparseModelTrainer:
+    def __init__(self, model_args, data_args, loss_functions, **kwargs):
+        self.model_args = model_args
+        self.data_args = data_args
+        self.loss_functions = loss_functions
+        self.args = kwargs["args"]
+        sparse_model = kwargs["model"]
+        self.model = ModelWrapper(sparse_model, model_args.inf_free)
+        self.train_dataset = kwargs.get("train_dataset")
+        self.data_collator = kwargs.get("data_collator")
+        self.optimizer, self.lr_scheduler = kwargs.get("optimizers", (None, None)) or (None, None)
+        self.state = TrainerState()
+        self.accelerator = ProcessInfo(sparse_model.backbone.device)
+        self._ma = torch.zeros(1, device=sparse_model.backbone.device)  # device-side moving average
+        self._last = {}
+        self._adam = None
+        self._comm_stream = None
+        self._pending = []
+        if self.accelerator.num_processes > 1:
+            self._setup_grad_overlap()
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def ranking_loss_moving_avg(self) -> float:
+        return float(self._ma.item())
+
+    @ranking_loss_moving_avg.setter
+    def ranking_loss_moving_avg(self, value: float) -> None:
+        self._ma.fill_(float(value))
+
+    def flops_value(self, representation, group_num=1):
+        return F.flops_value(representation, group_num, self.data_args.flops_threshold)
+
+    def get_lambda(self, lambda_value, lambda_T):
+        if self.state.global_step >= lambda_T:
+            return lambda_value
+        step = self.state.global_step + 1
+        return lambda_value * (step / lambda_T) ** 2
+
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
+        if hasattr(self, "bi_encoder_teacher"):
+            inputs["scores"] = self.bi_encoder_teacher.get_scores_batch(
+                q_features_list=inputs["query"][1:], d_features_list=inputs["docs"][1:])
+        model_wrapper_input = {
+            "q_input_ids": inputs["query"][0]["input_ids"],
+            "q_attention_mask": inputs["query"][0]["attention_mask"],
+            "input_ids": inputs["docs"][0]["input_ids"],
+            "attention_mask": inputs["docs"][0]["attention_mask"],
+        }
+        d_rep, q_rep = model(model_wrapper_input)
+        d_rep = gather_rep(d_rep, self.accelerator)
+        q_rep = gather_rep(q_rep, self.accelerator)
+        if "scores" in inputs:
+            inputs["scores"] = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
+        d_flops = self.flops_value(d_rep, d_rep.shape[0] // q_rep.shape[0])
+        flops_loss = d_flops * self.get_lambda(self.data_args.flops_d_lambda, self.data_args.flops_d_T)
+        if not self.model_args.inf_free:
+            flops_loss = flops_loss + self.flops_value(q_rep) * self.get_lambda(
+                self.data_args.flops_q_lambda, self.data_args.flops_q_T)
+        ranking_loss = 0
+        for loss_function in self.loss_functions:
+            ranking_loss = ranking_loss + loss_function.get_loss(q_rep=q_rep, d_rep=d_rep, inputs=inputs)
+        # moving average kept on the device: ma = 0.01 * ranking + 0.99 * ma   (trainer.py:120-122)
+        rl = ranking_loss.detach().reshape(1).float()
+        ops.axpby(0.01, rl, 0.99, self._ma, self._ma)
+        loss = ranking_loss + flops_loss
+        outputs = {"q_rep": q_rep, "d_rep": d_rep}
+        self._last = {"d_flops": d_flops.detach(), "flops_loss": flops_loss.detach(), "d_rep": d_rep.detach()}
+        if self.state.global_step % self.args.logging_steps == 0:
+            self._log_step()
+        loss = loss * self.accelerator.num_processes  # DDP averages, trainer.py:139-141
+        return (loss, outputs) if return_outputs else loss
+
+    def _log_step(self):
+        d_rep = self._last["d_rep"]
+        nz = d_rep[d_rep > 0]
+        logger.info(
+            "Step %d. ranking loss moving avg:%s, d_flops: %s, flops_loss: %s avg doc length: %s",
+            self.state.global_step, self.ranking_loss_moving_avg, float(self._last["d_flops"]),
+            float(self._last["flops_loss"]), float((d_rep > 0).sum() / d_rep.shape[0]))
+        if nz.numel():
+            logger.info("nonzero entries: %s %s %s", float(nz.mean()), float(nz.mean()), float(nz.max()))
+
+    def _save(self, output_dir=None, state_dict=None):
+        output_dir = output_dir if output_dir is not None else self.args.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        logger.info("Saving model checkpoint to %s", output_dir)
+        if self.accelerator.is_main_process:
+            self.accelerator.unwrap_model(self.model).save(
+                output_dir, state_dict=state_dict, safe_serialization=getattr(self.args, "save_safetensors", True))
+
+    def set_bi_encoder_teacher(self, embedding_service=None):
+        from .bi_encoder_wrapper import BiEncoderWrapper
+
+        kw = self.data_args.kd_ensemble_teacher_kwargs
+        bb = self.model.sparse_model.backbone
+        self.bi_encoder_teacher = BiEncoderWrapper(
+            types=kw["types"], model_ids=kw["model_ids"], use_in_batch_negatives=self.data_args.use_in_batch_negatives,
+            score_scale=kw.get("score_scale", 30), embedding_service=embedding_service,
+            compute_dtype=bb.compute_dtype, device=bb.device)
+        self.bi_encoder_teacher.accelerator = self.accelerator
+
+    def get_train_dataloader(self):
+        if self.train_dataset is None:
+            raise ValueError("Trainer: training requires a train_dataset.")
+        from torch.utils.data import DataLoader, RandomSampler
+        from torch.utils.data.distributed import DistributedSampler
+
+        if self.accelerator.num_processes > 1 and not getattr(self.train_dataset, "no_prepare", False):
+            sampler = DistributedSampler(self.train_dataset, num_replicas=self.accelerator.num_processes,
+                                         rank=self.accelerator.process_index, shuffle=True, seed=self.args.seed,
+                                         drop_last=self.args.dataloader_drop_last)
+        else:
+            g = torch.Generator()
+            g.manual_seed(self.args.seed)
+            sampler = RandomSampler(self.train_dataset, generator=g)
+        return DataLoader(self.train_dataset, batch_size=self.args.per_device_train_batch_size, sampler=sampler,
+                          collate_fn=self.data_collator, drop_last=self.args.dataloader_drop_last,
+                          num_workers=self.args.dataloader_num_workers, pin_memory=True)
+
+    # ------------------------------------------------------------------ step driver
+    def _prepare_inputs(self, obj):
+        dev = self.accelerator.device
+        if isinstance(obj, torch.Tensor):
+            return obj.to(dev, non_blocking=True)
+        if isinstance(obj, dict) or hasattr(obj, "items"):
+            return {k: self._prepare_inputs(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [self._prepare_inputs(v) for v in obj]
+        return obj
+
+    def _setup_grad_overlap(self):
+        """Side-stream all-reduce of each layer's gradient slice as soon as backward has produced it."""
+        bb = self.model.sparse_model.backbone
+        self._comm_stream = torch.cuda.Stream(device=bb.device)
+        if not self.model_args.inf_free:
+            return  # the encoder runs twice per step (queries + docs): reduce once at the end instead
+        layout = bb._layout
+        names = [n for n, _ in layout]
+        self._slices = {}
+        for l in range(bb.config.num_hidden_layers):
+            first = next(n for n in names if n.startswith(f"bert.encoder.layer.{l}."))
+            last = [n for n in names if n.startswith(f"bert.encoder.layer.{l}.")][-1]
+            o0, _ = bb._offsets[first]
+            o1, s1 = bb._offsets[last]
+            n1 = 1
+            for d in s1:
+                n1 *= d
+            self._slices[l] = (o0, o1 + (n1 + 3) // 4 * 4)
+        o_cls, _ = bb._offsets["cls.predictions.transform.dense.weight"]
+        self._slices["head"] = (o_cls, bb.n_flat)
+        self._slices["emb"] = (0, self._slices[0][0])
+        bb._layer_hook = self._reduce_slice_async
+
+    def _reduce_slice_async(self, key):
+        bb = self.model.sparse_model.backbone
+        a, b = self._slices[key]
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            self._pending.append(dist.all_reduce(bb.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _finish_grad_reduce(self):
+        sm = self.model.sparse_model
+        bb = sm.backbone
+        if self.accelerator.num_processes == 1:
+            return
+        if bb._layer_hook is not None:
+            self._reduce_slice_async("emb")
+        else:
+            self._pending.append(dist.all_reduce(bb.flat_grad, op=dist.ReduceOp.SUM, async_op=True))
+        if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None:
+            self._pending.append(dist.all_reduce(sm.idf_vector.grad, op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def _optimizer_step(self):
+        sm = self.model.sparse_model
+        bb = sm.backbone
+        a = self.args
+        n = self.accelerator.num_processes
+        if self.optimizer is not None:  # caller-supplied torch optimiser (train_ir.py:85-107 style)
+            if n > 1:
+                bb.flat_grad.div_(n)
+            self.optimizer.step()
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            bb.mark_weights_dirty()
+            return
+        step = self.state.global_step  # scheduler has been stepped `step` times so far
+        lr = linear_schedule_lr(step, a.learning_rate, a.warmup_steps, a.max_steps)
+        if self._adam is None:
+            self._adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
+            if sm.idf_vector.requires_grad:
+                self._adam["im"] = torch.zeros_like(sm.idf_vector)
+                self._adam["iv"] = torch.zeros_like(sm.idf_vector)
+        ops.adamw(bb.flat_param, bb.flat_grad, self._adam["m"], self._adam["v"], lr, a.adam_beta1, a.adam_beta2,
+                  a.adam_epsilon, a.weight_decay, step + 1, 1.0 / n)
+        if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None:
+            idf_lr = self.data_args.idf_lr if self.data_args.idf_lr is not None else a.learning_rate
+            lr_i = linear_schedule_lr(step, idf_lr, a.warmup_steps, a.max_steps)
+            ops.adamw(sm.idf_vector.data, sm.idf_vector.grad, self._adam["im"], self._adam["iv"], lr_i, a.adam_beta1,
+                      a.adam_beta2, a.adam_epsilon, a.weight_decay, step + 1, 1.0 / n)
+        bb.mark_weights_dirty()
+
+    def zero_grad(self):
+        sm = self.model.sparse_model
+        sm.backbone.zero_grad()
+        if sm.idf_vector.grad is not None:
+            sm.idf_vector.grad.zero_()
+
+    def training_step(self, inputs) -> torch.Tensor:
+        """One optimisation step (hf trainer.py:1892-1963 + 1780-1797). Returns the detached loss."""
+        self.model.train()
+        bb = self.model.sparse_model.backbone
+        bb.set_dropout_seed(self.args.seed * 1000003 + self.state.global_step * 64 + self.accelerator.process_index)
+        loss = self.compute_loss(self.model, inputs)
+        loss.backward()
+        self._finish_grad_reduce()
+        self._optimizer_step()
+        self.zero_grad()
+        self.state.global_step += 1
+        return loss.detach()
+
+    def train(self):
+        a = self.args
+        dl = self.get_train_dataloader()
+        it = iter(dl)
+        epoch = 0
+        self.zero_grad()
+        loss = None
+        while self.state.global_step < a.max_steps:
+            try:
+                batch = next(it)
+            except StopIteration:
+                epoch += 1
+                if hasattr(dl.sampler, "set_epoch"):
+                    dl.sampler.set_epoch(epoch)
+                it = iter(dl)
+                batch = next(it)
+            loss = self.training_step(self._prepare_inputs(batch))
+            step = self.state.global_step
+            if step % a.logging_steps == 0:
+                logger.info("{'loss': %.4f, 'learning_rate': %.3e, 'step': %d}", float(loss),
+                            linear_schedule_lr(step, a.learning_rate, a.warmup_steps, a.max_steps), step)
+            if a.save_strategy == "steps" and a.save_steps and step % a.save_steps == 0:
+                self._save(os.path.join(a.output_dir, f"checkpoint-{step}"))
+        return loss

@@ -1,0 +1,454 @@
+"""BERT-MLM backbone of the sparse encoder, executed by libsparse_hip.so.
+
+Replaces ``transformers.BertForMaskedLM`` as used by the reference's
+``SparseModel.backbone`` (scripts/model/sparse_encoders.py:57-59,108): same parameter
+names and ``[out,in]`` layouts (so checkpoints round-trip with ``transformers``), but
+forward and backward are sequences of C-ABI kernel launches.
+
+Memory layout in HBM
+  * fp32 master parameters live in ONE flat buffer (``flat_param``); every HF-named
+    ``nn.Parameter`` is a view into it.  Within a layer q/k/v weights (and biases) are
+    adjacent, so the fused QKV weight ``[3H,H]`` is a view, not a copy.
+  * gradients live in one flat buffer with the same layout (``flat_grad``); each
+    parameter's ``.grad`` is a view.  Kernels *accumulate* into it (fp32 atomics), the
+    trainer zeroes it once per step, and the data-parallel all-reduce runs over
+    contiguous slices of it.
+  * compute-dtype staging copies (bf16, or fp32 in parity mode) of every GEMM weight and
+    of its transpose (for the input-gradient GEMMs) are refreshed once per optimiser step
+    by ``sync_weights()``; the word-embedding table is padded to a multiple of 128 rows.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+
+Tensor = torch.Tensor
+
+SUPPORTED_S = (32, 64, 128, 256)
+
+
+@dataclass
+class BertConfigLite:
+    """The BertConfig fields the path reads (config.json of the checkpoint)."""
+
+    vocab_size: int = 30522
+    hidden_size: int = 384
+    num_hidden_layers: int = 6
+    num_attention_heads: int = 12
+    intermediate_size: int = 1536
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    hidden_dropout_prob: float = 0.1
+    attention_probs_dropout_prob: float = 0.1
+    hidden_act: str = "gelu"
+    pad_token_id: int = 0
+
+    @staticmethod
+    def from_json(path: str) -> "BertConfigLite":
+        with open(path) as f:
+            raw = json.load(f)
+        fields = BertConfigLite.__dataclass_fields__
+        cfg = BertConfigLite(**{k: raw[k] for k in fields if k in raw})
+        if cfg.hidden_act != "gelu":
+            raise L.SparseHipError(f"hidden_act={cfg.hidden_act!r} unsupported (exact-erf gelu only)")
+        return cfg
+
+    def to_hf_dict(self) -> dict:
+        d = {k: getattr(self, k) for k in self.__dataclass_fields__}
+        d.update(model_type="bert", architectures=["BertForMaskedLM"], position_embedding_type="absolute",
+                 tie_word_embeddings=True)
+        return d
+
+
+def param_layout(cfg: BertConfigLite) -> List[Tuple[str, Tuple[int, ...]]]:
+    """HF parameter names and shapes in flat-buffer order (q,k,v adjacent)."""
+    H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    e = "bert.embeddings."
+    out += [(e + "word_embeddings.weight", (V, H)), (e + "position_embeddings.weight", (cfg.max_position_embeddings, H)),
+            (e + "token_type_embeddings.weight", (cfg.type_vocab_size, H)),
+            (e + "LayerNorm.weight", (H,)), (e + "LayerNorm.bias", (H,))]
+    for l in range(cfg.num_hidden_layers):
+        p = f"bert.encoder.layer.{l}."
+        out += [(p + "attention.self.query.weight", (H, H)), (p + "attention.self.key.weight", (H, H)),
+                (p + "attention.self.value.weight", (H, H)),
+                (p + "attention.self.query.bias", (H,)), (p + "attention.self.key.bias", (H,)),
+                (p + "attention.self.value.bias", (H,)),
+                (p + "attention.output.dense.weight", (H, H)), (p + "attention.output.dense.bias", (H,)),
+                (p + "attention.output.LayerNorm.weight", (H,)), (p + "attention.output.LayerNorm.bias", (H,)),
+                (p + "intermediate.dense.weight", (I, H)), (p + "intermediate.dense.bias", (I,)),
+                (p + "output.dense.weight", (H, I)), (p + "output.dense.bias", (H,)),
+                (p + "output.LayerNorm.weight", (H,)), (p + "output.LayerNorm.bias", (H,))]
+    c = "cls.predictions."
+    out += [(c + "transform.dense.weight", (H, H)), (c + "transform.dense.bias", (H,)),
+            (c + "transform.LayerNorm.weight", (H,)), (c + "transform.LayerNorm.bias", (H,)), (c + "bias", (V,))]
+    return out
+
+
+def _attach(root: torch.nn.Module, dotted: str, param: torch.nn.Parameter) -> None:
+    mod = root
+    parts = dotted.split(".")
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, torch.nn.Module())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], param)
+
+
+class _Site:
+    EMB, ATTN, HID1, HID2 = 0, 1, 2, 3
+
+
+class HipBertMLM(torch.nn.Module):
+    """BertForMaskedLM-shaped module whose math runs in libsparse_hip.so."""
+
+    def __init__(self, cfg: BertConfigLite, compute_dtype: torch.dtype = torch.bfloat16,
+                 device: Optional[torch.device] = None, init_seed: Optional[int] = 0, with_head: bool = True):
+        super().__init__()
+        self.config = cfg
+        self.compute_dtype = compute_dtype
+        self.with_head = with_head
+        H = cfg.hidden_size
+        if H % 64 or H > 1024 or (H % 128 and H != 64):
+            raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
+        if H // cfg.num_attention_heads not in (32, 64):
+            raise L.SparseHipError(f"head dim {H // cfg.num_attention_heads} unsupported (32 or 64)")
+        if cfg.intermediate_size % 64:
+            raise L.SparseHipError("intermediate_size must be a multiple of 64")
+        device = torch.device(device if device is not None else "cuda")
+        self._layout = param_layout(cfg)
+        self._offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, shape in self._layout:
+            n = int(math.prod(shape))
+            self._offsets[name] = (off, shape)
+            off += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        self.n_flat = off
+        flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.register_buffer("flat_param", flat, persistent=False)
+        self.register_buffer("flat_grad", torch.zeros_like(flat), persistent=False)
+        for name, shape in self._layout:
+            o, _ = self._offsets[name]
+            n = int(math.prod(shape))
+            p = torch.nn.Parameter(flat[o:o + n].view(shape))
+            p.grad = self.flat_grad[o:o + n].view(shape)
+            _attach(self, name, p)
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._staged: Dict[str, Tensor] = {}
+        self._weights_dirty = True
+        self._drop_seed = 0x5EED
+        self._invocation = 0
+        if init_seed is not None:
+            self.reset_parameters(init_seed)
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def device(self) -> torch.device:
+        return self.flat_param.device
+
+    def view(self, name: str, grad: bool = False) -> Tensor:
+        o, shape = self._offsets[name]
+        n = int(math.prod(shape))
+        return (self.flat_grad if grad else self.flat_param)[o:o + n].view(shape)
+
+    def _span(self, first: str, last: str, grad: bool, shape) -> Tensor:
+        o0, _ = self._offsets[first]
+        o1, s1 = self._offsets[last]
+        buf = self.flat_grad if grad else self.flat_param
+        return buf[o0:o1 + int(math.prod(s1))].view(shape)
+
+    def qkv_weight(self, l: int, grad: bool = False) -> Tensor:
+        p = f"bert.encoder.layer.{l}.attention.self."
+        H = self.config.hidden_size
+        return self._span(p + "query.weight", p + "value.weight", grad, (3 * H, H))
+
+    def qkv_bias(self, l: int, grad: bool = False) -> Tensor:
+        p = f"bert.encoder.layer.{l}.attention.self."
+        return self._span(p + "query.bias", p + "value.bias", grad, (3 * self.config.hidden_size,))
+
+    def reset_parameters(self, seed: int = 0, std: float = 0.02) -> None:
+        """HF-style init: N(0, 0.02) weights, zero biases, LN weight 1 (generated on the host)."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, shape in self._layout:
+                if "LayerNorm.weight" in name:
+                    val = torch.ones(shape)
+                elif name.endswith("bias"):
+                    val = torch.zeros(shape)
+                else:
+                    val = torch.randn(shape, generator=g) * std
+                    if name.endswith("word_embeddings.weight"):
+                        val[self.config.pad_token_id].zero_()
+                self.view(name).copy_(val)
+        self._weights_dirty = True
+
+    def load_hf_state_dict(self, sd: Dict[str, Tensor]) -> None:
+        with torch.no_grad():
+            for name, _ in self._layout:
+                if name not in sd:
+                    if name == "cls.predictions.bias" and "cls.predictions.decoder.bias" in sd:
+                        src = sd["cls.predictions.decoder.bias"]
+                    else:
+                        raise L.SparseHipError(f"checkpoint is missing {name}")
+                else:
+                    src = sd[name]
+                self.view(name).copy_(torch.as_tensor(src, dtype=torch.float32))
+        self._weights_dirty = True
+
+    def hf_state_dict(self) -> Dict[str, Tensor]:
+        sd = {name: self.view(name).detach().cpu().clone() for name, _ in self._layout}
+        sd["cls.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+        sd["cls.predictions.decoder.bias"] = sd["cls.predictions.bias"]
+        return sd
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, compute_dtype=torch.bfloat16, device=None, with_head=True) -> "HipBertMLM":
+        cfg = BertConfigLite.from_json(os.path.join(model_dir, "config.json"))
+        model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head)
+        st = os.path.join(model_dir, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu")
+        if not any(k.startswith("bert.") for k in sd):  # bare BertModel checkpoint
+            sd = {"bert." + k: v for k, v in sd.items()}
+        if not with_head:
+            H, V = cfg.hidden_size, cfg.vocab_size
+            sd.setdefault("cls.predictions.transform.dense.weight", torch.zeros(H, H))
+            sd.setdefault("cls.predictions.transform.dense.bias", torch.zeros(H))
+            sd.setdefault("cls.predictions.transform.LayerNorm.weight", torch.ones(H))
+            sd.setdefault("cls.predictions.transform.LayerNorm.bias", torch.zeros(H))
+            sd.setdefault("cls.predictions.bias", torch.zeros(V))
+        model.load_hf_state_dict(sd)
+        return model
+
+    def save_pretrained(self, output_dir: str, state_dict=None, safe_serialization: bool = True, **_) -> None:
+        """HF-format checkpoint dir loadable by transformers.AutoModelForMaskedLM (trainer.py:37-49)."""
+        os.makedirs(output_dir, exist_ok=True)
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(self.config.to_hf_dict(), f, indent=2)
+        sd = self.hf_state_dict()
+        if safe_serialization:
+            from safetensors.torch import save_file
+            sd.pop("cls.predictions.decoder.weight")  # tied
+            sd.pop("cls.predictions.decoder.bias")
+            save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(output_dir, "model.safetensors"),
+                      metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(output_dir, "pytorch_model.bin"))
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: D401 - keeps .grad views alive
+        self.flat_grad.zero_()
+
+    def mark_weights_dirty(self) -> None:
+        self._weights_dirty = True
+
+    # ------------------------------------------------------------------ staging copies
+    def sync_weights(self) -> None:
+        """Refresh the compute-dtype copies (and transposes) of every GEMM weight."""
+        if not self._weights_dirty:
+            return
+        cfg, dt, dev = self.config, self.compute_dtype, self.device
+        H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        st = self._staged
+
+        def buf(key, shape):
+            if key not in st:
+                st[key] = torch.zeros(shape, dtype=dt, device=dev)
+            return st[key]
+
+        vpad = (V + 127) // 128 * 128
+        ops.cast_weight(self.view("bert.embeddings.word_embeddings.weight"), buf("E", (vpad, H)), None)
+        for l in range(cfg.num_hidden_layers):
+            p = f"bert.encoder.layer.{l}."
+            ops.cast_weight(self.qkv_weight(l), buf(f"qkv{l}", (3 * H, H)), buf(f"qkvT{l}", (H, 3 * H)))
+            ops.cast_weight(self.view(p + "attention.output.dense.weight"), buf(f"o{l}", (H, H)), buf(f"oT{l}", (H, H)))
+            ops.cast_weight(self.view(p + "intermediate.dense.weight"), buf(f"w1{l}", (I, H)), buf(f"w1T{l}", (H, I)))
+            ops.cast_weight(self.view(p + "output.dense.weight"), buf(f"w2{l}", (H, I)), buf(f"w2T{l}", (I, H)))
+        ops.cast_weight(self.view("cls.predictions.transform.dense.weight"), buf("t", (H, H)), buf("tT", (H, H)))
+        self._weights_dirty = False
+
+    # ------------------------------------------------------------------ forward / backward
+    @staticmethod
+    def padded_len(S: int) -> int:
+        for s in SUPPORTED_S:
+            if S <= s:
+                return s
+        raise L.SparseHipError(f"sequence length {S} > {SUPPORTED_S[-1]} is not supported in this build")
+
+    def _prep_inputs(self, input_ids: Tensor, attention_mask: Tensor):
+        B, S = input_ids.shape
+        Sp = self.padded_len(S)
+        if Sp > self.config.max_position_embeddings:
+            raise L.SparseHipError("padded sequence exceeds max_position_embeddings")
+        ids = input_ids.to(self.device, torch.int64)
+        mask = attention_mask.to(self.device).ne(0).to(torch.uint8)
+        if Sp != S:
+            ids = torch.nn.functional.pad(ids, (0, Sp - S), value=self.config.pad_token_id)
+            mask = torch.nn.functional.pad(mask, (0, Sp - S), value=0)
+        return ids.contiguous(), mask.contiguous(), B, Sp
+
+    def _drop(self, p: float, training: bool, seed: int, layer: int, kind: int):
+        if not training or p <= 0.0:
+            return None
+        return L.dropout(p, seed, layer * 4 + kind)
+
+    def _forward_impl(self, ids: Tensor, mask: Tensor, B: int, S: int, training: bool, seed: int, save: bool):
+        cfg = self.config
+        A, eps = cfg.num_attention_heads, cfg.layer_norm_eps
+        ph, pa = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
+        self.sync_weights()
+        st, v = self._staged, self.view
+        e = "bert.embeddings."
+        saved = {"layers": []} if save else None
+        d_emb = self._drop(ph, training, seed, 0, _Site.EMB)
+        z0, x, m0, r0 = ops.embed_fwd(ids, st["E"], v(e + "position_embeddings.weight"),
+                                      v(e + "token_type_embeddings.weight")[0], v(e + "LayerNorm.weight"),
+                                      v(e + "LayerNorm.bias"), eps, d_emb)
+        if save:
+            saved["emb"] = (z0, m0, r0)
+        for l in range(cfg.num_hidden_layers):
+            p = f"bert.encoder.layer.{l}."
+            d_at = self._drop(pa, training, seed, l + 1, _Site.ATTN)
+            d_h1 = self._drop(ph, training, seed, l + 1, _Site.HID1)
+            d_h2 = self._drop(ph, training, seed, l + 1, _Site.HID2)
+            qkv = ops.gemm_nt(x, st[f"qkv{l}"], bias=self.qkv_bias(l))
+            ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at)
+            z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x)
+            x1, m1, r1 = ops.layernorm_fwd(z1, v(p + "attention.output.LayerNorm.weight"),
+                                           v(p + "attention.output.LayerNorm.bias"), eps)
+            f1 = torch.empty((x1.shape[0], cfg.intermediate_size), dtype=x1.dtype, device=x1.device) if save else None
+            ga = ops.gemm_nt(x1, st[f"w1{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
+            z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=x1)
+            x2, m2, r2 = ops.layernorm_fwd(z2, v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias"), eps)
+            if save:
+                saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2))
+            x = x2
+        return x, saved
+
+    def hidden_states(self, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+        """Last hidden states [B,S,H] (no grad) -- used by frozen dense teachers."""
+        S0 = input_ids.shape[1]
+        ids, mask, B, S = self._prep_inputs(input_ids, attention_mask)
+        with torch.no_grad():
+            x, _ = self._forward_impl(ids, mask, B, S, False, 0, False)
+        return x.view(B, S, -1)[:, :S0].float()
+
+    def encode(self, input_ids: Tensor, attention_mask: Tensor, use_l0: bool = False,
+               prune_ratio: Optional[float] = None) -> Tensor:
+        """rep[B,V] = log1p(relu(max_l mask*logits)) (scripts/model/sparse_encoders.py:107-119)."""
+        ids, mask, B, S = self._prep_inputs(input_ids, attention_mask)
+        need_grad = torch.is_grad_enabled()
+        training = self.training and need_grad
+        self._invocation += 1
+        seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._invocation) & 0xFFFFFFFFFFFFFFFF
+        return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad)
+
+    def _reattach_grads(self) -> None:
+        """An external optimiser may have set .grad to None; restore the flat-buffer views."""
+        for name, _ in self._layout:
+            mod = self
+            parts = name.split(".")
+            for q in parts[:-1]:
+                mod = mod._modules[q]
+            p = mod._parameters[parts[-1]]
+            if p.grad is None:
+                p.grad = self.view(name, grad=True)
+
+    def set_dropout_seed(self, seed: int) -> None:
+        self._drop_seed = int(seed)
+        self._invocation = 0
+
+
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad):
+        cfg = model.config
+        x, saved = model._forward_impl(ids, mask, B, S, training, seed, need_grad)
+        v, st = model.view, model._staged
+        c = "cls.predictions."
+        ft = torch.empty_like(x) if need_grad else None
+        gt = ops.gemm_nt(x, st["t"], bias=v(c + "transform.dense.bias"), act=1, preact=ft)
+        tn, mt, rt = ops.layernorm_fwd(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
+                                       cfg.layer_norm_eps)
+        rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0)
+        if prune_ratio is not None:
+            ops.prune_rows(rep, prune_ratio)
+        if need_grad:
+            ctx.model, ctx.saved = model, saved
+            ctx.head = (x, ft, gt, mt, rt, tn, rep, argmax)
+            ctx.meta = (ids, mask, B, S, use_l0, training, seed)
+        return rep
+
+    @staticmethod
+    def backward(ctx, grad_rep):
+        model: HipBertMLM = ctx.model
+        cfg = model.config
+        ids, mask, B, S, use_l0, training, seed = ctx.meta
+        x_last, ft, gt, mt, rt, tn, rep, argmax = ctx.head
+        A = cfg.num_attention_heads
+        ph, pa = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
+        st = model._staged
+        v = model.view
+        g = lambda n: model.view(n, grad=True)
+        c = "cls.predictions."
+        e = "bert.embeddings."
+        grad_rep = grad_rep.contiguous().float()
+        dtn = ops.sparse_head_bwd(grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"),
+                                  B, S, cfg.vocab_size, use_l0)
+        dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
+                                   g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
+        dft = ops.gelu_bwd(dgt, ft)
+        ops.gemm_tn_acc(dft, x_last, g(c + "transform.dense.weight"), colsum=g(c + "transform.dense.bias"))
+        dx = ops.gemm_nt(dft, st["tT"])
+        if model._layer_hook is not None:
+            model._layer_hook("head")
+        for l in reversed(range(cfg.num_hidden_layers)):
+            p = f"bert.encoder.layer.{l}."
+            x, qkv, ctxt, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2 = ctx.saved["layers"][l]
+            d_at = model._drop(pa, training, seed, l + 1, _Site.ATTN)
+            d_h1 = model._drop(ph, training, seed, l + 1, _Site.HID1)
+            d_h2 = model._drop(ph, training, seed, l + 1, _Site.HID2)
+            dz2, dz2d = ops.layernorm_bwd(dx, z2, v(p + "output.LayerNorm.weight"), m2, r2,
+                                          g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"),
+                                          d_h2, want_drop=d_h2 is not None)
+            a2 = dz2d if d_h2 is not None else dz2
+            ops.gemm_tn_acc(a2, ga, g(p + "output.dense.weight"), colsum=g(p + "output.dense.bias"))
+            df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
+            ops.gemm_tn_acc(df1, x1, g(p + "intermediate.dense.weight"), colsum=g(p + "intermediate.dense.bias"))
+            dx1 = ops.gemm_nt(df1, st[f"w1T{l}"], residual=dz2)
+            dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                          g(p + "attention.output.LayerNorm.weight"),
+                                          g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
+            a1 = dz1d if d_h1 is not None else dz1
+            ops.gemm_tn_acc(a1, ctxt, g(p + "attention.output.dense.weight"), colsum=g(p + "attention.output.dense.bias"))
+            dctx = ops.gemm_nt(a1, st[f"oT{l}"])
+            dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at)
+            ops.gemm_tn_acc(dqkv, x, model.qkv_weight(l, grad=True), colsum=model.qkv_bias(l, grad=True))
+            dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
+            if model._layer_hook is not None:
+                model._layer_hook(l)
+        z0, m0, r0 = ctx.saved["emb"]
+        d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
+        if d_emb is not None:
+            dx = ops.dropout_bwd(dx, d_emb)
+        dz0, _ = ops.layernorm_bwd(dx, z0, v(e + "LayerNorm.weight"), m0, r0, g(e + "LayerNorm.weight"),
+                                   g(e + "LayerNorm.bias"))
+        ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),
+                      g(e + "token_type_embeddings.weight")[0])
+        ctx.saved = ctx.head = None
+        model._reattach_grads()
+        return (None,) * 11
+
+
+HipBertMLM._layer_hook = None

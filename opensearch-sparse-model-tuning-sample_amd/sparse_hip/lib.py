@@ -44,6 +44,7 @@ SIGNATURES = {
     "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _p],
     "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_dropout_bwd": [_i, _p, _p, _l, C.POINTER(SmDropout), _p],
+    "sm_gelu_bwd": [_i, _p, _p, _p, _l, _p],
     "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
     "sm_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
     "sm_sparse_head_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -62,6 +63,7 @@ SIGNATURES = {
     "sm_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
     "sm_cast_weight": [_i, _p, _i, _i, _p, _i, _p, _i, _p],
     "sm_axpby": [_f, _p, _f, _p, _p, _l, _p],
+    "sm_scale_by": [_p, _p, _f, _l, _p],
 }
 
 _lib = None

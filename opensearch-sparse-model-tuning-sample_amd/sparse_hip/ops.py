@@ -98,6 +98,12 @@ def dropout_bwd(dy: Tensor, drop: L.SmDropout) -> Tensor:
     return dx
 
 
+def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    dx = torch.empty_like(dy)
+    L.call("sm_gelu_bwd", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(x), L.ptr(dx), dy.numel(), L.stream_ptr())
+    return dx
+
+
 # ---------------------------------------------------------------- attention
 def attention_fwd(qkv: Tensor, keymask: Tensor, B: int, S: int, A: int, drop: Optional[L.SmDropout] = None):
     H = qkv.shape[1] // 3
@@ -232,6 +238,12 @@ def cast_weight(w: Tensor, out: Optional[Tensor], out_t: Optional[Tensor]):
     L.call("sm_cast_weight", L.dtype_code(ref.dtype), L.ptr(w), rows, cols, L.ptr(out),
            out.stride(0) if out is not None else 0, L.ptr(out_t), out_t.stride(0) if out_t is not None else 0,
            L.stream_ptr())
+
+
+def scale_by(x: Tensor, s: Tensor, c: float = 1.0) -> Tensor:
+    """x *= s[0] * c, s a device scalar (no host sync)."""
+    L.call("sm_scale_by", L.ptr(x), L.ptr(s.reshape(1)), float(c), x.numel(), L.stream_ptr())
+    return x
 
 
 def axpby(a: float, x: Optional[Tensor], b: float, y: Optional[Tensor], out: Tensor):

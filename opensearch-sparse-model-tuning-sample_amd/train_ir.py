@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Training entry point: ``torchrun --nproc_per_node=N train_ir.py cfg.yaml`` or
+``python train_ir.py cfg.yaml`` -- the reference's train_ir.py:30-150 launch contract on the
+MI355X kernels.  ``train_file: synthetic`` selects the built-in MS-MARCO-shaped generator."""
+import logging
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from scripts.args import parse_args  # noqa: E402
+from scripts.dataset.collator import COLLATOR_CLS_MAP  # noqa: E402
+from scripts.train.loss import LOSS_CLS_MAP  # noqa: E402
+from scripts.train.trainer import SparseModelTrainer  # noqa: E402
+from scripts.utils import get_model, set_logging  # noqa: E402
+
+logger = logging.getLogger(__name__)
+
+
+def init_distributed():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    return world, local
+
+
+def load_training_dataset(data_args, model):
+    if data_args.train_file == "synthetic":
+        from scripts.dataset.synthetic import SyntheticTriplesDataset
+
+        k = data_args.sample_num_one_query + 1 if data_args.data_type == "posnegs" else data_args.sample_num_one_query
+        return SyntheticTriplesDataset(data_args.synthetic_samples, k, data_args.max_seq_length,
+                                       data_args.synthetic_query_len, model.vocab_size,
+                                       with_scores=data_args.data_type == "kd" and not data_args.kd_ensemble_teacher_kwargs)
+    raise ValueError("only train_file: synthetic is wired in this build (text datasets are host-side plumbing: "
+                     "feed any torch Dataset yielding (query, pos, negs) / (query, docs, scores) to SparseModelTrainer)")
+
+
+def main():
+    model_args, data_args, training_args = parse_args()
+    world, local = init_distributed()
+    os.makedirs(training_args.output_dir, exist_ok=True)
+    if len(sys.argv) == 2 and sys.argv[1].endswith((".yaml", ".yml")) and local == 0:
+        shutil.copyfile(sys.argv[1], os.path.join(training_args.output_dir, "train_config.yaml"))
+    set_logging(training_args, "train.log")
+    torch.manual_seed(training_args.seed)
+
+    model = get_model(model_args, compute_dtype=training_args.compute_dtype)
+    collator_key = "synthetic" if data_args.train_file == "synthetic" else data_args.data_type
+    data_collator = COLLATOR_CLS_MAP[collator_key](
+        model.tokenizer, data_args.max_seq_length,
+        data_args.kd_ensemble_teacher_kwargs.get("teacher_tokenizer_ids", []))
+    loss_functions = [LOSS_CLS_MAP[t](use_in_batch_negatives=data_args.use_in_batch_negatives,
+                                      weight=data_args.ranking_loss_weight, temperature=data_args.temperature)
+                      for t in data_args.loss_types]
+    dataset = load_training_dataset(data_args, model)
+    trainer = SparseModelTrainer(model_args=model_args, data_args=data_args, model=model, args=training_args,
+                                 train_dataset=dataset, data_collator=data_collator, loss_functions=loss_functions)
+    if len(data_args.kd_ensemble_teacher_kwargs) != 0:
+        logger.info("Set bi-encoder teacher. %s", data_args.kd_ensemble_teacher_kwargs)
+        trainer.set_bi_encoder_teacher()
+    trainer.train()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

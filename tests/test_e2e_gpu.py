@@ -1,0 +1,264 @@
+"""GPU end-to-end parity: the reference-API mirror (SparseModel / losses / SparseModelTrainer)
+running on the HIP kernels against (a) golden vectors captured from the reference and
+(b) the CPU oracle on seeded mid-size inputs.  fp32 storage: 1e-3; bf16 storage: 1e-2
+(both relative to the tensor's scale, north_star tolerances)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sparse_oracle as O  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+SPECIAL = [0, 100, 101, 102, 103]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def close(got, want, tol, what=""):
+    got = torch.as_tensor(got).detach().float().cpu()
+    want = torch.as_tensor(want).detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol} * {scale:.3e}"
+
+
+def tiny_cfg(**kw):
+    from sparse_hip.encoder import BertConfigLite
+    base = dict(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    base.update(kw)
+    return BertConfigLite(**base)
+
+
+def tiny_backbone(dtype):
+    from sparse_hip.encoder import HipBertMLM
+    g1 = load("g1_encode.npz")
+    bb = HipBertMLM(tiny_cfg(), compute_dtype=dtype, device="cuda", init_seed=None)
+    bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
+    return bb
+
+
+def tiny_sparse_model(dtype, **kw):
+    from scripts.model.sparse_encoders import SparseModel
+    idf = torch.tensor(load("g2_inf_free.npz")["idf_vector"])
+    return SparseModel(tiny_backbone(dtype), idf=idf, **kw)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_g1_encode_matches_reference(dtype):
+    g = load("g1_encode.npz")
+    ids, mask = torch.tensor(g["input_ids"]).cuda(), torch.tensor(g["attention_mask"]).cuda()
+    for l0 in (0, 1):
+        for pr in (0, 1):
+            if pr and dtype == torch.bfloat16:
+                continue  # the prune threshold makes single entries flip under bf16 rounding
+            m = tiny_sparse_model(dtype, use_l0=bool(l0), prune_ratio=0.1 if pr else None)
+            m.train()
+            rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
+            close(rep, g[f"rep_l0{l0}_prune{pr}"], TOL[dtype], f"rep l0={l0} prune={pr}")
+            pre = f"grad_l0{l0}_prune{pr}/"
+            names = [k[len(pre):] for k in g.files if k.startswith(pre)]
+            if not names:
+                continue
+            m.backbone.zero_grad()
+            (rep * torch.tensor(g["upstream"]).cuda()).sum().backward()
+            for n in names:
+                if n.endswith("attention.self.key.bias"):
+                    continue  # mathematically zero gradient, pure rounding noise
+                close(m.backbone.view(n, grad=True), g[pre + n], TOL[dtype] * 2, "grad " + n)
+
+
+def _make_trainer(dtype, case):
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    mkw, dkw, lts = case
+    margs = ModelArguments(model_name_or_path="unused", **mkw)
+    dargs = DataTrainingArguments(loss_types=lts, **dkw)
+    targs = TrainingArguments(output_dir="/tmp/sm_test_out", per_device_train_batch_size=3, logging_steps=1000,
+                              learning_rate=1e-3, weight_decay=0.01, warmup_steps=2, max_steps=6)
+    model = tiny_sparse_model(dtype, use_l0=margs.use_l0, prune_ratio=margs.prune_ratio)
+    losses = [LOSS_CLS_MAP[t](use_in_batch_negatives=dargs.use_in_batch_negatives, weight=dargs.ranking_loss_weight,
+                              temperature=dargs.temperature) for t in lts]
+    return SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs, loss_functions=losses), model
+
+
+G6_CASES = {
+    "infonce_ibn": (dict(inf_free=True), dict(use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10), ["infonce"]),
+    "kldiv_l0": (dict(inf_free=True, use_l0=True), dict(use_in_batch_negatives=False, flops_d_lambda=0.08, flops_d_T=10, flops_threshold=150), ["kldiv"]),
+    "bienc_infonce_mse": (dict(inf_free=False), dict(use_in_batch_negatives=False, flops_d_lambda=0.01, flops_d_T=10, flops_q_lambda=0.02, flops_q_T=4, temperature=2.0, ranking_loss_weight=0.5), ["infonce", "marginmse"]),
+}
+
+
+def _inputs(g, prefix):
+    t = lambda k: torch.tensor(g[f"{prefix}/{k}"]).cuda()
+    inp = {"query": [{"input_ids": t("q_ids"), "attention_mask": t("q_mask")}],
+           "docs": [{"input_ids": t("d_ids"), "attention_mask": t("d_mask")}]}
+    if f"{prefix}/scores" in g.files:
+        inp["scores"] = t("scores")
+    return inp
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", list(G6_CASES))
+def test_g6_compute_loss_matches_reference(dtype, name):
+    g = load("g6_compute_loss.npz")
+    trainer, model = _make_trainer(dtype, G6_CASES[name])
+    trainer.model.train()
+    tol = TOL[dtype]
+    for step in (0, 5, 10, 25):
+        trainer.state.global_step = step
+        trainer.ranking_loss_moving_avg = 0
+        trainer.zero_grad()
+        loss, outputs = trainer.compute_loss(trainer.model, _inputs(g, name), return_outputs=True)
+        close(loss, g[f"{name}/loss_step{step}"], tol * 2, f"loss step {step}")
+        assert abs(trainer.ranking_loss_moving_avg - float(g[f"{name}/ranking_ma_step{step}"])) < tol
+        if step == 5:
+            close(outputs["q_rep"], g[f"{name}/q_rep"], tol, "q_rep")
+            close(outputs["d_rep"], g[f"{name}/d_rep"], tol, "d_rep")
+            loss.backward()
+            pre = f"{name}/grad/"
+            for k in [k for k in g.files if k.startswith(pre)]:
+                close(model.backbone.view(k[len(pre):], grad=True), g[k], tol * 2, "grad " + k[len(pre):])
+
+
+def test_g8_three_optimizer_steps_match_reference():
+    """fused AdamW (wd on all params) + linear warm-up + the full step driver, fp32 storage."""
+    g8 = load("g8_adamw.npz")
+    trainer, model = _make_trainer(torch.float32, G6_CASES["infonce_ibn"])
+    for step in range(3):
+        loss = trainer.training_step(_inputs(g8, f"step{step}"))
+        close(loss, g8[f"step{step}/loss"], 1e-3, f"loss step {step}")
+    bb = model.backbone
+    for k in [k for k in g8.files if k.startswith("final/")]:
+        close(bb.view(k[len("final/"):]), g8[k], 1e-3, k)
+    for k in [k for k in g8.files if k.startswith("sum/")]:
+        n = k[len("sum/"):]
+        if n.endswith("attention.self.key.bias"):
+            continue
+        a = bb.view(n).double().cpu().numpy()
+        ref_sum, ref_sq = float(g8[k]), float(g8["sumsq/" + n])
+        # parameters with (near-)zero gradients take +-lr Adam steps whose sign is rounding
+        # noise, so sums are compared with a budget of a few lr-sized flips per tensor
+        assert abs(a.sum() - ref_sum) < 2e-2 + 1e-3 * abs(ref_sum), n
+        assert abs((a * a).sum() - ref_sq) < 1e-3 * max(1.0, ref_sq), n
+
+
+def _mid_case(dtype, inf_free, ibn, loss_types, use_l0=False, thr=None, S=64):
+    """seeded mid-size batch through the HIP path and through the oracle"""
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    cfg = BertConfigLite(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                         max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    oc = O.BertShape(1000, 128, 2, 4, 256, 128)
+    p = O.init_params(oc, seed=3, std=0.08)
+    g = torch.Generator().manual_seed(5)
+    for k in p:
+        if k.endswith("bias"):
+            p[k] = 0.05 * torch.randn(p[k].shape, generator=g)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None)
+    bb.load_hf_state_dict(p)
+    idf = torch.exp(torch.rand(1000, generator=g) * 6 - 3)
+    model = SparseModel(bb, idf=idf, use_l0=use_l0)
+    nq, k = 3, 4
+    ds = SyntheticTriplesDataset(nq, k, S, 16, 1000, seed=11, with_scores=True)
+    batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
+    margs = ModelArguments(model_name_or_path="x", inf_free=inf_free, use_l0=use_l0)
+    dargs = DataTrainingArguments(loss_types=loss_types, use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
+                                  flops_q_lambda=0.03, flops_q_T=10, flops_threshold=thr)
+    if ibn and "infonce" not in loss_types:
+        batch["scores"] = torch.randn(nq, nq * k, generator=g) * 3
+    targs = TrainingArguments(output_dir="/tmp/sm_test_out", logging_steps=1000)
+    losses = [LOSS_CLS_MAP[t](use_in_batch_negatives=ibn, weight=1, temperature=1.0) for t in loss_types]
+    trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs, loss_functions=losses)
+    trainer.state.global_step = 4
+    trainer.model.train()
+    inp = trainer._prepare_inputs(batch)
+    trainer.zero_grad()
+    loss, out = trainer.compute_loss(trainer.model, inp, return_outputs=True)
+    loss.backward()
+    # oracle on the same inputs; weights rounded to the storage dtype like the staged copies
+    pr = {n: (v.to(dtype).float() if v.dim() == 2 and "embeddings.position" not in n and "token_type" not in n else v.clone()).requires_grad_(True)
+          for n, v in p.items()}
+    lc = O.LossConfig(loss_types=tuple(loss_types), use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
+                      flops_q_lambda=0.03, flops_q_T=10, flops_threshold=thr, inf_free=inf_free)
+    q, d = batch["query"][0], batch["docs"][0]
+    oloss, _, _, oq, od = O.compute_loss(pr, oc, idf, SPECIAL, q["input_ids"], q["attention_mask"], d["input_ids"],
+                                         d["attention_mask"], batch.get("scores"), lc, 4, use_l0=use_l0)
+    oloss.backward()
+    return loss, out, bb, oloss, oq, od, pr
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("inf_free,ibn,loss_types,use_l0,thr", [
+    (True, True, ["infonce"], False, None),
+    (True, False, ["kldiv"], True, 20),
+    (False, True, ["kldiv"], False, None),
+    (False, False, ["infonce", "marginmse"], False, None),
+])
+def test_mid_size_step_matches_oracle(dtype, inf_free, ibn, loss_types, use_l0, thr):
+    loss, out, bb, oloss, oq, od, pr = _mid_case(dtype, inf_free, ibn, loss_types, use_l0, thr)
+    tol = TOL[dtype]
+    close(out["d_rep"], od, tol, "d_rep")
+    close(out["q_rep"], oq, tol, "q_rep")
+    close(loss, oloss, tol * 2, "loss")
+    for n in ("bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+              "bert.embeddings.LayerNorm.weight", "bert.encoder.layer.0.attention.self.query.weight",
+              "bert.encoder.layer.0.attention.self.value.bias", "bert.encoder.layer.0.intermediate.dense.weight",
+              "bert.encoder.layer.1.output.dense.weight", "bert.encoder.layer.1.output.LayerNorm.bias",
+              "cls.predictions.transform.dense.weight", "cls.predictions.transform.LayerNorm.weight", "cls.predictions.bias"):
+        want = pr[n].grad if pr[n].grad is not None else torch.zeros_like(pr[n])
+        close(bb.view(n, grad=True), want, tol * 3, "grad " + n)
+
+
+def test_seq128_and_256_documents():
+    """longer documents (S=128: one doc per decoder tile, S=256: two tiles per doc), bf16"""
+    for S in (128, 256):
+        loss, out, bb, oloss, oq, od, pr = _mid_case(torch.bfloat16, True, True, ["infonce"], S=S)
+        close(out["d_rep"], od, 1e-2, f"d_rep S={S}")
+        close(loss, oloss, 2e-2, f"loss S={S}")
+
+
+def test_training_mode_dropout_is_seeded_and_finite():
+    from scripts.model.sparse_encoders import SparseModel
+    from sparse_hip.encoder import HipBertMLM
+    cfg = tiny_cfg(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    g = load("g1_encode.npz")
+    ids, mask = torch.tensor(g["input_ids"]).cuda(), torch.tensor(g["attention_mask"]).cuda()
+    reps, grads = [], []
+    for seed in (1, 1, 2):
+        bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=None)
+        bb.load_hf_state_dict({k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith("sd/")})
+        m = SparseModel(bb, use_l0=False)
+        m.train()
+        bb.set_dropout_seed(seed)
+        rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
+        rep.sum().backward()
+        reps.append(rep.detach().clone())
+        grads.append(bb.flat_grad.clone())
+        assert torch.isfinite(rep).all() and torch.isfinite(bb.flat_grad).all()
+    assert torch.equal(reps[0], reps[1]) and not torch.equal(reps[0], reps[2])
+    m.eval()
+    with torch.no_grad():
+        close(m(inf_free=False, input_ids=ids, attention_mask=mask), g["rep_l00_prune0"], 1e-2, "eval = no dropout")
+
+
+def test_product_path_refuses_cpu_tensors():
+    from sparse_hip import functional as F
+    from sparse_hip.lib import SparseHipError
+    with pytest.raises(SparseHipError):
+        F.flops_value(torch.ones(4, 8), 2)
