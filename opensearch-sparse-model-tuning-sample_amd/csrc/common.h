@@ -78,6 +78,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// d rep / d logit of the sparse activation as a function of rep itself
+// (rep = log1p(y), or log1p(log1p(y)) with the L0 activation; y = relu(max logit))
+__device__ __forceinline__ float head_fprime(float r, int use_l0) {
+  if (!(r > 0.f)) return 0.f;
+  return use_l0 ? __expf(-r - expm1f(r)) : __expf(-r);
+}
+
 // ---- counter-based dropout mask -------------------------------------------------
 // keep(element) = hash16(seed, site, element index) >= round(p * 65536).  Forward and
 // backward regenerate the same mask from (seed, site, element index), so no mask

@@ -107,7 +107,54 @@ __device__ __forceinline__ void nt_mainloop(const T* __restrict__ A, int lda, in
   }
 }
 
+constexpr int CS = 132;  // fp32 row stride (floats) of the LDS-staged C tile: 528 B, conflict-free
+
+// 8 consecutive elements <-> fp32 registers; `full` = whole 16-byte-aligned vector in range
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8], bool full, int nvalid);
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nvalid ? (float)p[k] : 0.f;
+  }
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nvalid ? p[k] : 0.f;
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8], bool full, int nvalid);
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    bf16x8 x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (bf16)v[k];
+    *reinterpret_cast<bf16x8*>(p) = x;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < nvalid) p[k] = (bf16)v[k];
+  }
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < nvalid) p[k] = v[k];
+  }
+}
+
 struct EpiArgs {
+  int vec_ok;  // ldc and every epilogue pointer allow 8-element vectors
   const float* bias;
   int act;
   void* preact;
@@ -119,7 +166,7 @@ struct EpiArgs {
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[128 * CS * 4 > 4 * TILE_BYTES ? 128 * CS * 4 : 4 * TILE_BYTES];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   f32x4 acc[4][4];
 #pragma unroll
@@ -128,32 +175,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
 
+  // Epilogue through LDS: the accumulators (MFMA C layout: 2-byte column fragments) are staged
+  // as an fp32 [128][CS] tile so that every global access of the epilogue -- C, preact, residual,
+  // gelu_grad_of, bias -- is a 16-byte row-contiguous vector (256 B per 16 lanes).
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sC[(wm * 64 + i * 16 + g * 4 + r) * CS + wn * 64 + j * 16 + li] = acc[i][j][r];
+  __syncthreads();
   T* preact = reinterpret_cast<T*>(e.preact);
   const T* residual = reinterpret_cast<const T*>(e.residual);
   const T* ggo = reinterpret_cast<const T*>(e.gelu_grad_of);
+  const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  const int col = n0 + c * 8;
+  if (col >= N) return;
+  const bool full = e.vec_ok && col + 8 <= N;
+  float bv[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wn * 64 + j * 16 + li;
-    if (col >= N) continue;
-    const float bv = e.bias ? e.bias[col] : 0.f;
+  for (int k = 0; k < 8; ++k) bv[k] = (e.bias && col + k < N) ? e.bias[col + k] : 0.f;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int rt = r0 + 16 * it, row = m0 + rt;
+    if (row >= M) break;
+    const size_t off = (size_t)row * ldc + col;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8 + 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int k = 0; k < 4; ++k) { v[k] = lo[k] + bv[k]; v[4 + k] = hi[k] + bv[4 + k]; }
+    if (preact) store8<T>(preact + off, v, full, N - col);
+    if (e.act == 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
-        if (row >= M) continue;
-        const size_t off = (size_t)row * ldc + col;
-        float v = acc[i][j][r] + bv;
-        if (preact) preact[off] = from_f32<T>(v);
-        if (e.act == 1) v = gelu_f(v);
-        if (e.drop.thresh16) v = drop_keep1(e.drop, (uint64_t)row * (uint64_t)N + col) ? v * e.drop.scale : 0.f;
-        if (residual) v += to_f32<T>(residual[off]);
-        if (ggo) v *= gelu_grad_f(to_f32<T>(ggo[off]));
-        C[off] = from_f32<T>(v);
-      }
+      for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
     }
+    if (e.drop.thresh16) {
+      const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = drop_keep1(e.drop, eb + k) ? v[k] * e.drop.scale : 0.f;
+    }
+    if (residual) {
+      float rv[8];
+      load8<T>(residual + off, rv, full, N - col);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += rv[k];
+    }
+    if (ggo) {
+      float xv[8];
+      load8<T>(ggo + off, xv, full, N - col);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(xv[k]);
+    }
+    store8<T>(C + off, v, full, N - col);
   }
 }
 
@@ -387,6 +464,127 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const T* __restrict__
   if (do_colsum && threadIdx.x < 128 && n0 + threadIdx.x < N) atomicAdd(&colsum[n0 + threadIdx.x], csum);
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward of the fused head w.r.t. the transform output: dt[T,H] = G[T,V] . E[V,H] where the
+// logit-gradient matrix G has ONE non-zero per (document, vocab column) -- at the arg-max
+// position -- and is never materialised: each K-step builds its [128 x BK] slice of G in LDS
+// straight from (grad_rep, rep, argmax) and feeds it to the MFMAs as the A operand, while the
+// E tile ([BK vocab rows][128 hidden cols], row-major as in HBM) comes out of LDS through the
+// transposing read like the weight-gradient kernel's operands.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
+                                                                const uint16_t* __restrict__ argmax, const T* __restrict__ E,
+                                                                T* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0) {
+  using MM = Mma<T>;
+  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
+  constexpr int ESTAGE = BK * Tn<T>::RS;
+  constexpr int TPC = NTHREADS / BK;   // threads sharing one vocab column of the G tile
+  constexpr int RPT = 128 / TPC;       // G rows written per thread
+  constexpr int MAXDOC = 8;            // 128 / 16
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 2 * ESTAGE];
+  char* const sG = smem;
+  char* const sE = smem + 2 * TILE_BYTES;
+  const int Ttot = Bdocs * S;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int ndoc = S >= 128 ? 1 : 128 / S;
+  const int b0 = m0 / S;
+  const int loff = S >= 128 ? m0 % S : 0;  // first sequence position covered by this tile
+  const int kk = threadIdx.x % BK, rg = threadIdx.x / BK;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Each (document-in-tile, vocab column) pair is owned by one thread: it SETS the single
+  // non-zero of that column in the next stage's G image and CLEARS the one it set two steps
+  // earlier in the same buffer, so a K-step costs two 2-byte LDS stores per pair, not a tile fill.
+  constexpr int NDT = MAXDOC / TPC > 0 ? MAXDOC / TPC : 1;  // pairs owned per thread and column
+  float gval[NDT];
+  int goff[NDT], prev0[NDT], prev1[NDT];
+#pragma unroll
+  for (int q = 0; q < NDT; ++q) { prev0[q] = -1; prev1[q] = -1; }
+  for (int i = threadIdx.x; i < 2 * TILE_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
+  uint4 re[4];
+  auto load_cols = [&](int k0) {
+    const int v = k0 + kk;
+    const int cb = kk * (int)sizeof(T);
+#pragma unroll
+    for (int q = 0; q < NDT; ++q) {
+      const int dd = rg + q * TPC;
+      gval[q] = 0.f;
+      goff[q] = -1;
+      if (dd < ndoc && v < V && b0 + dd < Bdocs) {
+        const size_t o = (size_t)(b0 + dd) * V + v;
+        const float gr = grad_rep[o] * head_fprime(rep[o], use_l0);
+        const int row = (int)argmax[o] - loff + dd * S;
+        if (gr != 0.f && row >= dd * S && row < 128) {
+          gval[q] = gr;
+          goff[q] = row * 128 + ((((cb >> 4) ^ (row & 7))) << 4) + (cb & 15);
+        }
+      }
+    }
+  };
+  auto write_g = [&](char* tile, int (&prev)[NDT]) {
+#pragma unroll
+    for (int q = 0; q < NDT; ++q) {
+      if (prev[q] >= 0) *reinterpret_cast<T*>(tile + prev[q]) = from_f32<T>(0.f);
+      if (goff[q] >= 0) *reinterpret_cast<T*>(tile + goff[q]) = from_f32<T>(gval[q]);
+      prev[q] = goff[q];
+    }
+  };
+
+  const int nk = (V + BK - 1) / BK;
+  __syncthreads();  // zero fill of both G images visible
+  load_cols(0);
+  g2r_tn<T>(E, H, 0, V, n0, H, re);
+  write_g(sG, prev0);
+  r2s_tn<T>(sE, re);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      load_cols((kt + 1) * BK);
+      g2r_tn<T>(E, H, (kt + 1) * BK, V, n0, H, re);
+    }
+    const char* a = sG + (kt & 1) * TILE_BYTES;
+    const char* b = sE + (kt & 1) * ESTAGE;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
+        fb[i] = Tn<T>::load(b, ks, wn * 64 + i * 16, g, li);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      if ((kt + 1) & 1) write_g(sG + TILE_BYTES, prev1);
+      else write_g(sG, prev0);
+      r2s_tn<T>(sE + ((kt + 1) & 1) * ESTAGE, re);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
+        if (row < Ttot && col < H) dt[(size_t)row * H + col] = from_f32<T>(acc[i][j][r]);
+      }
+    }
+}
+
 template <typename T>
 int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const sm_epilogue* epi, hipStream_t st) {
@@ -397,6 +595,9 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.drop = make_drop(epi ? &epi->drop : nullptr);
   e.residual = epi ? epi->residual : nullptr;
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  const uintptr_t vb = 8 * sizeof(T);
+  e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
+             ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
   dim3 grid(sm_cdiv(N, BN), sm_cdiv(M, BM));
   hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
   return 0;
@@ -467,6 +668,21 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   else if (dtype == SM_F32)
     hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
   else SM_REQUIRE(false, "sm_sparse_head_fwd: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+// dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
+int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
+                      int B, int S, int H, int V, int use_l0, hipStream_t st) {
+  SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0), "sm_sparse_head_bwd: S=%d unsupported", S);
+  SM_REQUIRE(H % 8 == 0, "sm_sparse_head_bwd: H=%d must be a multiple of 8", H);
+  const long T = (long)B * S;
+  dim3 grid(sm_cdiv(H, 128), sm_cdiv(T, 128));
+  if (dtype == SM_BF16)
+    hipLaunchKernelGGL(head_dt_mfma_kernel<bf16>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt, B, S, H, V, use_l0);
+  else
+    hipLaunchKernelGGL(head_dt_mfma_kernel<float>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const float*)E, (float*)dt, B, S, H, V, use_l0);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -4,13 +4,10 @@
 // Every reduction is a 64-lane wave reduction; every global access is coalesced along V.
 #include "common.h"
 
-namespace {
+int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
+                      int B, int S, int H, int V, int use_l0, hipStream_t st);
 
-// d rep / d logit as a function of rep itself (rep = log1p(y), or log1p(log1p(y)) with L0)
-__device__ __forceinline__ float head_fprime(float r, int use_l0) {
-  if (!(r > 0.f)) return 0.f;
-  return use_l0 ? __expf(-r - expm1f(r)) : __expf(-r);
-}
+namespace {
 
 // ---- backward of the fused head, part 1: dt[b,l,:] = sum_{v: argmax[b,v]=l} g[b,v] E[v,:] ----
 // grid (B, H/CW), CW = 64*CPL columns; the [S][CW] fp32 slice of dt accumulates in LDS (ds_add_f32).
@@ -390,20 +387,10 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  const int cpl = (H % 128 == 0) ? 2 : 1;
-  const int cw = 64 * cpl;
-  const size_t lds = (size_t)S * cw * 4;
-  SM_REQUIRE(lds <= 160 * 1024, "sm_sparse_head_bwd: S=%d too long for the LDS accumulator", S);
-#define LAUNCH_DT(T, CPL)                                                                                           \
-  do {                                                                                                              \
-    auto kern = head_dt_kernel<T, CPL>;                                                                             \
-    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-    hipLaunchKernelGGL(kern, dim3(B, H / cw), dim3(256), lds, st, grad_rep, rep, argmax, (const T*)E, (T*)dt, S, H, V, use_l0); \
-  } while (0)
-  if (dtype == SM_BF16) { if (cpl == 2) LAUNCH_DT(bf16, 2); else LAUNCH_DT(bf16, 1); }
-  else { if (cpl == 2) LAUNCH_DT(float, 2); else LAUNCH_DT(float, 1); }
-#undef LAUNCH_DT
-  SM_LAUNCH_CHECK();
+  {
+    const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, st);
+    if (rc != SM_OK) return rc;
+  }
   const int nc = H / 64;
   dim3 grid(sm_cdiv(V, 16));
 #define LAUNCH_DE(T, NC) \
