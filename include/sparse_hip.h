@@ -143,6 +143,16 @@ int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pai
 int sm_scores_bwd(const float* q, const float* d, const float* ds, int nq, int nd, int D, int pairs,
                   float* dq, float* dd, int accumulate, void* stream);
 
+/* Sparse-query form of the same contractions for inference-free queries (each q row has at most
+ * `cap` non-zeros, scripts/model/sparse_encoders.py:121-127): compact q once, then gather-dot.
+ * `overflow` (device int) is incremented for every row that had more than `cap` non-zeros. */
+int sm_row_compact(const float* q, int nq, int V, int cap, int* cols, float* vals, int* nnz, int* overflow, void* stream);
+int sm_scores_csr_fwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, int nq, int nd, int V,
+                      int pairs, float* scores, void* stream);
+/* dd[nd,V] = ds^T . q (written in full), dq[nq,V] = ds . d restricted to q's non-zero columns (rest 0) */
+int sm_scores_csr_bwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, const float* ds, int nq,
+                      int nd, int V, int pairs, float* dq, float* dd, void* stream);
+
 /* ---- ranking losses on a score matrix -----------------------------------------------------
  * InfoNCE (loss.py:86-107): rows nq, cols nd = nq*k; positives at column i*k for row i;
  * pairs==1 (no in-batch negatives) => scores is [nq,k] with the positive in column 0.

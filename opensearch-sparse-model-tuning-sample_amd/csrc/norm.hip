@@ -6,79 +6,144 @@
 
 namespace {
 
-constexpr int MAXC = 16;  // H <= 1024
+constexpr int MAXC = 16;  // H <= 1024 (scalar-column mapping of the embedding backward)
+constexpr int MAXCH = 8;  // 16-byte chunks of 8 elements per lane in the vector mapping (H <= 1024)
 
-template <typename T>
+// Vector mapping: a 64-lane wave works on 4 rows at once, 16 lanes per row; lane `sl` of a
+// row group holds chunks sl, sl+16, ... of 8 consecutive elements (16 B of bf16), so each
+// wave instruction moves 4 x 256 contiguous bytes and row statistics are 16-lane reductions.
+__device__ __forceinline__ float sub16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float (&v)[8]) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float (&v)[8]) {
+  bf16x8 x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (bf16)v[k];
+  *reinterpret_cast<bf16x8*>(p) = x;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int H, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int nc = H >> 6;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+  const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
+  const int nch = H >> 3;
+  for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
     const T* xr = x + (size_t)row * H;
-    float v[MAXC];
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) { v[i] = to_f32<T>(xr[lane + 64 * i]); s += v[i]; }
-    const float mu = wave_sum(s) / H;
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        ld8<T>(xr + (sl + 16 * i) * 8, v[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[i][k];
+      }
+    const float mu = sub16_sum(s) / H;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) { const float d = v[i] - mu; q += d * d; }
-    const float rs = rsqrtf(wave_sum(q) / H + eps);
-    T* yr = y + (size_t)row * H;
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch)
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) { const int c = lane + 64 * i; yr[c] = from_f32<T>((v[i] - mu) * rs * gamma[c] + beta[c]); }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+    const float rs = rsqrtf(sub16_sum(q) / H + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        const int c0 = (sl + 16 * i) * 8;
+        float ga[8], be[8], o[8];
+        ld8<float>(gamma + c0, ga);
+        ld8<float>(beta + c0, be);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
+        st8<T>(y + (size_t)row * H + c0, o);
+      }
+    if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, DropCfg drop,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int H) {
   __shared__ float red[4][2][MAXC * 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nc = H >> 6;
-  float gam[MAXC], dg[MAXC], db[MAXC];
+  const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4, w = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float gam[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) { gam[i] = i < nc ? gamma[lane + 64 * i] : 0.f; dg[i] = 0.f; db[i] = 0.f; }
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-    const T* xr = x + (size_t)row * H;
-    const T* dyr = dy + (size_t)row * H;
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dg[i][k] = 0.f; db[i][k] = 0.f; gam[i][k] = 0.f; }
+    if (sl + 16 * i < nch) ld8<float>(gamma + (sl + 16 * i) * 8, gam[i]);
+  }
+  for (int row = (blockIdx.x * 4 + w) * 4 + sub; row < rows; row += gridDim.x * 16) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[MAXC], dyh[MAXC];
+    float xh[NCH][8], dyh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) {
-        const float d = to_f32<T>(dyr[lane + 64 * i]);
-        xh[i] = (to_f32<T>(xr[lane + 64 * i]) - mu) * rs;
-        dyh[i] = d * gam[i];
-        dg[i] += d * xh[i];
-        db[i] += d;
-        s1 += dyh[i];
-        s2 += dyh[i] * xh[i];
-      }
-    const float c1 = wave_sum(s1) / H, c2 = wave_sum(s2) / H;
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        float d[8];
+        ld8<T>(dy + (size_t)row * H + (sl + 16 * i) * 8, d);
+        ld8<T>(x + (size_t)row * H + (sl + 16 * i) * 8, xh[i]);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) {
-        const int c = lane + 64 * i;
-        const float g = rs * (dyh[i] - c1 - xh[i] * c2);
-        dx[(size_t)row * H + c] = from_f32<T>(g);
+        for (int k = 0; k < 8; ++k) {
+          xh[i][k] = (xh[i][k] - mu) * rs;
+          dyh[i][k] = d[k] * gam[i][k];
+          dg[i][k] += d[k] * xh[i][k];
+          db[i][k] += d[k];
+          s1 += dyh[i][k];
+          s2 += dyh[i][k] * xh[i][k];
+        }
+      }
+    const float c1 = sub16_sum(s1) / H, c2 = sub16_sum(s2) / H;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        const int c0 = (sl + 16 * i) * 8;
+        float gx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gx[k] = rs * (dyh[i][k] - c1 - xh[i][k] * c2);
+        st8<T>(dx + (size_t)row * H + c0, gx);
         if (dx_drop) {
-          const float gd = drop.thresh16 ? (drop_keep1(drop, (uint64_t)row * (uint64_t)H + c) ? g * drop.scale : 0.f) : g;
-          dx_drop[(size_t)row * H + c] = from_f32<T>(gd);
+          if (drop.thresh16) {
+            const uint64_t eb = (uint64_t)row * (uint64_t)H + c0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gx[k] = drop_keep1(drop, eb + k) ? gx[k] * drop.scale : 0.f;
+          }
+          st8<T>(dx_drop + (size_t)row * H + c0, gx);
         }
       }
   }
+  // column partials: 4 row groups of the wave (xor 16, 32), then the 4 waves through LDS
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
-    if (i < nc) { red[w][0][lane + 64 * i] = dg[i]; red[w][1][lane + 64 * i] = db[i]; }
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float a = dg[i][k], b = db[i][k];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (sub == 0 && sl + 16 * i < nch) { red[w][0][(sl + 16 * i) * 8 + k] = a; red[w][1][(sl + 16 * i) * 8 + k] = b; }
+    }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
     atomicAdd(&dgamma[c], red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
@@ -86,75 +151,97 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ word,
                                                         const float* __restrict__ pos, const float* __restrict__ type0,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         T* __restrict__ z, T* __restrict__ y, float* __restrict__ mean,
                                                         float* __restrict__ rstd, int rows, int S, int H, float eps, DropCfg drop) {
-  const int lane = threadIdx.x & 63;
-  const int nc = H >> 6;
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+  const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
+  const int nch = H >> 3;
+  for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
     const int64_t id = ids[row];
     const int s = row % S;
-    const T* wr = word + (size_t)id * H;
-    float v[MAXC];
+    float v[NCH][8];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) {
-        const int c = lane + 64 * i;
-        // z is rounded to the storage type first so forward and backward see the same value
-        v[i] = to_f32<T>(from_f32<T>(to_f32<T>(wr[c]) + pos[(size_t)s * H + c] + type0[c]));
-        sum += v[i];
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        const int c0 = (sl + 16 * i) * 8;
+        float wv[8], pv[8], tv[8];
+        ld8<T>(word + (size_t)id * H + c0, wv);
+        ld8<float>(pos + (size_t)s * H + c0, pv);
+        ld8<float>(type0 + c0, tv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // z is rounded to the storage type first so forward and backward see the same value
+          v[i][k] = to_f32<T>(from_f32<T>(wv[k] + pv[k] + tv[k]));
+          sum += v[i][k];
+        }
       }
-    const float mu = wave_sum(sum) / H;
+    const float mu = sub16_sum(sum) / H;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) { const float d = v[i] - mu; q += d * d; }
-    const float rs = rsqrtf(wave_sum(q) / H + eps);
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch)
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-      if (i < nc) {
-        const int c = lane + 64 * i;
-        float o = (v[i] - mu) * rs * gamma[c] + beta[c];
-        if (drop.thresh16) o = drop_keep1(drop, (uint64_t)row * (uint64_t)H + c) ? o * drop.scale : 0.f;
-        z[(size_t)row * H + c] = from_f32<T>(v[i]);
-        y[(size_t)row * H + c] = from_f32<T>(o);
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+    const float rs = rsqrtf(sub16_sum(q) / H + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (sl + 16 * i < nch) {
+        const int c0 = (sl + 16 * i) * 8;
+        float ga[8], be[8], o[8];
+        ld8<float>(gamma + c0, ga);
+        ld8<float>(beta + c0, be);
+        const uint64_t eb = (uint64_t)row * (uint64_t)H + c0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
+          if (drop.thresh16) o[k] = drop_keep1(drop, eb + k) ? o[k] * drop.scale : 0.f;
+        }
+        st8<T>(z + (size_t)row * H + c0, v[i]);
+        st8<T>(y + (size_t)row * H + c0, o);
       }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
+// grid (S, nsplit): block (s, z) sums dz[b, s, :] over its share of the documents.  Scalar-column
+// mapping (lane <-> columns lane + 64 i) so every float-atomic wave instruction covers 256
+// contiguous bytes of one word-embedding row (the full-rate atomic shape on gfx950).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz, const int64_t* __restrict__ ids,
                                                         float* __restrict__ gword, float* __restrict__ gpos,
-                                                        float* __restrict__ gtype0, int rows, int S, int H) {
+                                                        float* __restrict__ gtype0, int B, int S, int H) {
   __shared__ float red[4][MAXC * 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nc = H >> 6;
+  const int s = blockIdx.x;
   float acc[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) acc[i] = 0.f;
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+  for (int b = blockIdx.y * 4 + w; b < B; b += gridDim.y * 4) {
+    const size_t row = (size_t)b * S + s;
     const int64_t id = ids[row];
-    const int s = row % S;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
       if (i < nc) {
         const int c = lane + 64 * i;
-        const float g = to_f32<T>(dz[(size_t)row * H + c]);
+        const float g = to_f32<T>(dz[row * H + c]);
         acc[i] += g;
         atomicAdd(&gword[(size_t)id * H + c], g);
-        atomicAdd(&gpos[(size_t)s * H + c], g);
       }
   }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
     if (i < nc) red[w][lane + 64 * i] = acc[i];
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&gtype0[c], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    atomicAdd(&gpos[(size_t)s * H + c], t);
+    atomicAdd(&gtype0[c], t);
+  }
 }
 
 template <typename T>
@@ -171,6 +258,22 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_grad_f(to_f32<T>(x[i])));
 }
+
+inline int row_grid16(int rows) {
+  int g = sm_cdiv(rows, 16);
+  return g > 2048 ? 2048 : g;
+}
+// chunks of 8 elements per lane (16 lanes per row): 1 for H <= 128, ... 8 for H <= 1024
+#define LN_NCH(H, ...)                                                   \
+  do {                                                                   \
+    const int _n = ((H) / 8 + 15) / 16;                                  \
+    if (_n <= 1) { constexpr int NCH = 1; __VA_ARGS__; }                 \
+    else if (_n <= 2) { constexpr int NCH = 2; __VA_ARGS__; }            \
+    else if (_n <= 3) { constexpr int NCH = 3; __VA_ARGS__; }            \
+    else if (_n <= 4) { constexpr int NCH = 4; __VA_ARGS__; }            \
+    else if (_n <= 6) { constexpr int NCH = 6; __VA_ARGS__; }            \
+    else { constexpr int NCH = 8; __VA_ARGS__; }                         \
+  } while (0)
 
 inline int row_grid(int rows) {
   int g = sm_cdiv(rows, 4);
@@ -191,7 +294,7 @@ extern "C" int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   SM_REQUIRE(rows > 0 && H % 64 == 0 && H <= 1024, "sm_layernorm_fwd: rows=%d H=%d (H must be a multiple of 64, <= 1024)", rows, H);
   hipStream_t st = (hipStream_t)stream;
   SM_DISPATCH(dtype, "sm_layernorm_fwd",
-              hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, H, eps));
+              LN_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(row_grid16(rows)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, H, eps)));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -202,11 +305,11 @@ extern "C" int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
   SM_REQUIRE(rows > 0 && H % 64 == 0 && H <= 1024, "sm_layernorm_bwd: rows=%d H=%d", rows, H);
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(drop);
-  int grid = sm_cdiv(rows, 16);  // >= 4 rows per wave so the dgamma/dbeta atomics stay few
-  if (grid > 1024) grid = 1024;
+  int grid = sm_cdiv(rows, 64);  // >= 4 passes per wave so the dgamma/dbeta atomics stay few
+  if (grid > 512) grid = 512;
   SM_DISPATCH(dtype, "sm_layernorm_bwd",
-              hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx,
-                                 (T*)dx_drop, d, dgamma, dbeta, rows, H));
+              LN_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                                           (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -219,8 +322,8 @@ extern "C" int sm_embed_fwd(int dtype, const int64_t* ids, const void* word, con
   const DropCfg d = make_drop(drop);
   const int rows = B * S;
   SM_DISPATCH(dtype, "sm_embed_fwd",
-              hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3(row_grid(rows)), dim3(256), 0, st, ids, (const T*)word, pos, type0, gamma, beta,
-                                 (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d));
+              LN_NCH(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NCH>), dim3(row_grid16(rows)), dim3(256), 0, st, ids, (const T*)word, pos, type0,
+                                           gamma, beta, (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d)));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -229,11 +332,10 @@ extern "C" int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float
                             int B, int S, int H, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && H % 64 == 0 && H <= 1024, "sm_embed_bwd: B=%d S=%d H=%d", B, S, H);
   hipStream_t st = (hipStream_t)stream;
-  const int rows = B * S;
-  int grid = sm_cdiv(rows, 16);
-  if (grid > 1024) grid = 1024;
+  int nsplit = sm_cdiv(1024, S);
+  if (nsplit > sm_cdiv(B, 4)) nsplit = sm_cdiv(B, 4);
   SM_DISPATCH(dtype, "sm_embed_bwd",
-              hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)dz, ids, gword, gpos, gtype0, rows, S, H));
+              hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(S, nsplit), dim3(256), 0, st, (const T*)dz, ids, gword, gpos, gtype0, B, S, H));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -279,6 +279,81 @@ __global__ __launch_bounds__(256) void scores_pairs_bwd_kernel(const float* __re
   }
 }
 
+// ---- sparse-query score matrices (inference-free queries: <= cap non-zeros per row) -------
+// row compaction: q[nq,V] dense -> (cols, vals)[nq,cap], nnz[nq]; one block per row, ballot-prefix
+__global__ __launch_bounds__(256) void row_compact_kernel(const float* __restrict__ q, int V, int cap, int* __restrict__ cols,
+                                                          float* __restrict__ vals, int* __restrict__ nnz, int* __restrict__ overflow) {
+  __shared__ int wcount[4];
+  __shared__ int base;
+  const int row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += 256) {
+    const int v = v0 + threadIdx.x;
+    const float x = v < V ? q[(size_t)row * V + v] : 0.f;
+    const unsigned long long m = __ballot(x != 0.f);
+    if (lane == 0) wcount[w] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < w; ++k) off += wcount[k];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (x != 0.f && off < cap) { cols[(size_t)row * cap + off] = v; vals[(size_t)row * cap + off] = x; }
+    __syncthreads();
+    if (threadIdx.x == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    nnz[row] = base < cap ? base : cap;
+    if (base > cap) atomicAdd(overflow, 1);
+  }
+}
+// scores[i,j] = sum_t vals[i,t] d[j, cols[i,t]]; block per document row j, waves over queries
+__global__ __launch_bounds__(256) void scores_csr_kernel(const int* __restrict__ cols, const float* __restrict__ vals,
+                                                         const int* __restrict__ nnz, int cap, const float* __restrict__ d,
+                                                         int nq, int nd, int V, int k, int pairs, float* __restrict__ scores) {
+  const int j = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* dr = d + (size_t)j * V;
+  const int i_lo = pairs ? j / k : 0, i_hi = pairs ? j / k + 1 : nq;
+  for (int i = i_lo + w; i < i_hi; i += 4) {
+    const int n = nnz[i];
+    float acc = 0.f;
+    for (int t = lane; t < n; t += 64) acc += vals[(size_t)i * cap + t] * dr[cols[(size_t)i * cap + t]];
+    acc = wave_sum(acc);
+    if (lane == 0) scores[pairs ? (size_t)j : (size_t)i * nd + j] = acc;
+  }
+}
+// dd[j, cols[i,t]] += ds[i,j] vals[i,t]  (dd pre-zeroed or accumulating; atomics: queries share tokens)
+__global__ __launch_bounds__(256) void scores_csr_bwd_dd_kernel(const int* __restrict__ cols, const float* __restrict__ vals,
+                                                                const int* __restrict__ nnz, int cap, const float* __restrict__ ds,
+                                                                int nq, int nd, int V, int k, int pairs, float* __restrict__ dd) {
+  const int j = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* dr = dd + (size_t)j * V;
+  const int i_lo = pairs ? j / k : 0, i_hi = pairs ? j / k + 1 : nq;
+  for (int i = i_lo + w; i < i_hi; i += 4) {
+    const float s = ds[pairs ? (size_t)j : (size_t)i * nd + j];
+    if (s == 0.f) continue;
+    const int n = nnz[i];
+    for (int t = lane; t < n; t += 64) atomicAdd(&dr[cols[(size_t)i * cap + t]], s * vals[(size_t)i * cap + t]);
+  }
+}
+// dq[i, cols[i,t]] = sum_j ds[i,j] d[j, cols[i,t]]  (dq pre-zeroed); one wave per (i, t)
+__global__ __launch_bounds__(256) void scores_csr_bwd_dq_kernel(const int* __restrict__ cols, const int* __restrict__ nnz, int cap,
+                                                                const float* __restrict__ ds, const float* __restrict__ d, int nq,
+                                                                int nd, int V, int k, int pairs, float* __restrict__ dq) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = idx / cap, t = idx % cap;
+  if (i >= nq || t >= nnz[i]) return;
+  const int c = cols[(size_t)i * cap + t];
+  float acc = 0.f;
+  if (pairs) {
+    for (int jj = lane; jj < k; jj += 64) acc += ds[(size_t)i * k + jj] * d[(size_t)(i * k + jj) * V + c];
+  } else {
+    for (int j = lane; j < nd; j += 64) acc += ds[(size_t)i * nd + j] * d[(size_t)j * V + c];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dq[(size_t)i * V + c] = acc;
+}
+
 // ---- ranking losses: one wave per score row ------------------------------------------------
 __global__ __launch_bounds__(256) void infonce_kernel(const float* __restrict__ scores, int nq, int ncols, int k, int pairs,
                                                       float* __restrict__ loss, float* __restrict__ dscores) {
@@ -530,6 +605,38 @@ extern "C" int sm_marginmse_fwd_bwd(const float* scores, const float* teacher, i
 extern "C" int sm_minmax_accumulate(const float* scores, int nq, int ncols, float weight, float* acc, int accumulate, void* stream) {
   SM_REQUIRE(nq > 0 && ncols > 0, "sm_minmax_accumulate: empty problem");
   hipLaunchKernelGGL(minmax_kernel, dim3(sm_cdiv(nq, 4)), dim3(256), 0, (hipStream_t)stream, scores, nq, ncols, weight, acc, accumulate);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_row_compact(const float* q, int nq, int V, int cap, int* cols, float* vals, int* nnz, int* overflow, void* stream) {
+  SM_REQUIRE(nq > 0 && V > 0 && cap > 0, "sm_row_compact: empty problem");
+  hipLaunchKernelGGL(row_compact_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, q, V, cap, cols, vals, nnz, overflow);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_scores_csr_fwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, int nq, int nd, int V,
+                                 int pairs, float* scores, void* stream) {
+  SM_REQUIRE(nq > 0 && nd > 0 && nd % nq == 0, "sm_scores_csr_fwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
+  hipLaunchKernelGGL(scores_csr_kernel, dim3(nd), dim3(256), 0, (hipStream_t)stream, cols, vals, nnz, cap, d, nq, nd, V, nd / nq, pairs, scores);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_scores_csr_bwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, const float* ds, int nq,
+                                 int nd, int V, int pairs, float* dq, float* dd, void* stream) {
+  SM_REQUIRE(nq > 0 && nd > 0 && nd % nq == 0, "sm_scores_csr_bwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
+  hipStream_t st = (hipStream_t)stream;
+  if (dd) {
+    SM_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nd * V * sizeof(float), st));
+    hipLaunchKernelGGL(scores_csr_bwd_dd_kernel, dim3(nd), dim3(256), 0, st, cols, vals, nnz, cap, ds, nq, nd, V, nd / nq, pairs, dd);
+  }
+  if (dq) {
+    SM_HIP_CHECK(hipMemsetAsync(dq, 0, (size_t)nq * V * sizeof(float), st));
+    hipLaunchKernelGGL(scores_csr_bwd_dq_kernel, dim3(sm_cdiv((long)nq * cap, 4)), dim3(256), 0, st, cols, nnz, cap, ds, d, nq, nd, V,
+                       nd / nq, pairs, dq);
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -7,6 +7,10 @@ from sparse_hip import functional as F
 
 
 class SparseTrainingLoss:
+    # upper bound on the non-zeros per query row when the caller can guarantee one (set by the
+    # trainer for inference-free queries: at most one per query token); None = dense queries
+    sparse_query_cap = None
+
     def __init__(self, weight=1):
         self.weight = weight
 
@@ -24,7 +28,8 @@ class KLDivLoss(SparseTrainingLoss):
         super().__init__(weight)
 
     def __call__(self, q_rep, d_rep, inputs):
-        return F.ranking_loss("kldiv", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature)
+        return F.ranking_loss("kldiv", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature,
+                              q_cap=self.sparse_query_cap)
 
 
 class MarginMSELoss(SparseTrainingLoss):
@@ -34,7 +39,8 @@ class MarginMSELoss(SparseTrainingLoss):
         super().__init__(weight)
 
     def __call__(self, q_rep, d_rep, inputs):
-        return F.ranking_loss("marginmse", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature)
+        return F.ranking_loss("marginmse", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature,
+                              q_cap=self.sparse_query_cap)
 
 
 class InfoNCELoss(SparseTrainingLoss):
@@ -43,7 +49,7 @@ class InfoNCELoss(SparseTrainingLoss):
         super().__init__(weight)
 
     def __call__(self, q_rep, d_rep, inputs):
-        return F.ranking_loss("infonce", q_rep, d_rep, None, self.use_in_batch_negatives)
+        return F.ranking_loss("infonce", q_rep, d_rep, None, self.use_in_batch_negatives, q_cap=self.sparse_query_cap)
 
 
 LOSS_CLS_MAP = {"infonce": InfoNCELoss, "kldiv": KLDivLoss, "marginmse": MarginMSELoss}

@@ -141,6 +141,11 @@ class SparseModelTrainer:
             "attention_mask": inputs["docs"][0]["attention_mask"],
         }
         d_rep, q_rep = model(model_wrapper_input)
+        # inference-free queries have at most one non-zero per query token: let the losses use the
+        # sparse-query score kernels (identical values, no V-length dense dot products)
+        cap = model_wrapper_input["q_input_ids"].shape[1] if self.model_args.inf_free else None
+        for loss_function in self.loss_functions:
+            loss_function.sparse_query_cap = cap
         d_rep = gather_rep(d_rep, self.accelerator)
         q_rep = gather_rep(q_rep, self.accelerator)
         if "scores" in inputs:

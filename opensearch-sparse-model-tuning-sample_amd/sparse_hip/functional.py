@@ -73,13 +73,18 @@ def flops_value(rep: Tensor, group_num: int = 1, flops_threshold: Optional[int] 
 # same row pass as the loss, scaled by the upstream gradient on the device in backward.
 class _RankLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q_rep: Tensor, d_rep: Tensor, teacher: Optional[Tensor], kind: str, ibn: bool, tau: float):
+    def forward(ctx, q_rep: Tensor, d_rep: Tensor, teacher: Optional[Tensor], kind: str, ibn: bool, tau: float,
+                q_cap: Optional[int]):
         q, d = _f32c(q_rep), _f32c(d_rep)
         nq, nd = q.shape[0], d.shape[0]
         if nd % nq:
             raise L.SparseHipError(f"d_rep rows {nd} must be a multiple of q_rep rows {nq}")
         k = nd // nq
-        scores = ops.scores_fwd(q, d, pairs=not ibn)
+        # q_cap: the caller guarantees <= q_cap non-zeros per query row (inference-free queries:
+        # at most one per query token) -> gather-dot over the token lists instead of dense V-length dots
+        csr = ops.row_compact(q, int(q_cap)) if q_cap else None
+        ctx.csr = csr
+        scores = ops.scores_csr_fwd(csr, d, pairs=not ibn) if csr is not None else ops.scores_fwd(q, d, pairs=not ibn)
         if kind == "infonce":
             loss, ds = ops.infonce(scores, k, pairs=not ibn)
         else:
@@ -98,14 +103,18 @@ class _RankLossFn(torch.autograd.Function):
         dq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
         dd = torch.empty_like(d) if ctx.needs_input_grad[1] else None
         if dq is not None or dd is not None:
-            ops.scores_bwd(q, d, ds, not ctx.ibn, dq, dd, False)
-        return dq, dd, None, None, None, None
+            if ctx.csr is not None:
+                ops.scores_csr_bwd(ctx.csr, d, ds, not ctx.ibn, dq, dd)
+            else:
+                ops.scores_bwd(q, d, ds, not ctx.ibn, dq, dd, False)
+        return dq, dd, None, None, None, None, None
 
 
-def ranking_loss(kind: str, q_rep: Tensor, d_rep: Tensor, teacher: Optional[Tensor], ibn: bool, tau: float = 1.0) -> Tensor:
+def ranking_loss(kind: str, q_rep: Tensor, d_rep: Tensor, teacher: Optional[Tensor], ibn: bool, tau: float = 1.0,
+                 q_cap: Optional[int] = None) -> Tensor:
     if kind not in ("infonce", "kldiv", "marginmse"):
         raise KeyError(kind)
-    return _RankLossFn.apply(q_rep, d_rep, teacher, kind, bool(ibn), float(tau))
+    return _RankLossFn.apply(q_rep, d_rep, teacher, kind, bool(ibn), float(tau), q_cap)
 
 
 def score_matrix(q_rep: Tensor, d_rep: Tensor, ibn: bool) -> Tensor:

@@ -56,6 +56,9 @@ SIGNATURES = {
     "sm_flops_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     "sm_scores_fwd": [_p, _p, _i, _i, _i, _i, _p, _p],
     "sm_scores_bwd": [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p],
+    "sm_row_compact": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "sm_scores_csr_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
+    "sm_scores_csr_bwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p],
     "sm_infonce_fwd_bwd": [_p, _i, _i, _i, _i, _p, _p, _p],
     "sm_kldiv_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p],
     "sm_marginmse_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p],

@@ -194,6 +194,35 @@ def scores_bwd(q: Tensor, d: Tensor, ds: Tensor, pairs: bool, dq: Optional[Tenso
            int(accumulate), L.stream_ptr())
 
 
+def row_compact(q: Tensor, cap: int):
+    """(cols, vals, nnz, overflow) of the <= cap non-zeros of each row of q[nq,V]."""
+    nq, V = q.shape
+    cols = _new((nq, cap), torch.int32, q)
+    vals = _new((nq, cap), torch.float32, q)
+    nnz = _new((nq,), torch.int32, q)
+    overflow = torch.zeros(1, dtype=torch.int32, device=q.device)
+    L.call("sm_row_compact", L.ptr(q), nq, V, cap, L.ptr(cols), L.ptr(vals), L.ptr(nnz), L.ptr(overflow), L.stream_ptr())
+    return cols, vals, nnz, overflow
+
+
+def scores_csr_fwd(csr, d: Tensor, pairs: bool) -> Tensor:
+    cols, vals, nnz, _ = csr
+    nq, cap = cols.shape
+    nd, V = d.shape
+    out = _new((nq, nd // nq) if pairs else (nq, nd), torch.float32, d)
+    L.call("sm_scores_csr_fwd", L.ptr(cols), L.ptr(vals), L.ptr(nnz), cap, L.ptr(d), nq, nd, V, int(pairs), L.ptr(out),
+           L.stream_ptr())
+    return out
+
+
+def scores_csr_bwd(csr, d: Tensor, ds: Tensor, pairs: bool, dq: Optional[Tensor], dd: Optional[Tensor]):
+    cols, vals, nnz, _ = csr
+    nq, cap = cols.shape
+    nd, V = d.shape
+    L.call("sm_scores_csr_bwd", L.ptr(cols), L.ptr(vals), L.ptr(nnz), cap, L.ptr(d), L.ptr(ds), nq, nd, V, int(pairs),
+           L.ptr(dq), L.ptr(dd), L.stream_ptr())
+
+
 def infonce(scores: Tensor, k: int, pairs: bool, want_grad: bool = True):
     nq, ncols = scores.shape
     loss = _new((1,), torch.float32, scores)

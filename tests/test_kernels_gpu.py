@@ -351,3 +351,36 @@ def test_cast_weight(ops, dtype):
     assert torch.equal(out[:70, :45].cpu(), w.to(dtype))
     assert torch.equal(out_t[:, :70].cpu(), w.t().to(dtype))
     assert out[70:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_sparse_query_scores_match_dense(ops, pairs):
+    """inference-free queries: row compaction + gather-dot kernels == the dense score kernels"""
+    nq, k, V, cap = 7, 4, 30522, 32
+    g = torch.Generator().manual_seed(3)
+    qv = torch.zeros(nq, V)
+    for i in range(nq):
+        n = int(torch.randint(0, cap + 1, (1,), generator=g)) if i else cap  # row 0 full, some rows empty-ish
+        idx = torch.randperm(V, generator=g)[:n]
+        qv[i, idx] = torch.rand(n, generator=g) * 5 + 0.1
+    dv = torch.relu(rnd(nq * k, V, seed=2) - 0.5)
+    csr = ops.row_compact(dev(qv), cap)
+    assert int(csr[3].item()) == 0
+    assert torch.equal(csr[2].cpu(), (qv != 0).sum(1).int())
+    s_sparse = ops.scores_csr_fwd(csr, dev(dv), pairs)
+    s_dense = ops.scores_fwd(dev(qv), dev(dv), pairs)
+    close(s_sparse, s_dense, 1e-5, "scores")
+    ref = torch.einsum("bkv,bv->bk", dv.view(nq, k, V), qv) if pairs else qv @ dv.t()
+    close(s_sparse, ref, 1e-4, "scores vs torch")
+    ds = rnd(*ref.shape, seed=4)
+    dq, dd_ = torch.empty(nq, V, device="cuda"), torch.empty(nq * k, V, device="cuda")
+    ops.scores_csr_bwd(csr, dev(dv), dev(ds), pairs, dq, dd_)
+    if pairs:
+        dd_ref = (ds[:, :, None] * qv[:, None, :]).reshape(nq * k, V)
+        dq_ref = torch.einsum("bk,bkv->bv", ds, dv.view(nq, k, V))
+    else:
+        dd_ref, dq_ref = ds.t() @ qv, ds @ dv
+    close(dd_, dd_ref, 1e-4, "dd")
+    close(dq, dq_ref * (qv != 0), 1e-4, "dq (restricted to q's support)")
+    over = ops.row_compact(dev(qv), 8)
+    assert int(over[3].item()) > 0, "rows with more than cap non-zeros must be flagged"
