@@ -60,52 +60,85 @@ __device__ __forceinline__ void r2s_nt(char* tile, const uint4 regs[4]) {
   }
 }
 
+// One K-step of the NT main loop.  SET selects the register set that currently holds tile
+// kt + 1 (loaded two iterations ago): it is written to the idle LDS stage, immediately re-used
+// for the global loads of tile kt + 3, and only then are the MFMAs of tile kt issued -- so every
+// global load has two full K-steps to land (register-staged prefetch distance 2).
+template <typename T, int SET>
+__device__ __forceinline__ void nt_kstep(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb,
+                                         int N, int n0, int kt, int nk, char* sA, char* sB, uint4 (&ra)[2][4],
+                                         uint4 (&rb)[2][4], f32x4 (&acc)[4][4], int wm, int wn, int g, int li) {
+  using MM = Mma<T>;
+  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
+  if (kt + 1 < nk) {
+    r2s_nt(sA + ((kt + 1) & 1) * TILE_BYTES, ra[SET]);
+    r2s_nt(sB + ((kt + 1) & 1) * TILE_BYTES, rb[SET]);
+  }
+  if (kt + 3 < nk) {
+    g2r_nt(A, lda, m0, M, (kt + 3) * BK, ra[SET]);
+    g2r_nt(B, ldb, n0, N, (kt + 3) * BK, rb[SET]);
+  }
+  const char* a = sA + (kt & 1) * TILE_BYTES;
+  const char* b = sB + (kt & 1) * TILE_BYTES;
+#pragma unroll
+  for (int ks = 0; ks < NS; ++ks) {
+    typename MM::Frag fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
+      fb[i] = MM::load_nt(b, wn * 64 + i * 16 + li, ks, g);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+  }
+  __syncthreads();
+}
+
 // acc[i][j] += A[m0.., :] . B[n0.., :]^T over the whole K; smem = 4 * TILE_BYTES
 template <typename T>
 __device__ __forceinline__ void nt_mainloop(const T* __restrict__ A, int lda, int M, int m0,
                                             const T* __restrict__ B, int ldb, int N, int n0, int K,
                                             char* smem, f32x4 acc[4][4]) {
   using MM = Mma<T>;
-  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
+  constexpr int BK = MM::BK;
   char* const sA = smem;                   // two stages of A, then two stages of B
   char* const sB = smem + 2 * TILE_BYTES;
-  uint4 ra[4], rb[4];
+  uint4 ra[2][4], rb[2][4];
   const int nk = K / BK;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  f32x4 (&accr)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(acc);
 
-  g2r_nt(A, lda, m0, M, 0, ra);
-  g2r_nt(B, ldb, n0, N, 0, rb);
-  r2s_nt(sA, ra);
-  r2s_nt(sB, rb);
+  g2r_nt(A, lda, m0, M, 0, ra[0]);
+  g2r_nt(B, ldb, n0, N, 0, rb[0]);
+  if (nk > 1) { g2r_nt(A, lda, m0, M, BK, ra[1]); g2r_nt(B, ldb, n0, N, BK, rb[1]); }
+  r2s_nt(sA, ra[0]);
+  r2s_nt(sB, rb[0]);
+  if (nk > 2) { g2r_nt(A, lda, m0, M, 2 * BK, ra[0]); g2r_nt(B, ldb, n0, N, 2 * BK, rb[0]); }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      g2r_nt(A, lda, m0, M, (kt + 1) * BK, ra);
-      g2r_nt(B, ldb, n0, N, (kt + 1) * BK, rb);
-    }
-    const char* a = sA + (kt & 1) * TILE_BYTES;
-    const char* b = sB + (kt & 1) * TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      typename MM::Frag fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
-        fb[i] = MM::load_nt(b, wn * 64 + i * 16 + li, ks, g);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) {
-      r2s_nt(sA + ((kt + 1) & 1) * TILE_BYTES, ra);
-      r2s_nt(sB + ((kt + 1) & 1) * TILE_BYTES, rb);
-    }
-    __syncthreads();
+  // register set holding tile kt+1: set 1 for even kt, set 0 for odd kt
+  for (int kt = 0; kt < nk; kt += 2) {
+    nt_kstep<T, 1>(A, lda, M, m0, B, ldb, N, n0, kt, nk, sA, sB, ra, rb, accr, wm, wn, g, li);
+    if (kt + 1 < nk) nt_kstep<T, 0>(A, lda, M, m0, B, ldb, N, n0, kt + 1, nk, sA, sB, ra, rb, accr, wm, wn, g, li);
   }
 }
+
+// Map this workgroup's linear id to (m-tile, n-tile): groups of `mg` m-tiles are owned by one
+// XCD group (id % 8) and walked n-major inside the group, so the group's A panels stay in that
+// XCD's L2 while the B tiles stream through it once per group.  mt = -1: padding id, no work.
+__device__ __forceinline__ void xcd_tile(int n_mt, int n_nt, int mg, int& mt, int& nt) {
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xcd = lin & 7, seq = lin >> 3;
+  const int per_group = mg * n_nt;
+  const int grp = (seq / per_group) * 8 + xcd, r = seq % per_group;
+  nt = r / mg;
+  mt = grp * mg + r % mg;
+  if (mt >= n_mt) mt = -1;
+}
+
+constexpr int HEAD_MG = 16;  // row tiles per XCD group in the fused head kernel
 
 constexpr int CS = 132;  // fp32 row stride (floats) of the LDS-staged C tile: 528 B, conflict-free
 
@@ -167,7 +200,13 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
   __shared__ __attribute__((aligned(16))) char smem[128 * CS * 4 > 4 * TILE_BYTES ? 128 * CS * 4 : 4 * TILE_BYTES];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so linear id L runs
+  // on XCD group L % 8.  All N-tiles of one M-tile are given to the same group, back to back, so
+  // the A row panel is fetched into that XCD's L2 once (placement only changes speed).
+  int mt, nt;
+  xcd_tile((M + BM - 1) / BM, gridDim.x, 1, mt, nt);
+  if (mt < 0) return;
+  const int m0 = mt * BM, n0 = nt * BN;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -250,16 +289,20 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
   float* redv = reinterpret_cast<float*>(smem);  // [8 groups][128 cols]
   int* redi = reinterpret_cast<int*>(redv + 8 * 128);
   const int Ttot = Bdocs * S;
-  const int n0 = blockIdx.x * BN;
+  const bool long_doc = S > 128;
+  // XCD-aware order: 16 row tiles (their t panels stay in one XCD's L2) x all vocab tiles
+  int mt, nt;
+  xcd_tile(long_doc ? Bdocs : (Ttot + 127) / 128, gridDim.x, HEAD_MG, mt, nt);
+  if (mt < 0) return;
+  const int n0 = nt * BN;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
-  const bool long_doc = S > 128;
   const int ntile = long_doc ? S / 128 : 1;
   float run_v = -INFINITY;
   int run_i = 0;
 
-  for (int mt = 0; mt < ntile; ++mt) {
-    const int m0 = long_doc ? blockIdx.y * S + mt * 128 : blockIdx.y * 128;
+  for (int mtile = 0; mtile < ntile; ++mtile) {
+    const int m0 = long_doc ? mt * S + mtile * 128 : mt * 128;
     // mask bytes of this lane's 16 rows (4 consecutive rows per MFMA tile); B*S % 16 == 0
     uint32_t mrow[4];
 #pragma unroll
@@ -306,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
 #pragma unroll
         for (int grp = 0; grp < 8; ++grp) {
           const float v = redv[grp * 128 + threadIdx.x];
-          if (v > run_v) { run_v = v; run_i = mt * 128 + redi[grp * 128 + threadIdx.x]; }
+          if (v > run_v) { run_v = v; run_i = mtile * 128 + redi[grp * 128 + threadIdx.x]; }
         }
       } else {
         const int gper = S / 16, ndoc = 128 / S;
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
     __syncthreads();
   }
   if (long_doc && threadIdx.x < 128) {
-    const int col = n0 + threadIdx.x, b = blockIdx.y;
+    const int col = n0 + threadIdx.x, b = mt;
     if (col < V) {
       float y = fmaxf(run_v + bias[col], 0.f);
       y = log1pf(y);
@@ -598,7 +641,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
-  dim3 grid(sm_cdiv(N, BN), sm_cdiv(M, BM));
+  dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
   return 0;
 }
@@ -662,7 +705,8 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
   hipStream_t st = (hipStream_t)stream;
   const long T = (long)B * S;
-  dim3 grid(sm_cdiv(V, BN), S > 128 ? B : sm_cdiv(T, 128));
+  const int mtiles = S > 128 ? B : sm_cdiv(T, 128);
+  dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)
     hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
   else if (dtype == SM_F32)

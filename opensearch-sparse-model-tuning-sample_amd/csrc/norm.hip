@@ -224,14 +224,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz
   for (int b = blockIdx.y * 4 + w; b < B; b += gridDim.y * 4) {
     const size_t row = (size_t)b * S + s;
     const int64_t id = ids[row];
+    float gv[MAXC];
+    bool nz = false;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
       if (i < nc) {
-        const int c = lane + 64 * i;
-        const float g = to_f32<T>(dz[row * H + c]);
-        acc[i] += g;
-        atomicAdd(&gword[(size_t)id * H + c], g);
+        gv[i] = to_f32<T>(dz[row * H + lane + 64 * i]);
+        acc[i] += gv[i];
+        nz |= gv[i] != 0.f;
       }
+    // padded positions carry an exactly-zero gradient: skipping them keeps thousands of adders
+    // off the single [PAD] row (same-row float atomics are an order of magnitude slower)
+    if (__any(nz)) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+        if (i < nc) atomicAdd(&gword[(size_t)id * H + lane + 64 * i], gv[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)

@@ -384,6 +384,8 @@ class _EncodeFn(torch.autograd.Function):
         rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0)
         if prune_ratio is not None:
             ops.prune_rows(rep, prune_ratio)
+        if model._argmax_log is not None:  # test hook: which position each (doc, vocab) max came from
+            model._argmax_log.append(argmax)
         if need_grad:
             ctx.model, ctx.saved = model, saved
             ctx.head = (x, ft, gt, mt, rt, tn, rep, argmax)
@@ -452,3 +454,4 @@ class _EncodeFn(torch.autograd.Function):
 
 
 HipBertMLM._layer_hook = None
+HipBertMLM._argmax_log = None

@@ -133,9 +133,17 @@ def bert_mlm_logits(
 # a1: SparseModel._encode  (scripts/model/sparse_encoders.py:107-119)
 # --------------------------------------------------------------------------
 def sparse_activation(logits: Tensor, attention_mask: Tensor, use_l0: bool = False,
-                      prune_ratio: Optional[float] = None) -> Tensor:
-    """max over seq of mask*logits, log1p(relu) (twice with use_l0), ratio prune."""
-    values, _ = torch.max(logits * attention_mask.unsqueeze(-1).to(logits.dtype), dim=1)
+                      prune_ratio: Optional[float] = None, route: Optional[Tensor] = None) -> Tensor:
+    """max over seq of mask*logits, log1p(relu) (twice with use_l0), ratio prune.
+
+    ``route`` [B,V] (test aid, not in the reference): take the value at the given sequence
+    position instead of the arg-max, so that gradients of a reduced-precision run whose
+    near-tied maxima landed on a different position can be compared like for like."""
+    masked = logits * attention_mask.unsqueeze(-1).to(logits.dtype)
+    if route is None:
+        values, _ = torch.max(masked, dim=1)
+    else:
+        values = torch.gather(masked, 1, route.long().clamp(0, logits.shape[1] - 1).unsqueeze(1)).squeeze(1)
     values = torch.log1p(torch.relu(values))
     if use_l0:
         values = torch.log1p(values)
@@ -146,9 +154,9 @@ def sparse_activation(logits: Tensor, attention_mask: Tensor, use_l0: bool = Fal
 
 
 def encode_docs(p, input_ids, attention_mask, cfg, use_l0=False, prune_ratio=None,
-                dropout_p=0.0, gen=None) -> Tensor:
+                dropout_p=0.0, gen=None, route=None) -> Tensor:
     logits = bert_mlm_logits(p, input_ids, attention_mask, cfg, dropout_p, gen)
-    return sparse_activation(logits, attention_mask, use_l0, prune_ratio)
+    return sparse_activation(logits, attention_mask, use_l0, prune_ratio, route)
 
 
 # teacher variant: BiSparseModel.forward (scripts/train/bi_encoder_wrapper.py:28-35)
@@ -313,13 +321,13 @@ def total_loss(q_rep: Tensor, d_rep: Tensor, scores: Optional[Tensor], lc: LossC
 
 def compute_loss(p, cfg: BertShape, idf_vector, special_token_ids, q_ids, q_mask, d_ids, d_mask,
                  scores, lc: LossConfig, global_step: int, use_l0=False, prune_ratio=None,
-                 dropout_p=0.0, gen=None):
+                 dropout_p=0.0, gen=None, d_route=None, q_route=None):
     """Single-process ModelWrapper.forward (trainer.py:24-35) + compute_loss."""
-    d_rep = encode_docs(p, d_ids, d_mask, cfg, use_l0, prune_ratio, dropout_p, gen)
+    d_rep = encode_docs(p, d_ids, d_mask, cfg, use_l0, prune_ratio, dropout_p, gen, d_route)
     if lc.inf_free:
         q_rep = encode_inf_free(q_ids, idf_vector, special_token_ids)
     else:
-        q_rep = encode_docs(p, q_ids, q_mask, cfg, use_l0, prune_ratio, dropout_p, gen)
+        q_rep = encode_docs(p, q_ids, q_mask, cfg, use_l0, prune_ratio, dropout_p, gen, q_route)
     loss, rank_l, d_flops = total_loss(q_rep, d_rep, scores, lc, global_step, 1)
     return loss, rank_l, d_flops, q_rep, d_rep
 
