@@ -7,6 +7,8 @@
 // Block tile 128 x 128, 256 threads = 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles.
 // LDS stage rows are 128 bytes of K (64 bf16 / 32 fp32), XOR-swizzled in 16-byte chunks
 // (chunk ^= row & 7) so ds_read_b128 fragment reads are bank-conflict free; two stages.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -60,75 +62,151 @@ __device__ __forceinline__ void r2s_nt(char* tile, const uint4 regs[4]) {
   }
 }
 
-// One K-step of the NT main loop.  SET selects the register set that currently holds tile
-// kt + 1 (loaded two iterations ago): it is written to the idle LDS stage, immediately re-used
-// for the global loads of tile kt + 3, and only then are the MFMAs of tile kt issued -- so every
-// global load has two full K-steps to land (register-staged prefetch distance 2).
-template <typename T, int SET>
-__device__ __forceinline__ void nt_kstep(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb,
-                                         int N, int n0, int kt, int nk, char* sA, char* sB, uint4 (&ra)[2][4],
-                                         uint4 (&rb)[2][4], f32x4 (&acc)[4][4], int wm, int wn, int g, int li) {
-  using MM = Mma<T>;
-  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
-  if (kt + 1 < nk) {
-    r2s_nt(sA + ((kt + 1) & 1) * TILE_BYTES, ra[SET]);
-    r2s_nt(sB + ((kt + 1) & 1) * TILE_BYTES, rb[SET]);
-  }
-  if (kt + 3 < nk) {
-    g2r_nt(A, lda, m0, M, (kt + 3) * BK, ra[SET]);
-    g2r_nt(B, ldb, n0, N, (kt + 3) * BK, rb[SET]);
-  }
-  const char* a = sA + (kt & 1) * TILE_BYTES;
-  const char* b = sB + (kt & 1) * TILE_BYTES;
-#pragma unroll
-  for (int ks = 0; ks < NS; ++ks) {
-    typename MM::Frag fa[4], fb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
-      fb[i] = MM::load_nt(b, wn * 64 + i * 16 + li, ks, g);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
-  }
-  __syncthreads();
-}
-
-// acc[i][j] += A[m0.., :] . B[n0.., :]^T over the whole K; smem = 4 * TILE_BYTES
+// acc[i][j] += A[m0.., :] . B[n0.., :]^T over the whole K; smem = 4 * TILE_BYTES.
+// Register-staged, two LDS stages (used by the fp32 parity path and as the fallback).
 template <typename T>
 __device__ __forceinline__ void nt_mainloop(const T* __restrict__ A, int lda, int M, int m0,
                                             const T* __restrict__ B, int ldb, int N, int n0, int K,
                                             char* smem, f32x4 acc[4][4]) {
   using MM = Mma<T>;
-  constexpr int BK = MM::BK;
+  constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
   char* const sA = smem;                   // two stages of A, then two stages of B
   char* const sB = smem + 2 * TILE_BYTES;
-  uint4 ra[2][4], rb[2][4];
+  uint4 ra[4], rb[4];
   const int nk = K / BK;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
-  f32x4 (&accr)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(acc);
 
-  g2r_nt(A, lda, m0, M, 0, ra[0]);
-  g2r_nt(B, ldb, n0, N, 0, rb[0]);
-  if (nk > 1) { g2r_nt(A, lda, m0, M, BK, ra[1]); g2r_nt(B, ldb, n0, N, BK, rb[1]); }
-  r2s_nt(sA, ra[0]);
-  r2s_nt(sB, rb[0]);
-  if (nk > 2) { g2r_nt(A, lda, m0, M, 2 * BK, ra[0]); g2r_nt(B, ldb, n0, N, 2 * BK, rb[0]); }
+  g2r_nt(A, lda, m0, M, 0, ra);
+  g2r_nt(B, ldb, n0, N, 0, rb);
+  r2s_nt(sA, ra);
+  r2s_nt(sB, rb);
   __syncthreads();
-  // register set holding tile kt+1: set 1 for even kt, set 0 for odd kt
-  for (int kt = 0; kt < nk; kt += 2) {
-    nt_kstep<T, 1>(A, lda, M, m0, B, ldb, N, n0, kt, nk, sA, sB, ra, rb, accr, wm, wn, g, li);
-    if (kt + 1 < nk) nt_kstep<T, 0>(A, lda, M, m0, B, ldb, N, n0, kt + 1, nk, sA, sB, ra, rb, accr, wm, wn, g, li);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      g2r_nt(A, lda, m0, M, (kt + 1) * BK, ra);
+      g2r_nt(B, ldb, n0, N, (kt + 1) * BK, rb);
+    }
+    const char* a = sA + (kt & 1) * TILE_BYTES;
+    const char* b = sB + (kt & 1) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = MM::load_nt(a, wm * 64 + i * 16 + li, ks, g);
+        fb[i] = MM::load_nt(b, wn * 64 + i * 16 + li, ks, g);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      r2s_nt(sA + ((kt + 1) & 1) * TILE_BYTES, ra);
+      r2s_nt(sB + ((kt + 1) & 1) * TILE_BYTES, rb);
+    }
+    __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct-to-LDS main loop (global_load_lds_dwordx4): no staging registers, a ring of GL_NSTAGE
+// stages of 64-byte K-slices per operand row, three stages in flight behind a counted
+// s_waitcnt vmcnt(N) and a raw s_barrier, so HBM/L2 latency hides under three K-steps of MFMAs.
+// LDS image of a stage: [128 rows][64 B]; one wave instruction writes 16 rows x 64 B = 1 KiB
+// linearly (lane l -> row l >> 2, 16-byte slot l & 3), and the bank swizzle
+// (slot ^= (-(row >> 2)) & 3, conflict-free for ds_read_b128's 16-lane groups, which mix two
+// k-chunks: lanes {0-3, 12-15} of one chunk with lanes {4-11} of the next) is applied to the per-lane SOURCE address and to the fragment reads.
+// Rows past the end of A / B are clamped to the last valid row: those rows / columns of the tile
+// are never stored (and are masked in the fused head), so the duplicated data is harmless.
+// ---------------------------------------------------------------------------------------
+constexpr int GL_NSTAGE = 4;
+constexpr int GL_STAGE = 128 * 64;  // bytes per operand per stage
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename T>
+__device__ __forceinline__ void glds_issue(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb,
+                                           int N, int n0, int k0, char* sa, char* sb, int w, int lane) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int piece = w * 2 + p;
+    const int row = piece * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+    const int ra = min(m0 + row, M - 1), rb = min(n0 + row, N - 1);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + (size_t)ra * lda + k0 + lchunk * EPC), (lds_void_t*)(sa + piece * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (size_t)rb * ldb + k0 + lchunk * EPC), (lds_void_t*)(sb + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <typename T> struct GlFrag;
+template <> struct GlFrag<bf16> {
+  static constexpr int BK = 32, NS = 1;
+  __device__ static __forceinline__ bf16x8 load(const char* st, int row, int ks, int g) {
+    return *reinterpret_cast<const bf16x8*>(st + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
+  }
+};
+template <> struct GlFrag<float> {
+  static constexpr int BK = 16, NS = 4;
+  __device__ static __forceinline__ float load(const char* st, int row, int ks, int g) {
+    return *reinterpret_cast<const float*>(st + row * 64 + ((ks ^ ((0 - (row >> 2)) & 3)) << 4) + g * 4);
+  }
+};
+
+// smem >= 2 * GL_NSTAGE * GL_STAGE (64 KiB); K % BK == 0
+template <typename T>
+__device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int lda, int M, int m0,
+                                                 const T* __restrict__ B, int ldb, int N, int n0, int K,
+                                                 char* smem, f32x4 acc[4][4]) {
+  using MM = Mma<T>;
+  using GF = GlFrag<T>;
+  constexpr int BK = GF::BK;
+  char* const sA = smem;
+  char* const sB = smem + GL_NSTAGE * GL_STAGE;
+  const int nk = K / BK;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+#pragma unroll
+  for (int s = 0; s < GL_NSTAGE - 1; ++s)
+    if (s < nk) glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, s * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt must have landed; the (up to two) younger stages stay in flight: 4 loads per stage and wave
+    const int younger = min(GL_NSTAGE - 2, nk - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces landed; stage (kt-1) % NSTAGE is free again
+    asm volatile("" ::: "memory");
+    if (kt + GL_NSTAGE - 1 < nk) {
+      const int s = (kt + GL_NSTAGE - 1) % GL_NSTAGE;
+      glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, (kt + GL_NSTAGE - 1) * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
+    }
+    const char* a = sA + (kt % GL_NSTAGE) * GL_STAGE;
+    const char* b = sB + (kt % GL_NSTAGE) * GL_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < GF::NS; ++ks) {
+      typename MM::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = GF::load(a, wm * 64 + i * 16 + li, ks, g);
+        fb[i] = GF::load(b, wn * 64 + i * 16 + li, ks, g);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  __syncthreads();  // callers reuse smem right after the loop
 }
 
 // Map this workgroup's linear id to (m-tile, n-tile): groups of `mg` m-tiles are owned by one
 // XCD group (id % 8) and walked n-major inside the group, so the group's A panels stay in that
 // XCD's L2 while the B tiles stream through it once per group.  mt = -1: padding id, no work.
-__device__ __forceinline__ void xcd_tile(int n_mt, int n_nt, int mg, int& mt, int& nt) {
+__device__ __forceinline__ void xcd_tile(int n_mt, int n_nt, int mg, int& mt, int& nt, int enable = 1) {
+  if (!enable) { mt = blockIdx.y < n_mt ? (int)blockIdx.y : -1; nt = blockIdx.x; return; }
   const int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int xcd = lin & 7, seq = lin >> 3;
   const int per_group = mg * n_nt;
@@ -188,6 +266,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 
 struct EpiArgs {
   int vec_ok;  // ldc and every epilogue pointer allow 8-element vectors
+  int xcd;     // XCD-aware tile order on/off
   const float* bias;
   int act;
   void* preact;
@@ -196,7 +275,7 @@ struct EpiArgs {
   const void* gelu_grad_of;
 };
 
-template <typename T>
+template <typename T, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
   __shared__ __attribute__((aligned(16))) char smem[128 * CS * 4 > 4 * TILE_BYTES ? 128 * CS * 4 : 4 * TILE_BYTES];
@@ -204,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
   // on XCD group L % 8.  All N-tiles of one M-tile are given to the same group, back to back, so
   // the A row panel is fetched into that XCD's L2 once (placement only changes speed).
   int mt, nt;
-  xcd_tile((M + BM - 1) / BM, gridDim.x, 1, mt, nt);
+  xcd_tile((M + BM - 1) / BM, gridDim.x, 1, mt, nt, e.xcd);
   if (mt < 0) return;
   const int m0 = mt * BM, n0 = nt * BN;
   f32x4 acc[4][4];
@@ -212,7 +291,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  if constexpr (GLDS) nt_mainloop_glds<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  else nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
 
   // Epilogue through LDS: the accumulators (MFMA C layout: 2-byte column fragments) are staged
   // as an fp32 [128][CS] tile so that every global access of the epilogue -- C, preact, residual,
@@ -283,7 +363,7 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __restrict__ Tn, const T* __restrict__ E,
                                                                    const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                                    float* __restrict__ rep, uint16_t* __restrict__ argmax,
-                                                                   int Bdocs, int S, int H, int V, int use_l0) {
+                                                                   int Bdocs, int S, int H, int V, int use_l0, int xcd_on) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   // the per-group reduction scratch overlays the (then idle) staging buffers
   float* redv = reinterpret_cast<float*>(smem);  // [8 groups][128 cols]
@@ -292,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
   const bool long_doc = S > 128;
   // XCD-aware order: 16 row tiles (their t panels stay in one XCD's L2) x all vocab tiles
   int mt, nt;
-  xcd_tile(long_doc ? Bdocs : (Ttot + 127) / 128, gridDim.x, HEAD_MG, mt, nt);
+  xcd_tile(long_doc ? Bdocs : (Ttot + 127) / 128, gridDim.x, HEAD_MG, mt, nt, xcd_on);
   if (mt < 0) return;
   const int n0 = nt * BN;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -315,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    nt_mainloop<T>(Tn, H, Ttot, m0, E, H, V, n0, H, smem, acc);  // ends with a barrier: staging is idle
+    nt_mainloop_glds<T>(Tn, H, Ttot, m0, E, H, V, n0, H, smem, acc);  // ends with a barrier: staging is idle
 
     // per 16-row group max (value, row-in-tile) for each of this lane's columns
 #pragma unroll
@@ -638,11 +718,17 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.drop = make_drop(epi ? &epi->drop : nullptr);
   e.residual = epi ? epi->residual : nullptr;
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
+  e.xcd = xcd_on;
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
-  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+  static const int glds_on = getenv("SM_GLDS") ? atoi(getenv("SM_GLDS")) : 1;
+  if (glds_on)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
   return 0;
 }
 
@@ -705,12 +791,13 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
   hipStream_t st = (hipStream_t)stream;
   const long T = (long)B * S;
+  static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
   const int mtiles = S > 128 ? B : sm_cdiv(T, 128);
   dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)
-    hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V, use_l0, xcd_on);
   else if (dtype == SM_F32)
-    hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V, use_l0);
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V, use_l0, xcd_on);
   else SM_REQUIRE(false, "sm_sparse_head_fwd: bad dtype %d", dtype);
   SM_LAUNCH_CHECK();
   return SM_OK;
