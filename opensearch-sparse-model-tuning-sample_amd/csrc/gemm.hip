@@ -166,7 +166,9 @@ __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int ld
   char* const sA = smem;
   char* const sB = smem + GL_NSTAGE * GL_STAGE;
   const int nk = K / BK;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // readfirstlane makes the wave id provably uniform: the LDS-DMA base goes to M0 without a
+  // per-load waterfall loop (v_readfirstlane / s_and_saveexec retry sequence)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
 #pragma unroll
   for (int s = 0; s < GL_NSTAGE - 1; ++s)
@@ -462,6 +464,190 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
       rep[(size_t)b * V + col] = y;
       argmax[(size_t)b * V + col] = (uint16_t)run_i;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent form of the fused head for H = 384 in bf16 (the v2-mini headline shape): one
+// workgroup (4 waves, one per SIMD, so each wave owns the full 512-register file) per 128-token
+// row tile.  Each wave keeps its 64 x 384 slice of t as MFMA A-fragments IN REGISTERS for its
+// whole life (192 VGPRs) and the whole LDS becomes a 16-stage global_load_lds ring through which
+// the tied embedding table E streams continuously across the 239 vocab tiles (128 vocab rows x
+// 32 k per stage, up to 14 stages = 112 KiB in flight per CU: enough to cover L2-miss latency at
+// the ~60 GB/s per CU the MFMAs can consume).  B fragments are double-buffered in registers so
+// the LDS reads of slice k+1 fly under the MFMAs of slice k; the epilogue is the (max, argmax)
+// reduction of the generic kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int AR_K = 384, AR_NST = 16, AR_SLICES = AR_K / 32;
+constexpr int AR_LDS = AR_NST * GL_STAGE + 8 * 128 * 4;
+
+// s_waitcnt vmcnt(2 * n) for a run-time n in [0, AR_NST - 3] (the count must be an immediate)
+__device__ __forceinline__ void wait_younger(int n) {
+  if (n >= AR_NST - 3) { asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); return; }  // steady state
+  switch (n) {
+#define SM_W(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N) : "memory"); break;
+    SM_W(0) SM_W(1) SM_W(2) SM_W(3) SM_W(4) SM_W(5) SM_W(6) SM_W(7) SM_W(8) SM_W(9) SM_W(10) SM_W(11) SM_W(12)
+#undef SM_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int DBG>
+__global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf16* __restrict__ Tn, const bf16* __restrict__ E,
+                                                                        const float* __restrict__ bias, const uint8_t* __restrict__ mask,
+                                                                        float* __restrict__ rep, uint16_t* __restrict__ argmax,
+                                                                        int Bdocs, int S, int V, int use_l0) {
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  char* const ring = dsmem;
+  float* const redv = reinterpret_cast<float*>(ring + AR_NST * GL_STAGE);
+  const int Ttot = Bdocs * S;
+  const int m0 = blockIdx.x * 128;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  const int nvt = (V + 127) / 128, nslice = nvt * AR_SLICES;
+
+  // per-lane source offsets of this wave's two 1-KiB pieces of a stage (elements, within a vocab
+  // tile): row = piece*16 + lane/4, swizzled 16-byte chunk; the stream position (vocab tile, k
+  // slice) of the next stage to issue is tracked incrementally in scalars
+  int eoff[2], erow[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    erow[p] = (w * 2 + p) * 16 + (lane >> 2);
+    eoff[p] = erow[p] * AR_K + (((lane & 3) ^ ((0 - (erow[p] >> 2)) & 3)) << 3);
+  }
+  int ivt = 0, iks = 0, istage = 0;
+  auto issue_next = [&]() {
+    const bf16* src = E + (size_t)ivt * 128 * AR_K + iks * 32;
+    char* st = ring + istage * GL_STAGE + w * 2048;
+    if (ivt == nvt - 1) {  // last vocab tile: rows past V are clamped (their columns are never stored)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int r = min(ivt * 128 + erow[p], V - 1) - ivt * 128;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + eoff[p] + (r - erow[p]) * AR_K), (lds_void_t*)(st + p * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + eoff[p]), (lds_void_t*)(st + p * 1024), 16, 0, 0);
+    }
+    if (++iks == AR_SLICES) { iks = 0; ++ivt; }
+    istage = (istage + 1) & (AR_NST - 1);
+  };
+#pragma unroll
+  for (int s = 0; s < AR_NST - 1; ++s) issue_next();
+  // resident A fragments: rows wm*64 + i*16 + li, k = 32*ks + 8*g .. +7
+  bf16x8 fa[AR_SLICES][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + wm * 64 + i * 16 + li, Ttot - 1);
+#pragma unroll
+    for (int ks = 0; ks < AR_SLICES; ++ks)
+      fa[ks][i] = *reinterpret_cast<const bf16x8*>(Tn + (size_t)row * AR_K + ks * 32 + g * 8);
+  }
+  uint32_t mrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 64 + i * 16 + g * 4;
+    mrow[i] = row < Ttot ? *reinterpret_cast<const uint32_t*>(mask + row) : 0u;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  bf16x8 fb[2][4];
+  auto load_b = [&](int gs, bf16x8 (&b)[4]) {
+    const char* st = ring + (gs & (AR_NST - 1)) * GL_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = GlFrag<bf16>::load(st, wn * 64 + i * 16 + li, 0, g);
+  };
+  load_b(0, fb[0]);  // slice 0 is complete (the vmcnt(0) above)
+
+  // Epilogue pipelining: the in-lane (max, argmax) reduction of a tile (64 accumulators -> 4
+  // candidates per lane) runs right after its last MFMA; the LDS exchange and the finalisation
+  // (bias, log1p, stores) of tile vt-1 ride inside tile vt's K-loop, behind its slice barriers.
+  // (max, argmax) travel as ONE float: the row-in-tile index (7 bits) replaces the low mantissa
+  // bits of the candidate, so a plain v_max3_f32 chain carries the arg-max along (the value keeps
+  // 17 mantissa bits, a 2^-17 relative perturbation, far inside the bf16 error of the inputs).
+  f32x4 acc[4][4];
+  float cand[4];
+  float mneg[4][4];  // 0 for attended rows, -3e38 for padded rows of this lane
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mneg[i][r] = ((mrow[i] >> (8 * r)) & 0xFFu) ? 0.f : -3.0e38f;  // finite: -inf | index bits would be a NaN
+  const int rbase = wm * 64 + g * 4;
+
+  auto finalize = [&](int vt) {
+    if (threadIdx.x < 128) {
+      const int col = vt * 128 + threadIdx.x;
+      float c[8];
+#pragma unroll
+      for (int grp = 0; grp < 8; ++grp) c[grp] = redv[grp * 128 + threadIdx.x];
+      const float lo = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), hi = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+      const int ndoc = 128 / S;  // S is 64 or 128 here: a document is one or both 64-row wave blocks
+      for (int dd = 0; dd < ndoc; ++dd) {
+        const int b = m0 / S + dd;
+        const float best = ndoc == 2 ? (dd ? hi : lo) : fmaxf(lo, hi);
+        if (b < Bdocs && col < V) {
+          const uint32_t bits = __float_as_uint(best);
+          float y = best < -1.0e37f ? 0.f : fmaxf(__uint_as_float(bits & 0xFFFFFF80u) + bias[col], 0.f);
+          y = log1pf(y);
+          if (use_l0) y = log1pf(y);
+          rep[(size_t)b * V + col] = y;
+          argmax[(size_t)b * V + col] = (uint16_t)((int)(bits & 0x7Fu) - dd * S);
+        }
+      }
+    }
+  };
+  auto publish = [&]() {  // candidates of the previous tile -> LDS (4 lane groups x 2 wave rows)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) redv[(wm * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j];
+  };
+
+  for (int vt = 0; vt < nvt; ++vt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < AR_SLICES; ++ks) {
+      const int gs = vt * AR_SLICES + ks;
+      // slice gs+1 must have landed; slices gs+2 .. gs+NST-2 stay in flight (2 loads per slice and
+      // wave, completion in issue order; the epilogue's stores only make this wait conservative)
+      if (!(DBG & 2) && gs + 1 < nslice) wait_younger(min(AR_NST - 3, nslice - 2 - gs));
+      if (ks == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // publish() of slice 0 is in LDS
+      __builtin_amdgcn_s_barrier();  // slice gs+1 landed for every wave; stage (gs-1) % NST is free
+      asm volatile("" ::: "memory");
+      if (!(DBG & 2) && gs + AR_NST - 1 < nslice) issue_next();
+      if (gs + 1 < nslice) load_b(gs + 1, fb[(ks + 1) & 1]);
+      if (!(DBG & 1) && vt > 0 && ks == 0) publish();
+      if (!(DBG & 1) && vt > 0 && ks == 1) finalize(vt - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+    // in-lane reduction: 16 rows per lane and column block, index packed into the low mantissa bits
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float best = -3.0e38f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] + mneg[i][r];
+          best = fmaxf(best, __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (uint32_t)(rbase + i * 16 + r)));
+        }
+      cand[j] = best;
+    }
+  }
+  if (!(DBG & 1)) {  // epilogue of the last tile
+    publish();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    finalize(nvt - 1);
+  } else if (cand[0] + cand[1] + cand[2] + cand[3] == 12345.678f) {
+    rep[threadIdx.x] = cand[0];
   }
 }
 
@@ -792,6 +978,29 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   hipStream_t st = (hipStream_t)stream;
   const long T = (long)B * S;
   static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
+  static const int ares_on = getenv("SM_ARES") ? atoi(getenv("SM_ARES")) : 1;
+  if (ares_on && dtype == SM_BF16 && H == AR_K && (S == 64 || S == 128) && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
+    static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
+#define SM_ARES_LAUNCH(D)                                                                                                   \
+    {                                                                                                                       \
+      auto kern = sparse_head_fwd_ares_kernel<D>;                                                                           \
+      SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));             \
+      hipLaunchKernelGGL(kern, dim3(sm_cdiv(T, 128)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias,     \
+                         mask, rep, argmax, B, S, V, use_l0);                                                               \
+    }
+    switch (dbg) {
+      case 1: SM_ARES_LAUNCH(1) break;
+      case 2: SM_ARES_LAUNCH(2) break;
+      case 3: SM_ARES_LAUNCH(3) break;
+      case 4: SM_ARES_LAUNCH(4) break;
+      case 5: SM_ARES_LAUNCH(5) break;
+      case 6: SM_ARES_LAUNCH(6) break;
+      default: SM_ARES_LAUNCH(0) break;
+    }
+#undef SM_ARES_LAUNCH
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   const int mtiles = S > 128 ? B : sm_cdiv(T, 128);
   dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)

@@ -211,7 +211,8 @@ def test_attention_dropout_consistent_between_fwd_and_bwd(ops, dtype):
 
 # ------------------------------------------------------------------ fused sparse head
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,H,V", [(6, 16, 64, 520), (5, 64, 128, 300), (3, 128, 128, 1000), (2, 256, 128, 260)])
+@pytest.mark.parametrize("B,S,H,V", [(6, 16, 64, 520), (5, 64, 128, 300), (3, 128, 128, 1000), (2, 256, 128, 260),
+                                     (3, 128, 384, 700), (5, 64, 384, 300), (5, 32, 384, 300)])
 @pytest.mark.parametrize("use_l0", [False, True])
 def test_sparse_head_fwd_bwd(ops, dtype, B, S, H, V, use_l0):
     t = q(rnd(B * S, H, seed=1), dtype)
