@@ -894,6 +894,116 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16 weight-gradient kernel on the LDS-DMA ring: same math as gemm_tn_kernel (C += A^T B over a
+// split of the token dimension, fp32 atomics), but both operands stream global -> LDS with
+// global_load_lds (4 stages of 32 token rows x 128 columns per operand, 3 in flight) and are read
+// back with the transposing ds_read_b64_tr_b16.  LDS rows are 256 B = one full bank row, so the
+// 32-byte slot index is XOR-swizzled with f(row) = (row & 3) | ((row >> 3) & 1) << 2, which makes
+// the 8 rows a 32-lane half touches per transposing read land on 8 distinct slots.
+// Requires M % 32 == 0, N % 128 == 0, Kc % 128 == 0 (every stage is a full tile: no zero fill).
+// ---------------------------------------------------------------------------------------
+constexpr int TG_BKM = 32, TG_STAGE = TG_BKM * 256, TG_NST = 4;
+__device__ __forceinline__ int tg_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x8 tg_load(const char* st, int colbase, int g, int li) {
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  const int q = li >> 2, p = li & 3;
+  const int r0 = 8 * g + q, r1 = r0 + 4;
+  const int cb = colbase * 2 + 8 * p;  // byte offset of this lane's 4 columns within the 256-B row
+  const char* a0 = st + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
+  const char* a1 = st + r1 * 256 + ((((cb >> 5) ^ tg_f(r1)) << 5) | (cb & 31));
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)a1);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_glds_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                                float* __restrict__ C, int ldc, int M, int N, int Kc,
+                                                                int rows_per_split, float* __restrict__ colsum) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TG_NST * TG_STAGE];
+  char* const sA = smem;
+  char* const sB = smem + TG_NST * TG_STAGE;
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  const int mbeg = blockIdx.z * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  if (mbeg >= mend) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  const int nst = (mend - mbeg) / TG_BKM;
+  // this wave's two 1-KiB pieces per operand and stage: 4 token rows x 256 B each
+  size_t aoff[2], boff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (w * 2 + p) * 4 + (lane >> 4);
+    const int cphys = lane & 15;
+    const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;  // logical column (elements)
+    aoff[p] = (size_t)(mbeg + row) * lda + n0 + clog;
+    boff[p] = (size_t)(mbeg + row) * ldb + k0 + clog;
+  }
+  auto issue = [&](int st) {
+    char* da = sA + (st % TG_NST) * TG_STAGE + w * 2048;
+    char* db = sB + (st % TG_NST) * TG_STAGE + w * 2048;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + aoff[p] + (size_t)st * TG_BKM * lda), (lds_void_t*)(da + p * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + boff[p] + (size_t)st * TG_BKM * ldb), (lds_void_t*)(db + p * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = colsum != nullptr && blockIdx.x == 0;
+  float csum = 0.f;
+#pragma unroll
+  for (int s = 0; s < TG_NST - 1; ++s)
+    if (s < nst) issue(s);
+  for (int st = 0; st < nst; ++st) {
+    const int younger = min(TG_NST - 2, nst - 1 - st);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + TG_NST - 1 < nst) issue(st + TG_NST - 1);
+    const char* a = sA + (st % TG_NST) * TG_STAGE;
+    const char* b = sB + (st % TG_NST) * TG_STAGE;
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = tg_load(a, wm * 64 + i * 16, g, li);
+      fb[i] = tg_load(b, wn * 64 + i * 16, g, li);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if (do_colsum && threadIdx.x < 128) {
+      const int cb = threadIdx.x * 2;
+#pragma unroll 8
+      for (int m = 0; m < TG_BKM; ++m)
+        csum += (float)*reinterpret_cast<const bf16*>(a + m * 256 + ((((cb >> 5) ^ tg_f(m)) << 5) | (cb & 31)));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = k0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + wm * 64 + i * 16 + g * 4 + r;
+        atomicAdd(&C[(size_t)row * ldc + col], acc[i][j][r]);
+      }
+    }
+  if (do_colsum && threadIdx.x < 128) atomicAdd(&colsum[n0 + threadIdx.x], csum);
+}
+
 template <typename T>
 int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const sm_epilogue* epi, hipStream_t st) {
@@ -930,6 +1040,14 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
   int rows_per_split = ((M + nsplit - 1) / nsplit + BKM - 1) / BKM * BKM;
   nsplit = (M + rows_per_split - 1) / rows_per_split;
   dim3 grid(sm_cdiv(Kc, 128), sm_cdiv(N, 128), nsplit);
+  static const int tn_glds = getenv("SM_TN_GLDS") ? atoi(getenv("SM_TN_GLDS")) : 0;  // experimental: the register-staged kernel is still faster
+  if constexpr (sizeof(T) == 2) {
+    if (tn_glds && M % TG_BKM == 0 && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
+      hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(NTHREADS), 0, st, (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, Kc,
+                         rows_per_split, colsum);
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, Kc,
                      rows_per_split, colsum);
   return 0;

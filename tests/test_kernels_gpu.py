@@ -95,7 +95,8 @@ def test_gemm_nt_dropout_is_a_scaled_mask_and_reproducible(ops, dtype):
 
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,Kc", [(300, 72, 136), (1024, 128, 128), (96, 192, 64), (2000, 64, 520 - 520 % 8)])
+@pytest.mark.parametrize("M,N,Kc", [(300, 72, 136), (1024, 128, 128), (96, 192, 64), (2000, 64, 520 - 520 % 8),
+                                    (4096, 384, 256), (2080, 128, 384)])
 def test_gemm_tn_acc(ops, dtype, M, N, Kc):
     A, B = q(rnd(M, N, seed=1, scale=0.5), dtype), q(rnd(M, Kc, seed=2, scale=0.5), dtype)
     init = rnd(N, Kc, seed=3)

@@ -19,3 +19,8 @@ E=torch.randn(30592,384,device='cuda').bfloat16()*0.02
 bias=torch.zeros(30522,device='cuda'); mask=torch.ones(512,128,dtype=torch.uint8,device='cuda')
 us=timeit(lambda: ops.sparse_head_fwd(x,E,bias,mask,512,128,30522,False),5)
 print(f"head_fwd: {us:.1f} us {2*T*384*30522/us/1e6:.0f} TF/s")
+for N,Kc in ((384,384),(1152,384),(1536,384),(384,1536)):
+    A=torch.randn(T,N,device='cuda').bfloat16(); B=torch.randn(T,Kc,device='cuda').bfloat16()
+    out=torch.zeros(N,Kc,device='cuda'); cs=torch.zeros(N,device='cuda')
+    us=timeit(lambda: ops.gemm_tn_acc(A,B,out,cs))
+    print(f"gemm_tn N={N} Kc={Kc}: {us:.1f} us  {2*T*N*Kc/us/1e6:.0f} TF/s")
