@@ -14,7 +14,8 @@ def _model(dtype, seed=0, dropout=0.0):
     cfg = BertConfigLite(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
     bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=seed)
     with torch.no_grad():  # spread the logits a little so roughly half of the activations are live
-        bb.view("cls.predictions.bias").normal_(0.0, 0.5, generator=None)
+        g = torch.Generator().manual_seed(seed + 99)
+        bb.view("cls.predictions.bias").copy_(torch.randn(cfg.vocab_size, generator=g) * 0.5)
     bb.mark_weights_dirty()
     return SparseModel(bb, use_l0=False), bb
 
