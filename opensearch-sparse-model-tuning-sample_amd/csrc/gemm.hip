@@ -155,8 +155,9 @@ template <> struct GlFrag<float> {
   }
 };
 
-// smem >= 2 * GL_NSTAGE * GL_STAGE (64 KiB); K % BK == 0
-template <typename T>
+// smem >= 2 * NST * GL_STAGE; K % BK == 0.  NST = 4: three stages in flight (64 KiB);
+// NST = 3: two in flight (48 KiB, lets three workgroups share a CU)
+template <typename T, int NST = GL_NSTAGE>
 __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int lda, int M, int m0,
                                                  const T* __restrict__ B, int ldb, int N, int n0, int K,
                                                  char* smem, f32x4 acc[4][4]) {
@@ -164,29 +165,29 @@ __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int ld
   using GF = GlFrag<T>;
   constexpr int BK = GF::BK;
   char* const sA = smem;
-  char* const sB = smem + GL_NSTAGE * GL_STAGE;
+  char* const sB = smem + NST * GL_STAGE;
   const int nk = K / BK;
   // readfirstlane makes the wave id provably uniform: the LDS-DMA base goes to M0 without a
   // per-load waterfall loop (v_readfirstlane / s_and_saveexec retry sequence)
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
 #pragma unroll
-  for (int s = 0; s < GL_NSTAGE - 1; ++s)
+  for (int s = 0; s < NST - 1; ++s)
     if (s < nk) glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, s * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt must have landed; the (up to two) younger stages stay in flight: 4 loads per stage and wave
-    const int younger = min(GL_NSTAGE - 2, nk - 1 - kt);
+    const int younger = min(NST - 2, nk - 1 - kt);
     if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces landed; stage (kt-1) % NSTAGE is free again
     asm volatile("" ::: "memory");
-    if (kt + GL_NSTAGE - 1 < nk) {
-      const int s = (kt + GL_NSTAGE - 1) % GL_NSTAGE;
-      glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, (kt + GL_NSTAGE - 1) * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
+    if (kt + NST - 1 < nk) {
+      const int s = (kt + NST - 1) % NST;
+      glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, (kt + NST - 1) * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
     }
-    const char* a = sA + (kt % GL_NSTAGE) * GL_STAGE;
-    const char* b = sB + (kt % GL_NSTAGE) * GL_STAGE;
+    const char* a = sA + (kt % NST) * GL_STAGE;
+    const char* b = sB + (kt % NST) * GL_STAGE;
 #pragma unroll
     for (int ks = 0; ks < GF::NS; ++ks) {
       typename MM::Frag fa[4], fb[4];
@@ -280,10 +281,12 @@ struct EpiArgs {
 template <typename T, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) char smem[128 * CS * 4 > 4 * TILE_BYTES ? 128 * CS * 4 : 4 * TILE_BYTES];
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so linear id L runs
-  // on XCD group L % 8.  All N-tiles of one M-tile are given to the same group, back to back, so
-  // the A row panel is fetched into that XCD's L2 once (placement only changes speed).
+  // LDS: the glds variant uses a 3-stage ring (48 KiB) and stages the epilogue in two 64-row halves
+  // (33 KiB), so three workgroups fit a CU and their main loops cover each other's epilogues
+  constexpr int NT_NST = 3;
+  constexpr int SMEM_GLDS = 2 * NT_NST * GL_STAGE, SMEM_REG = 4 * TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[GLDS ? SMEM_GLDS : SMEM_REG];
+  static_assert(64 * CS * 4 <= SMEM_GLDS, "epilogue half tile must fit the ring");
   int mt, nt;
   xcd_tile((M + BM - 1) / BM, gridDim.x, 1, mt, nt, e.xcd);
   if (mt < 0) return;
@@ -293,65 +296,72 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (GLDS) nt_mainloop_glds<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  if constexpr (GLDS) nt_mainloop_glds<T, NT_NST>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
   else nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
 
-  // Epilogue through LDS: the accumulators (MFMA C layout: 2-byte column fragments) are staged
-  // as an fp32 [128][CS] tile so that every global access of the epilogue -- C, preact, residual,
-  // gelu_grad_of, bias -- is a 16-byte row-contiguous vector (256 B per 16 lanes).
+  // Epilogue through LDS, 64 rows (one wave row) at a time: the accumulators (MFMA C layout: one
+  // column x 4 rows per lane) are staged as an fp32 [64][CS] tile so that every global access of the
+  // epilogue -- C, preact, residual, gelu_grad_of -- is a 16-byte row-contiguous vector.
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
   float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sC[(wm * 64 + i * 16 + g * 4 + r) * CS + wn * 64 + j * 16 + li] = acc[i][j][r];
-  __syncthreads();
   T* preact = reinterpret_cast<T*>(e.preact);
   const T* residual = reinterpret_cast<const T*>(e.residual);
   const T* ggo = reinterpret_cast<const T*>(e.gelu_grad_of);
   const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
   const int col = n0 + c * 8;
-  if (col >= N) return;
   const bool full = e.vec_ok && col + 8 <= N;
   float bv[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) bv[k] = (e.bias && col + k < N) ? e.bias[col + k] : 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();  // first half fully read before it is overwritten
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sC[(i * 16 + g * 4 + r) * CS + wn * 64 + j * 16 + li] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (col < N) {
 #pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
-    const int rt = r0 + 16 * it, row = m0 + rt;
-    if (row >= M) break;
-    const size_t off = (size_t)row * ldc + col;
-    float v[8];
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8 + 4);
+      for (int it = 0; it < 4; ++it) {
+        const int rt = r0 + 16 * it, row = m0 + half * 64 + rt;
+        if (row >= M) break;
+        const size_t off = (size_t)row * ldc + col;
+        float v[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8 + 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = lo[k] + bv[k]; v[4 + k] = hi[k] + bv[4 + k]; }
-    if (preact) store8<T>(preact + off, v, full, N - col);
-    if (e.act == 1) {
+        for (int k = 0; k < 4; ++k) { v[k] = lo[k] + bv[k]; v[4 + k] = hi[k] + bv[4 + k]; }
+        if (preact) store8<T>(preact + off, v, full, N - col);
+        if (e.act == 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+          for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+        }
+        if (e.drop.thresh16) {
+          const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = drop_keep1(e.drop, eb + k) ? v[k] * e.drop.scale : 0.f;
+        }
+        if (residual) {
+          float rv[8];
+          load8<T>(residual + off, rv, full, N - col);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += rv[k];
+        }
+        if (ggo) {
+          float xv[8];
+          load8<T>(ggo + off, xv, full, N - col);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(xv[k]);
+        }
+        store8<T>(C + off, v, full, N - col);
+      }
     }
-    if (e.drop.thresh16) {
-      const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = drop_keep1(e.drop, eb + k) ? v[k] * e.drop.scale : 0.f;
-    }
-    if (residual) {
-      float rv[8];
-      load8<T>(residual + off, rv, full, N - col);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += rv[k];
-    }
-    if (ggo) {
-      float xv[8];
-      load8<T>(ggo + off, xv, full, N - col);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(xv[k]);
-    }
-    store8<T>(C + off, v, full, N - col);
   }
 }
 
