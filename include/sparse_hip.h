@@ -49,6 +49,20 @@ typedef struct sm_dropout {
   uint32_t site;  /* distinct per call site */
 } sm_dropout;
 
+/* ---- ragged (un-padded) document layout -------------------------------------------------
+ * Optional for the token-level kernels below.  Documents are packed back to back along the row
+ * dimension; each document occupies a multiple of 16 rows (rows past its true length are masked),
+ * so a 16-row MFMA tile never straddles two documents.  With rag == NULL the layout is the
+ * reference's dense [B, S] (document b = rows b*S .. b*S+S-1).  With rag != NULL, `B` is the number
+ * of documents, `S` the largest padded document length (a supported bucket), and ids / masks are
+ * indexed by packed row. */
+typedef struct sm_ragged {
+  const int32_t* doc_off; /* [B+1] first packed row of each document (device) */
+  const int32_t* blk_doc; /* [rows/16] document of every 16-row block (device) */
+  const int32_t* pos_ids; /* [rows] position of every packed row inside its document (device) */
+  int rows;               /* total packed rows, multiple of 16 */
+} sm_ragged;
+
 /* ---- GEMM, Y = epilogue(A[M,K] . B[N,K]^T) --------------------------------------
  * replaces every nn.Linear forward (hf:175-177 QKV, :290 attn-out, :335 FFN-up,
  * :348 FFN-down, :477 MLM transform) and, with pre-transposed weights, every
@@ -86,10 +100,10 @@ int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamm
 int sm_embed_fwd(int dtype, const int64_t* ids, const void* word /*dtype [*,H]*/, const float* pos,
                  const float* type0, const float* gamma, const float* beta, void* z, void* y,
                  float* mean, float* rstd, int B, int S, int H, float eps, const sm_dropout* drop,
-                 void* stream);
+                 const sm_ragged* rag, void* stream);
 /* dz[T,H] -> gword[ids] += , gpos[s] += , gtype0 += (fp32 atomics) */
 int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, float* gpos, float* gtype0,
-                 int B, int S, int H, void* stream);
+                 int B, int S, int H, const sm_ragged* rag, void* stream);
 /* elementwise y = dropout_bwd(dy) (used for the embedding dropout backward) */
 int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const sm_dropout* drop, void* stream);
 
@@ -100,24 +114,25 @@ int sm_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, long n, void
  * qkv: [B*S, 3H] packed (q | k | v), heads are contiguous dh-slices; keymask: [B,S] 1 = attend.
  * ctx: [B*S, H]; lse: [B, A, S] fp32 log-sum-exp of the scaled masked scores. */
 int sm_attention_fwd(int dtype, const void* qkv, const uint8_t* keymask, void* ctx, float* lse,
-                     int B, int S, int A, int dh, const sm_dropout* drop, void* stream);
+                     int B, int S, int A, int dh, const sm_dropout* drop, const sm_ragged* rag, void* stream);
 int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keymask, const void* ctx,
                      const void* dctx, const float* lse, void* dqkv, int B, int S, int A, int dh,
-                     const sm_dropout* drop, void* stream);
+                     const sm_dropout* drop, const sm_ragged* rag, void* stream);
 
 /* ---- fused MLM decoder + mask + seq-max + log1p(relu)  (hf:490-496 decoder ->
  * scripts/model/sparse_encoders.py:108-114).  t: [B*S,H] dtype, E: [>=V,H] dtype (tied
  * word embeddings), bias [V].  Writes rep[B,V] fp32 and argmax[B,V] (position of the max).
  * Never materialises the [B,S,V] logits. */
 int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
-                       float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, void* stream);
+                       float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0,
+                       const sm_ragged* rag, uint64_t* scratch /* [B,V], ragged layout only */, void* stream);
 /* scripts/model/sparse_encoders.py:115-119 ratio prune, in place on rep */
 int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream);
 /* backward of the fused head: given grad_rep[B,V] produces dt[B*S,H] (dtype),
  * dE[V,H] += (fp32), dbias[V] += .  Sparse: one non-zero logit gradient per (b,v). */
 int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax,
                        const void* t, const void* E, void* dt, float* dE, float* dbias,
-                       int B, int S, int H, int V, int use_l0, void* stream);
+                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, void* stream);
 
 /* ---- inference-free query encoder (scripts/model/sparse_encoders.py:121-127) ----------- */
 int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,

@@ -109,12 +109,14 @@ template <int NT> struct SeqProd<float, NT> {
 // cooperative staging of a [S][DH] slice (row stride `ld` elements in global) into LDS:
 // row-major image (stride rs bytes) and / or transposed image [DH][S] (stride rst bytes)
 template <typename T, int DH>
-__device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int S, char* rowimg, int rs, char* timg, int rst) {
+__device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int nvalid, int ntotal, char* rowimg, int rs, char* timg, int rst) {
+  // rows [0, nvalid) come from global memory, rows [nvalid, ntotal) are zero-filled (a ragged
+  // document shorter than the LDS image must not expose its neighbour's rows or stale NaNs)
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int CPR = DH / EPC;             // chunks per row
-  for (int idx = threadIdx.x; idx < S * CPR; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < ntotal * CPR; idx += blockDim.x) {
     const int r = idx / CPR, c = idx % CPR;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * EPC);
+    const uint4 v = r < nvalid ? *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * EPC) : make_uint4(0, 0, 0, 0);
     if (rowimg) *reinterpret_cast<uint4*>(rowimg + r * rs + c * 16) = v;
     if (timg) {
       const T* e = reinterpret_cast<const T*>(&v);
@@ -142,26 +144,31 @@ struct Lay {  // LDS strides (bytes); +16 keeps 16-byte alignment and rotates ba
 // ------------------------------------------------------------------------------------
 template <typename T, int DH, int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
-                                                       T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop) {
+                                                       T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
+                                                       const int32_t* __restrict__ doc_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lay<T, DH>;
   constexpr int NKS = DH / AT<T>::KSTEP;
   const int H = A * DH;
   const size_t ld = 3 * (size_t)H;
   const int b = blockIdx.x / A, h = blockIdx.x % A;
-  const int nkt = S / 16;
+  // dense layout: document b = rows [b*S, b*S+S); ragged: rows [doc_off[b], doc_off[b+1]), a multiple of 16
+  const int row0 = doc_off ? doc_off[b] : b * S;
+  const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
+  const int nqb = Lr / 16;             // query blocks that exist
+  const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
   char* sK = smem;                          // [S][DH] row-major
   char* sVt = sK + S * L::RS;               // [DH][S] transposed
   uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + DH * L::rst(S));
-  const T* base = qkv + (size_t)b * S * ld + h * DH;
-  stage<T, DH>(base + H, ld, S, sK, L::RS, nullptr, 0);
-  stage<T, DH>(base + 2 * H, ld, S, nullptr, 0, sVt, L::rst(S));
-  for (int i = threadIdx.x; i < S; i += blockDim.x) sM[i] = keymask[(size_t)b * S + i];
+  const T* base = qkv + (size_t)row0 * ld + h * DH;
+  stage<T, DH>(base + H, ld, Lr, nkt * 16, sK, L::RS, nullptr, 0);
+  stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, nullptr, 0, sVt, L::rst(S));
+  for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const float scale = rsqrtf((float)DH);
-  for (int qb = w; qb < nkt; qb += 4) {
+  for (int qb = w; qb < nqb; qb += 4) {
     typename AT<T>::Frag fq[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fq[ks] = grow_frag<T>(base, ld, qb * 16 + li, ks, g);
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
       const f32x4 o = SeqProd<T, NKT>::run(sVt, L::rst(S), dt * 16 + li, g, p, nkt);
-      store4<T>(ctx + ((size_t)b * S + q) * H + h * DH + dt * 16 + 4 * g, o);
+      store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
     }
   }
 }
@@ -220,14 +227,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 template <typename T, int DH, int NKT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
-                                                       const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop) {
+                                                       const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop,
+                                                       const int32_t* __restrict__ doc_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Lay<T, DH>;
   constexpr int NKS = DH / AT<T>::KSTEP;
   const int H = A * DH;
   const size_t ld = 3 * (size_t)H;
   const int b = blockIdx.x / A, h = blockIdx.x % A;
-  const int nt = S / 16;
+  const int row0 = doc_off ? doc_off[b] : b * S;
+  const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
+  const int nblk = Lr / 16;            // 16-row blocks that exist (outputs are written for these)
+  const int nt = (nblk + 1) & ~1;      // tiles of the LDS images, rounded up to a pair (zero-filled)
   const int rst = L::rst(S);
   char* sQ = smem;
   char* sK = sQ + S * L::RS;
@@ -239,28 +250,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   float* sLse = reinterpret_cast<float*>(sDOt + DH * rst);
   float* sDelta = sLse + S;
   uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
-  const T* base = qkv + (size_t)b * S * ld + h * DH;
-  const T* dob = dctx + (size_t)b * S * H + h * DH;
-  const T* ob = ctx + (size_t)b * S * H + h * DH;
-  stage<T, DH>(base, ld, S, sQ, L::RS, sQt, rst);
-  stage<T, DH>(base + H, ld, S, sK, L::RS, sKt, rst);
-  stage<T, DH>(base + 2 * H, ld, S, sV, L::RS, nullptr, 0);
-  stage<T, DH>(dob, H, S, sDO, L::RS, sDOt, rst);
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {
-    sM[i] = keymask[(size_t)b * S + i];
-    sLse[i] = lse[(size_t)(b * A + h) * S + i];
+  const T* base = qkv + (size_t)row0 * ld + h * DH;
+  const T* dob = dctx + (size_t)row0 * H + h * DH;
+  const T* ob = ctx + (size_t)row0 * H + h * DH;
+  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, sQt, rst);
+  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, sKt, rst);
+  stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sV, L::RS, nullptr, 0);
+  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, sDOt, rst);
+  for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
     float d = 0.f;
-    for (int c = 0; c < DH; ++c) d += to_f32<T>(dob[(size_t)i * H + c]) * to_f32<T>(ob[(size_t)i * H + c]);
+    if (i < Lr)
+      for (int c = 0; c < DH; ++c) d += to_f32<T>(dob[(size_t)i * H + c]) * to_f32<T>(ob[(size_t)i * H + c]);
+    sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
+    sLse[i] = i < Lr ? lse[(size_t)(b * A + h) * S + i] : 0.f;
     sDelta[i] = d;
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const float scale = rsqrtf((float)DH);
-  T* dq_out = dqkv + (size_t)b * S * ld + h * DH;
+  T* dq_out = dqkv + (size_t)row0 * ld + h * DH;
 
   // ---- phase A: per query block, S^T orientation (rows = keys, col = query) -> dQ ----
-  for (int qb = w; qb < nt; qb += 4) {
+  for (int qb = w; qb < nblk; qb += 4) {
     const int q = qb * 16 + li;
     typename AT<T>::Frag fq[NKS], fdo[NKS];
 #pragma unroll
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   }
 
   // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
-  for (int kb = w; kb < nt; kb += 4) {
+  for (int kb = w; kb < nblk; kb += 4) {
     const int key = kb * 16 + li;
     typename AT<T>::Frag fk[NKS], fv[NKS];
 #pragma unroll
@@ -344,22 +356,23 @@ size_t bwd_lds(int S) { return 4 * (size_t)S * Lay<T, DH>::RS + 3 * (size_t)DH *
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename T, int DH, int NKT>
-int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B, int S, int A, const DropCfg& d, hipStream_t st) {
+int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B, int S, int A, const DropCfg& d, const int32_t* doc_off,
+               hipStream_t st) {
   const size_t lds = fwd_lds<T, DH>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
   auto kern = attn_fwd_kernel<T, DH, NKT>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d);
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
 }
 template <typename T, int DH, int NKT>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
-               int B, int S, int A, const DropCfg& d, hipStream_t st) {
+               int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
   const size_t lds = bwd_lds<T, DH>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
   auto kern = attn_bwd_kernel<T, DH, NKT>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d);
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
   return SM_OK;
 }
 
@@ -387,24 +400,24 @@ int check_shape(const char* who, int dtype, int B, int S, int A, int dh) {
   } while (0)
 
 extern "C" int sm_attention_fwd(int dtype, const void* qkv, const uint8_t* keymask, void* ctx, float* lse, int B, int S,
-                                int A, int dh, const sm_dropout* drop, void* stream) {
+                                int A, int dh, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
   int rc = check_shape("sm_attention_fwd", dtype, B, S, A, dh);
   if (rc != SM_OK) return rc;
   const DropCfg d = make_drop(drop);
   hipStream_t st = (hipStream_t)stream;
-  ATT_DISPATCH(launch_fwd, qkv, keymask, ctx, lse, B, S, A, d, st);
+  ATT_DISPATCH(launch_fwd, qkv, keymask, ctx, lse, B, S, A, d, rag ? rag->doc_off : nullptr, st);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
 
 extern "C" int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keymask, const void* ctx, const void* dctx,
                                 const float* lse, void* dqkv, int B, int S, int A, int dh, const sm_dropout* drop,
-                                void* stream) {
+                                const sm_ragged* rag, void* stream) {
   int rc = check_shape("sm_attention_bwd", dtype, B, S, A, dh);
   if (rc != SM_OK) return rc;
   const DropCfg d = make_drop(drop);
   hipStream_t st = (hipStream_t)stream;
-  ATT_DISPATCH(launch_bwd, qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, st);
+  ATT_DISPATCH(launch_bwd, qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, rag ? rag->doc_off : nullptr, st);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -375,13 +375,16 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __restrict__ Tn, const T* __restrict__ E,
                                                                    const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                                    float* __restrict__ rep, uint16_t* __restrict__ argmax,
-                                                                   int Bdocs, int S, int H, int V, int use_l0, int xcd_on) {
+                                                                   int Bdocs, int S, int H, int V, int use_l0, int xcd_on,
+                                                                   const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
+                                                                   int rag_rows, unsigned long long* __restrict__ packed) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   // the per-group reduction scratch overlays the (then idle) staging buffers
   float* redv = reinterpret_cast<float*>(smem);  // [8 groups][128 cols]
   int* redi = reinterpret_cast<int*>(redv + 8 * 128);
-  const int Ttot = Bdocs * S;
-  const bool long_doc = S > 128;
+  const bool ragged = doc_off != nullptr;
+  const int Ttot = ragged ? rag_rows : Bdocs * S;
+  const bool long_doc = !ragged && S > 128;
   // XCD-aware order: 16 row tiles (their t panels stay in one XCD's L2) x all vocab tiles
   int mt, nt;
   xcd_tile(long_doc ? Bdocs : (Ttot + 127) / 128, gridDim.x, HEAD_MG, mt, nt, xcd_on);
@@ -437,7 +440,31 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
     __syncthreads();
     if (threadIdx.x < 128) {
       const int col = n0 + threadIdx.x;
-      if (long_doc) {
+      if (ragged) {
+        // a 16-row block belongs to one document; consecutive blocks of the same document are
+        // merged here and each (document, column) candidate is folded into a 64-bit
+        // (relu(max + bias) bits, position) word with atomicMax -- non-negative floats order
+        // like unsigned integers, so documents that span several row tiles combine exactly
+        int cur = -1;
+        unsigned long long best = 0ull;
+        const int nblk = Ttot / 16, blk0 = m0 / 16;
+        for (int grp = 0; grp < 8 && blk0 + grp < nblk; ++grp) {
+          const int d = blk_doc[blk0 + grp];
+          if (d != cur) {
+            if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+            cur = d;
+            best = 0ull;
+          }
+          const float v = redv[grp * 128 + threadIdx.x];
+          if (v > -INFINITY && col < V) {
+            const float y = fmaxf(v + bias[col], 0.f);
+            const unsigned pos = (unsigned)(m0 + redi[grp * 128 + threadIdx.x] - doc_off[d]);
+            const unsigned long long cand = ((unsigned long long)__float_as_uint(y) << 32) | (0xFFFFu - pos);
+            if (y > 0.f && cand > best) best = cand;
+          }
+        }
+        if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+      } else if (long_doc) {
 #pragma unroll
         for (int grp = 0; grp < 8; ++grp) {
           const float v = redv[grp * 128 + threadIdx.x];
@@ -474,6 +501,18 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_kernel(const T* __re
       rep[(size_t)b * V + col] = y;
       argmax[(size_t)b * V + col] = (uint16_t)run_i;
     }
+  }
+}
+
+// ragged layout: unpack the 64-bit (value bits, 0xFFFF - position) words into rep / argmax
+__global__ void head_unpack_kernel(const unsigned long long* __restrict__ packed, float* __restrict__ rep,
+                                   uint16_t* __restrict__ argmax, long n, int use_l0) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long w = packed[i];
+    float y = log1pf(__uint_as_float((unsigned)(w >> 32)));
+    if (use_l0) y = log1pf(y);
+    rep[i] = y;
+    argmax[i] = w ? (uint16_t)(0xFFFFu - (unsigned)(w & 0xFFFFu)) : (uint16_t)0;
   }
 }
 
@@ -794,7 +833,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
                                                                 const uint16_t* __restrict__ argmax, const T* __restrict__ E,
-                                                                T* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0) {
+                                                                T* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0,
+                                                                const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
+                                                                int rag_rows) {
   using MM = Mma<T>;
   constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
   constexpr int ESTAGE = BK * Tn<T>::RS;
@@ -804,11 +845,19 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 2 * ESTAGE];
   char* const sG = smem;
   char* const sE = smem + 2 * TILE_BYTES;
-  const int Ttot = Bdocs * S;
+  const bool ragged = doc_off != nullptr;
+  const int Ttot = ragged ? rag_rows : Bdocs * S;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  const int ndoc = S >= 128 ? 1 : 128 / S;
-  const int b0 = m0 / S;
-  const int loff = S >= 128 ? m0 % S : 0;  // first sequence position covered by this tile
+  // documents that own rows of this tile: dense layout -> 128/S whole documents (or a 128-row window of
+  // one long document); ragged layout -> the contiguous range blk_doc[first block] .. blk_doc[last block]
+  int ndoc = S >= 128 ? 1 : 128 / S;
+  int b0 = m0 / S;
+  const int loff = (!ragged && S >= 128) ? m0 % S : 0;  // first sequence position covered by this tile
+  if (ragged) {
+    const int blk0 = m0 / 16, blk1 = min(blk0 + 7, Ttot / 16 - 1);
+    b0 = blk_doc[blk0];
+    ndoc = blk_doc[blk1] - b0 + 1;
+  }
   const int kk = threadIdx.x % BK, rg = threadIdx.x / BK;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
@@ -840,8 +889,10 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
       if (dd < ndoc && v < V && b0 + dd < Bdocs) {
         const size_t o = (size_t)(b0 + dd) * V + v;
         const float gr = grad_rep[o] * head_fprime(rep[o], use_l0);
-        const int row = (int)argmax[o] - loff + dd * S;
-        if (gr != 0.f && row >= dd * S && row < 128) {
+        const int rbase = ragged ? doc_off[b0 + dd] - m0 : dd * S - loff;  // tile row of the document's position 0
+        const int row = (int)argmax[o] + rbase;
+        const int lo = ragged ? 0 : dd * S;
+        if (gr != 0.f && row >= lo && row < 128) {
           gval[q] = gr;
           goff[q] = row * 128 + ((((cb >> 4) ^ (row & 7))) << 4) + (cb & 15);
         }
@@ -1097,16 +1148,37 @@ extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, 
 }
 
 extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
-                                  float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, void* stream) {
+                                  float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, const sm_ragged* rag,
+                                  uint64_t* scratch, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_fwd: empty problem");
   SM_REQUIRE(H % 64 == 0, "sm_sparse_head_fwd: H=%d must be a multiple of 64", H);
-  SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0),
-             "sm_sparse_head_fwd: S=%d must be 16/32/64/128 or a multiple of 128 (pad the batch)", S);
   SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
+  SM_REQUIRE(dtype == SM_BF16 || dtype == SM_F32, "sm_sparse_head_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  const long T = (long)B * S;
   static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
   static const int ares_on = getenv("SM_ARES") ? atoi(getenv("SM_ARES")) : 1;
+  if (rag) {
+    // ragged layout: per-(document, column) candidates meet in a 64-bit atomicMax scratch
+    SM_REQUIRE(scratch != nullptr && rag->rows > 0 && rag->rows % 16 == 0, "sm_sparse_head_fwd: ragged layout needs scratch and rows % 16 == 0");
+    SM_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)B * V * sizeof(uint64_t), st));
+    const int mtiles = sm_cdiv(rag->rows, 128);
+    dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
+    unsigned long long* pk = reinterpret_cast<unsigned long long*>(scratch);
+    if (dtype == SM_BF16)
+      hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax,
+                         B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
+    else
+      hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax,
+                         B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
+    SM_LAUNCH_CHECK();
+    const long n = (long)B * V;
+    hipLaunchKernelGGL(head_unpack_kernel, dim3(2048), dim3(256), 0, st, pk, rep, argmax, n, use_l0);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
+  SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0),
+             "sm_sparse_head_fwd: S=%d must be 16/32/64/128 or a multiple of 128 (pad the batch)", S);
+  const long T = (long)B * S;
   if (ares_on && dtype == SM_BF16 && H == AR_K && (S == 64 || S == 128) && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
     static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
 #define SM_ARES_LAUNCH(D)                                                                                                   \
@@ -1132,25 +1204,32 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   const int mtiles = S > 128 ? B : sm_cdiv(T, 128);
   dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)
-    hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V, use_l0, xcd_on);
-  else if (dtype == SM_F32)
-    hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V, use_l0, xcd_on);
-  else SM_REQUIRE(false, "sm_sparse_head_fwd: bad dtype %d", dtype);
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V,
+                       use_l0, xcd_on, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, (unsigned long long*)nullptr);
+  else
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V,
+                       use_l0, xcd_on, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, (unsigned long long*)nullptr);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
 
 // dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
-                      int B, int S, int H, int V, int use_l0, hipStream_t st) {
-  SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0), "sm_sparse_head_bwd: S=%d unsupported", S);
+                      int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st) {
+  SM_REQUIRE(rag || (S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0)), "sm_sparse_head_bwd: S=%d unsupported", S);
   SM_REQUIRE(H % 8 == 0, "sm_sparse_head_bwd: H=%d must be a multiple of 8", H);
-  const long T = (long)B * S;
+  const long T = rag ? rag->rows : (long)B * S;
+  const int32_t* doc_off = rag ? rag->doc_off : nullptr;
+  const int32_t* blk_doc = rag ? rag->blk_doc : nullptr;
+  const int rrows = rag ? rag->rows : 0;
+  if (rag) S = 128;
   dim3 grid(sm_cdiv(H, 128), sm_cdiv(T, 128));
   if (dtype == SM_BF16)
-    hipLaunchKernelGGL(head_dt_mfma_kernel<bf16>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt, B, S, H, V, use_l0);
+    hipLaunchKernelGGL(head_dt_mfma_kernel<bf16>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt, B, S, H, V, use_l0,
+                       doc_off, blk_doc, rrows);
   else
-    hipLaunchKernelGGL(head_dt_mfma_kernel<float>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const float*)E, (float*)dt, B, S, H, V, use_l0);
+    hipLaunchKernelGGL(head_dt_mfma_kernel<float>, grid, dim3(NTHREADS), 0, st, grad_rep, rep, argmax, (const float*)E, (float*)dt, B, S, H, V, use_l0,
+                       doc_off, blk_doc, rrows);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

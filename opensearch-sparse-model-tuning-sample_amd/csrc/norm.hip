@@ -156,12 +156,13 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ pos, const float* __restrict__ type0,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         T* __restrict__ z, T* __restrict__ y, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, int rows, int S, int H, float eps, DropCfg drop) {
+                                                        float* __restrict__ rstd, int rows, int S, int H, float eps, DropCfg drop,
+                                                        const int32_t* __restrict__ pos_ids) {
   const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
   const int nch = H >> 3;
   for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
     const int64_t id = ids[row];
-    const int s = row % S;
+    const int s = pos_ids ? pos_ids[row] : row % S;
     float v[NCH][8];
     float sum = 0.f;
 #pragma unroll
@@ -207,29 +208,29 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// grid (S, nsplit): block (s, z) sums dz[b, s, :] over its share of the documents.  Scalar-column
-// mapping (lane <-> columns lane + 64 i) so every float-atomic wave instruction covers 256
-// contiguous bytes of one word-embedding row (the full-rate atomic shape on gfx950).
+// Row-based scatter of the embedding gradient.  Scalar-column mapping (lane <-> columns lane + 64 i)
+// so every float-atomic wave instruction covers 256 contiguous bytes of one table row (the
+// full-rate atomic shape on gfx950); rows whose gradient is exactly zero (padding) are skipped.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz, const int64_t* __restrict__ ids,
                                                         float* __restrict__ gword, float* __restrict__ gpos,
-                                                        float* __restrict__ gtype0, int B, int S, int H) {
+                                                        float* __restrict__ gtype0, int rows, int S, int H,
+                                                        const int32_t* __restrict__ pos_ids) {
   __shared__ float red[4][MAXC * 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nc = H >> 6;
-  const int s = blockIdx.x;
   float acc[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) acc[i] = 0.f;
-  for (int b = blockIdx.y * 4 + w; b < B; b += gridDim.y * 4) {
-    const size_t row = (size_t)b * S + s;
+  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
     const int64_t id = ids[row];
+    const int s = pos_ids ? pos_ids[row] : row % S;
     float gv[MAXC];
     bool nz = false;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
       if (i < nc) {
-        gv[i] = to_f32<T>(dz[row * H + lane + 64 * i]);
+        gv[i] = to_f32<T>(dz[(size_t)row * H + lane + 64 * i]);
         acc[i] += gv[i];
         nz |= gv[i] != 0.f;
       }
@@ -238,18 +239,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dz
     if (__any(nz)) {
 #pragma unroll
       for (int i = 0; i < MAXC; ++i)
-        if (i < nc) atomicAdd(&gword[(size_t)id * H + lane + 64 * i], gv[i]);
+        if (i < nc) {
+          atomicAdd(&gword[(size_t)id * H + lane + 64 * i], gv[i]);
+          atomicAdd(&gpos[(size_t)s * H + lane + 64 * i], gv[i]);
+        }
     }
   }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
     if (i < nc) red[w][lane + 64 * i] = acc[i];
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-    atomicAdd(&gpos[(size_t)s * H + c], t);
-    atomicAdd(&gtype0[c], t);
-  }
+  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&gtype0[c], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
 template <typename T>
@@ -324,26 +324,29 @@ extern "C" int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
 
 extern "C" int sm_embed_fwd(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0,
                             const float* gamma, const float* beta, void* z, void* y, float* mean, float* rstd, int B,
-                            int S, int H, float eps, const sm_dropout* drop, void* stream) {
+                            int S, int H, float eps, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && H % 64 == 0 && H <= 1024, "sm_embed_fwd: B=%d S=%d H=%d", B, S, H);
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(drop);
-  const int rows = B * S;
+  const int rows = rag ? rag->rows : B * S;
+  const int32_t* pos_ids = rag ? rag->pos_ids : nullptr;
   SM_DISPATCH(dtype, "sm_embed_fwd",
               LN_NCH(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NCH>), dim3(row_grid16(rows)), dim3(256), 0, st, ids, (const T*)word, pos, type0,
-                                           gamma, beta, (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d)));
+                                           gamma, beta, (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d, pos_ids)));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
 
 extern "C" int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, float* gpos, float* gtype0,
-                            int B, int S, int H, void* stream) {
+                            int B, int S, int H, const sm_ragged* rag, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && H % 64 == 0 && H <= 1024, "sm_embed_bwd: B=%d S=%d H=%d", B, S, H);
   hipStream_t st = (hipStream_t)stream;
-  int nsplit = sm_cdiv(1024, S);
-  if (nsplit > sm_cdiv(B, 4)) nsplit = sm_cdiv(B, 4);
+  const int rows = rag ? rag->rows : B * S;
+  int grid = sm_cdiv(rows, 32);
+  if (grid > 1024) grid = 1024;
   SM_DISPATCH(dtype, "sm_embed_bwd",
-              hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(S, nsplit), dim3(256), 0, st, (const T*)dz, ids, gword, gpos, gtype0, B, S, H));
+              hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)dz, ids, gword, gpos, gtype0, rows, S, H,
+                                 rag ? rag->pos_ids : nullptr));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -5,7 +5,7 @@
 #include "common.h"
 
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
-                      int B, int S, int H, int V, int use_l0, hipStream_t st);
+                      int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
 
 namespace {
 
@@ -56,7 +56,7 @@ template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_de_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
                                                       const uint16_t* __restrict__ argmax, const T* __restrict__ t,
                                                       float* __restrict__ dE, float* __restrict__ dbias, int B, int S, int H,
-                                                      int V, int use_l0) {
+                                                      int V, int use_l0, const int32_t* __restrict__ doc_off) {
   __shared__ float sg[256][16];
   __shared__ uint16_t sl[256][16];
   const int v0 = blockIdx.x * 16;
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void head_de_kernel(const float* __restrict__ 
         const float gv = sg[bb][vi];
         if (gv != 0.f) {
           gsum[k] += gv;
-          const T* tr = t + ((size_t)(b0 + bb) * S + sl[bb][vi]) * H;
+          const size_t r0 = doc_off ? (size_t)doc_off[b0 + bb] : (size_t)(b0 + bb) * S;  // first row of the document
+          const T* tr = t + (r0 + sl[bb][vi]) * H;
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[k][c] += gv * to_f32<T>(tr[lane + 64 * c]);
         }
@@ -457,19 +458,19 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ s
 
 extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t,
                                   const void* E, void* dt, float* dE, float* dbias, int B, int S, int H, int V, int use_l0,
-                                  void* stream) {
+                                  const sm_ragged* rag, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_bwd: empty problem");
   SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   {
-    const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, st);
+    const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
     if (rc != SM_OK) return rc;
   }
   const int nc = H / 64;
   dim3 grid(sm_cdiv(V, 16));
 #define LAUNCH_DE(T, NC) \
-  hipLaunchKernelGGL((head_de_kernel<T, NC>), grid, dim3(256), 0, st, grad_rep, rep, argmax, (const T*)t, dE, dbias, B, S, H, V, use_l0)
+  hipLaunchKernelGGL((head_de_kernel<T, NC>), grid, dim3(256), 0, st, grad_rep, rep, argmax, (const T*)t, dE, dbias, B, S, H, V, use_l0, rag ? rag->doc_off : nullptr)
 #define DISPATCH_NC(T)                                                         \
   switch (nc) {                                                                \
     case 1: LAUNCH_DE(T, 1); break;                                            \

@@ -15,7 +15,8 @@ from torch.utils.data import Dataset
 
 class SyntheticTriplesDataset(Dataset):
     def __init__(self, n_samples: int, docs_per_query: int, doc_len: int, query_len: int = 32, vocab_size: int = 30522,
-                 seed: int = 1234, with_scores: bool = False, full_length_docs: bool = False):
+                 seed: int = 1234, with_scores: bool = False, full_length_docs: bool = False,
+                 len_mean: float = 80.0, len_std: float = 30.0):
         rng = np.random.default_rng(seed)
         k, S, Sq = docs_per_query, doc_len, query_len
         lo = min(1000, vocab_size // 2)
@@ -25,7 +26,7 @@ class SyntheticTriplesDataset(Dataset):
         if full_length_docs:
             d_len = np.full((n_samples, k), S, dtype=np.int64)
         else:
-            d_len = np.clip(np.rint(rng.normal(80, 30, (n_samples, k))), min(16, S), S).astype(np.int64)
+            d_len = np.clip(np.rint(rng.normal(len_mean, len_std, (n_samples, k))), min(16, S), S).astype(np.int64)
         q_tok = rng.integers(lo, vocab_size, size=(n_samples, Sq))
         d_tok = rng.integers(lo, vocab_size, size=(n_samples, k, S))
         qpos = np.arange(Sq)[None, :]

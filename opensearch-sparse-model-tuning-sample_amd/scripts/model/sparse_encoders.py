@@ -115,7 +115,7 @@ class SparseModel(torch.nn.Module):
         # reference: logits -> * mask -> max over seq -> log1p(relu) [-> log1p] [-> prune]; here
         # one fused decoder kernel, the [B,S,V] logits are never materialised
         return self.backbone.encode(kwargs["input_ids"], kwargs["attention_mask"], use_l0=self.use_l0,
-                                    prune_ratio=self.prune_ratio)
+                                    prune_ratio=self.prune_ratio, packed=kwargs.get("packed"))
 
     def _encode_inf_free(self, **kwargs):
         return F.inf_free_encode(kwargs["input_ids"], self.idf_vector, self._special)

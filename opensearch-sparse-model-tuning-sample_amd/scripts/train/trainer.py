@@ -36,7 +36,8 @@ class ModelWrapper(torch.nn.Module):
         self.inf_free = inf_free
 
     def forward(self, inputs):
-        d_rep = self.sparse_model(inf_free=False, input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"])
+        d_rep = self.sparse_model(inf_free=False, input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                                  packed=inputs.get("packed"))
         q_rep = self.sparse_model(inf_free=self.inf_free, input_ids=inputs["q_input_ids"],
                                   attention_mask=inputs["q_attention_mask"])
         return d_rep, q_rep
@@ -139,6 +140,7 @@ class SparseModelTrainer:
             "q_attention_mask": inputs["query"][0]["attention_mask"],
             "input_ids": inputs["docs"][0]["input_ids"],
             "attention_mask": inputs["docs"][0]["attention_mask"],
+            "packed": inputs["docs"][0].get("packed"),  # host-packed ragged layout (see _prepare_inputs)
         }
         d_rep, q_rep = model(model_wrapper_input)
         # inference-free queries have at most one non-zero per query token: let the losses use the
@@ -218,13 +220,29 @@ class SparseModelTrainer:
 
     # ------------------------------------------------------------------ step driver
     def _prepare_inputs(self, obj):
+        """H2D copy of the collator output.  The student's document encoding is additionally packed on
+        the host into the ragged layout (padding tokens are then never computed on the device)."""
+        out = self._to_device(obj)
+        try:
+            enc = obj["docs"][0]
+            bb = self.model.sparse_model.backbone
+            if getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda:
+                from sparse_hip.encoder import pack_documents
+                packed = pack_documents(enc["input_ids"], enc["attention_mask"], self.accelerator.device, bb.config.pad_token_id)
+                if packed is not None:
+                    out["docs"][0]["packed"] = packed
+        except (KeyError, IndexError, TypeError, AttributeError):
+            pass
+        return out
+
+    def _to_device(self, obj):
         dev = self.accelerator.device
         if isinstance(obj, torch.Tensor):
             return obj.to(dev, non_blocking=True)
         if isinstance(obj, dict) or hasattr(obj, "items"):
-            return {k: self._prepare_inputs(v) for k, v in obj.items()}
+            return {k: self._to_device(v) for k, v in obj.items()}
         if isinstance(obj, (list, tuple)):
-            return [self._prepare_inputs(v) for v in obj]
+            return [self._to_device(v) for v in obj]
         return obj
 
     def _setup_grad_overlap(self):

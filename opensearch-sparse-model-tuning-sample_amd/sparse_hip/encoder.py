@@ -35,6 +35,43 @@ Tensor = torch.Tensor
 SUPPORTED_S = (32, 64, 128, 256)
 
 
+class PackedDocs:
+    """Un-padded (ragged) form of a right-padded [B, S] batch, built on the HOST before the H2D copy
+    (so no device sync is needed to learn the document lengths): documents are packed back to back,
+    each rounded up to a multiple of 16 rows; padding rows beyond that are simply not computed."""
+
+    def __init__(self, ids: Tensor, mask: Tensor, rag: "ops.Ragged"):
+        self.ids, self.mask, self.rag = ids, mask, rag
+
+
+def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_id: int = 0) -> Optional[PackedDocs]:
+    """Host-side packing; returns None when the batch cannot be packed (mask is not a prefix mask,
+    a document is empty or longer than the largest supported bucket)."""
+    import numpy as np
+
+    ids = input_ids.cpu().numpy()
+    mask = attention_mask.cpu().numpy() != 0
+    B, S = ids.shape
+    lens = mask.sum(1)
+    if lens.min() < 1 or not (mask == (np.arange(S)[None, :] < lens[:, None])).all():
+        return None
+    L16 = (lens + 15) // 16 * 16
+    if L16.max() > SUPPORTED_S[-1]:
+        return None
+    doc_off = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(L16, out=doc_off[1:])
+    rows = int(doc_off[-1])
+    row_doc = np.repeat(np.arange(B), L16)
+    pos = np.arange(rows) - np.repeat(doc_off[:-1], L16)
+    valid = pos < lens[row_doc]
+    pids = np.where(valid, ids[row_doc, np.minimum(pos, S - 1)], pad_token_id).astype(np.int64)
+    smax = next(s for s in SUPPORTED_S if s >= int(L16.max()))
+    dev = torch.device(device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev, non_blocking=True)
+    rag = ops.Ragged(t(doc_off, torch.int32), t(row_doc[::16], torch.int32), t(pos, torch.int32), rows, B, smax)
+    return PackedDocs(t(pids, torch.int64), t(valid, torch.uint8), rag)
+
+
 @dataclass
 class BertConfigLite:
     """The BertConfig fields the path reads (config.json of the checkpoint)."""
@@ -303,7 +340,7 @@ class HipBertMLM(torch.nn.Module):
             return None
         return L.dropout(p, seed, layer * 4 + kind)
 
-    def _forward_impl(self, ids: Tensor, mask: Tensor, B: int, S: int, training: bool, seed: int, save: bool):
+    def _forward_impl(self, ids: Tensor, mask: Tensor, B: int, S: int, training: bool, seed: int, save: bool, rag=None):
         cfg = self.config
         A, eps = cfg.num_attention_heads, cfg.layer_norm_eps
         ph, pa = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
@@ -314,7 +351,7 @@ class HipBertMLM(torch.nn.Module):
         d_emb = self._drop(ph, training, seed, 0, _Site.EMB)
         z0, x, m0, r0 = ops.embed_fwd(ids, st["E"], v(e + "position_embeddings.weight"),
                                       v(e + "token_type_embeddings.weight")[0], v(e + "LayerNorm.weight"),
-                                      v(e + "LayerNorm.bias"), eps, d_emb)
+                                      v(e + "LayerNorm.bias"), eps, d_emb, rag)
         if save:
             saved["emb"] = (z0, m0, r0)
         for l in range(cfg.num_hidden_layers):
@@ -323,7 +360,7 @@ class HipBertMLM(torch.nn.Module):
             d_h1 = self._drop(ph, training, seed, l + 1, _Site.HID1)
             d_h2 = self._drop(ph, training, seed, l + 1, _Site.HID2)
             qkv = ops.gemm_nt(x, st[f"qkv{l}"], bias=self.qkv_bias(l))
-            ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at)
+            ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at, rag)
             z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x)
             x1, m1, r1 = ops.layernorm_fwd(z1, v(p + "attention.output.LayerNorm.weight"),
                                            v(p + "attention.output.LayerNorm.bias"), eps)
@@ -345,14 +382,19 @@ class HipBertMLM(torch.nn.Module):
         return x.view(B, S, -1)[:, :S0].float()
 
     def encode(self, input_ids: Tensor, attention_mask: Tensor, use_l0: bool = False,
-               prune_ratio: Optional[float] = None) -> Tensor:
-        """rep[B,V] = log1p(relu(max_l mask*logits)) (scripts/model/sparse_encoders.py:107-119)."""
-        ids, mask, B, S = self._prep_inputs(input_ids, attention_mask)
+               prune_ratio: Optional[float] = None, packed: Optional[PackedDocs] = None) -> Tensor:
+        """rep[B,V] = log1p(relu(max_l mask*logits)) (scripts/model/sparse_encoders.py:107-119).
+        ``packed`` (from pack_documents) selects the ragged layout: padding tokens are not computed."""
+        if packed is not None:
+            ids, mask, B, S = packed.ids, packed.mask, packed.rag.n_docs, packed.rag.max_len
+        else:
+            ids, mask, B, S = self._prep_inputs(input_ids, attention_mask)
+        rag = packed.rag if packed is not None else None
         need_grad = torch.is_grad_enabled()
         training = self.training and need_grad
         self._invocation += 1
         seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._invocation) & 0xFFFFFFFFFFFFFFFF
-        return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad)
+        return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad, rag)
 
     def _reattach_grads(self) -> None:
         """An external optimiser may have set .grad to None; restore the flat-buffer views."""
@@ -372,16 +414,16 @@ class HipBertMLM(torch.nn.Module):
 
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad):
+    def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad, rag):
         cfg = model.config
-        x, saved = model._forward_impl(ids, mask, B, S, training, seed, need_grad)
+        x, saved = model._forward_impl(ids, mask, B, S, training, seed, need_grad, rag)
         v, st = model.view, model._staged
         c = "cls.predictions."
         ft = torch.empty_like(x) if need_grad else None
         gt = ops.gemm_nt(x, st["t"], bias=v(c + "transform.dense.bias"), act=1, preact=ft)
         tn, mt, rt = ops.layernorm_fwd(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
                                        cfg.layer_norm_eps)
-        rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0)
+        rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
         if prune_ratio is not None:
             ops.prune_rows(rep, prune_ratio)
         if model._argmax_log is not None:  # test hook: which position each (doc, vocab) max came from
@@ -389,14 +431,14 @@ class _EncodeFn(torch.autograd.Function):
         if need_grad:
             ctx.model, ctx.saved = model, saved
             ctx.head = (x, ft, gt, mt, rt, tn, rep, argmax)
-            ctx.meta = (ids, mask, B, S, use_l0, training, seed)
+            ctx.meta = (ids, mask, B, S, use_l0, training, seed, rag)
         return rep
 
     @staticmethod
     def backward(ctx, grad_rep):
         model: HipBertMLM = ctx.model
         cfg = model.config
-        ids, mask, B, S, use_l0, training, seed = ctx.meta
+        ids, mask, B, S, use_l0, training, seed, rag = ctx.meta
         x_last, ft, gt, mt, rt, tn, rep, argmax = ctx.head
         A = cfg.num_attention_heads
         ph, pa = cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
@@ -407,7 +449,7 @@ class _EncodeFn(torch.autograd.Function):
         e = "bert.embeddings."
         grad_rep = grad_rep.contiguous().float()
         dtn = ops.sparse_head_bwd(grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"),
-                                  B, S, cfg.vocab_size, use_l0)
+                                  B, S, cfg.vocab_size, use_l0, rag)
         dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
                                    g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
         dft = ops.gelu_bwd(dgt, ft)
@@ -435,7 +477,7 @@ class _EncodeFn(torch.autograd.Function):
             a1 = dz1d if d_h1 is not None else dz1
             ops.gemm_tn_acc(a1, ctxt, g(p + "attention.output.dense.weight"), colsum=g(p + "attention.output.dense.bias"))
             dctx = ops.gemm_nt(a1, st[f"oT{l}"])
-            dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at)
+            dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at, rag)
             ops.gemm_tn_acc(dqkv, x, model.qkv_weight(l, grad=True), colsum=model.qkv_bias(l, grad=True))
             dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
             if model._layer_hook is not None:
@@ -447,10 +489,10 @@ class _EncodeFn(torch.autograd.Function):
         dz0, _ = ops.layernorm_bwd(dx, z0, v(e + "LayerNorm.weight"), m0, r0, g(e + "LayerNorm.weight"),
                                    g(e + "LayerNorm.bias"))
         ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),
-                      g(e + "token_type_embeddings.weight")[0])
+                      g(e + "token_type_embeddings.weight")[0], rag)
         ctx.saved = ctx.head = None
         model._reattach_grads()
-        return (None,) * 11
+        return (None,) * 12
 
 
 HipBertMLM._layer_hook = None

@@ -33,7 +33,12 @@ class SmEpilogue(C.Structure):
     ]
 
 
+class SmRagged(C.Structure):
+    _fields_ = [("doc_off", C.c_void_p), ("blk_doc", C.c_void_p), ("pos_ids", C.c_void_p), ("rows", C.c_int)]
+
+
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+_rag = C.POINTER(SmRagged)
 
 # name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
 SIGNATURES = {
@@ -41,15 +46,15 @@ SIGNATURES = {
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
-    "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _p],
-    "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
+    "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _rag, _p],
     "sm_dropout_bwd": [_i, _p, _p, _l, C.POINTER(SmDropout), _p],
     "sm_gelu_bwd": [_i, _p, _p, _p, _l, _p],
-    "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
-    "sm_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _p],
-    "sm_sparse_head_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _rag, _p],
+    "sm_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _rag, _p],
+    "sm_sparse_head_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p],
     "sm_prune_rows": [_p, _i, _i, _f, _p],
-    "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],
     "sm_flops_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p],

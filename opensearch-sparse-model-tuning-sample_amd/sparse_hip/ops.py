@@ -23,6 +23,19 @@ def _drop_ref(drop):
     return C.byref(drop) if drop is not None else None
 
 
+class Ragged:
+    """Packed (un-padded) document layout: device index arrays + the C descriptor (sm_ragged)."""
+
+    def __init__(self, doc_off: Tensor, blk_doc: Tensor, pos_ids: Tensor, rows: int, n_docs: int, max_len: int):
+        self.doc_off, self.blk_doc, self.pos_ids = doc_off, blk_doc, pos_ids
+        self.rows, self.n_docs, self.max_len = int(rows), int(n_docs), int(max_len)
+        self.c = L.SmRagged(L.ptr(doc_off), L.ptr(blk_doc), L.ptr(pos_ids), self.rows)
+
+
+def _rag_ref(rag):
+    return C.byref(rag.c) if rag is not None else None
+
+
 # ---------------------------------------------------------------- GEMMs
 def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
@@ -72,8 +85,11 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 
 def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tensor, beta: Tensor, eps: float,
-              drop: Optional[L.SmDropout] = None):
-    B, S = ids.shape
+              drop: Optional[L.SmDropout] = None, rag: Optional[Ragged] = None):
+    if rag is None:
+        B, S = ids.shape
+    else:
+        B, S = rag.rows, 1
     H = word.shape[1]
     z = _new((B * S, H), word.dtype, word)
     y = torch.empty_like(z)
@@ -81,15 +97,18 @@ def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tens
     rstd = _new((B * S,), torch.float32, word)
     L.call("sm_embed_fwd", L.dtype_code(word.dtype), L.ptr(ids), L.ptr(word), L.ptr(pos), L.ptr(type0), L.ptr(gamma),
            L.ptr(beta), L.ptr(z), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, S, H, float(eps), _drop_ref(drop),
-           L.stream_ptr())
+           _rag_ref(rag), L.stream_ptr())
     return z, y, mean, rstd
 
 
-def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tensor):
-    B, S = ids.shape
+def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tensor, rag: Optional[Ragged] = None):
+    if rag is None:
+        B, S = ids.shape
+    else:
+        B, S = rag.rows, 1
     H = dz.shape[1]
     L.call("sm_embed_bwd", L.dtype_code(dz.dtype), L.ptr(dz), L.ptr(ids), L.ptr(gword), L.ptr(gpos), L.ptr(gtype0),
-           B, S, H, L.stream_ptr())
+           B, S, H, _rag_ref(rag), L.stream_ptr())
 
 
 def dropout_bwd(dy: Tensor, drop: L.SmDropout) -> Tensor:
@@ -105,31 +124,34 @@ def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------- attention
-def attention_fwd(qkv: Tensor, keymask: Tensor, B: int, S: int, A: int, drop: Optional[L.SmDropout] = None):
+def attention_fwd(qkv: Tensor, keymask: Tensor, B: int, S: int, A: int, drop: Optional[L.SmDropout] = None,
+                  rag: Optional[Ragged] = None):
     H = qkv.shape[1] // 3
-    ctx = _new((B * S, H), qkv.dtype, qkv)
+    ctx = _new((qkv.shape[0], H), qkv.dtype, qkv)
     lse = _new((B, A, S), torch.float32, qkv)
     L.call("sm_attention_fwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(keymask), L.ptr(ctx), L.ptr(lse), B, S, A,
-           H // A, _drop_ref(drop), L.stream_ptr())
+           H // A, _drop_ref(drop), _rag_ref(rag), L.stream_ptr())
     return ctx, lse
 
 
 def attention_bwd(qkv: Tensor, keymask: Tensor, ctx: Tensor, dctx: Tensor, lse: Tensor, B: int, S: int, A: int,
-                  drop: Optional[L.SmDropout] = None) -> Tensor:
+                  drop: Optional[L.SmDropout] = None, rag: Optional[Ragged] = None) -> Tensor:
     H = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     L.call("sm_attention_bwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(keymask), L.ptr(ctx), L.ptr(dctx),
-           L.ptr(lse), L.ptr(dqkv), B, S, A, H // A, _drop_ref(drop), L.stream_ptr())
+           L.ptr(lse), L.ptr(dqkv), B, S, A, H // A, _drop_ref(drop), _rag_ref(rag), L.stream_ptr())
     return dqkv
 
 
 # ---------------------------------------------------------------- fused sparse head
-def sparse_head_fwd(t: Tensor, E: Tensor, bias: Tensor, mask: Tensor, B: int, S: int, V: int, use_l0: bool):
+def sparse_head_fwd(t: Tensor, E: Tensor, bias: Tensor, mask: Tensor, B: int, S: int, V: int, use_l0: bool,
+                    rag: Optional[Ragged] = None):
     H = t.shape[1]
     rep = _new((B, V), torch.float32, t)
     argmax = _new((B, V), torch.int16, t)  # u16 payload
+    scratch = _new((B, V), torch.int64, t) if rag is not None else None
     L.call("sm_sparse_head_fwd", L.dtype_code(t.dtype), L.ptr(t), L.ptr(E), L.ptr(bias), L.ptr(mask), L.ptr(rep),
-           L.ptr(argmax), B, S, H, V, int(use_l0), L.stream_ptr())
+           L.ptr(argmax), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(scratch), L.stream_ptr())
     return rep, argmax
 
 
@@ -139,11 +161,11 @@ def prune_rows(rep: Tensor, ratio: float) -> Tensor:
 
 
 def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E: Tensor, dE: Tensor, dbias: Tensor,
-                    B: int, S: int, V: int, use_l0: bool) -> Tensor:
+                    B: int, S: int, V: int, use_l0: bool, rag: Optional[Ragged] = None) -> Tensor:
     H = t.shape[1]
     dt = torch.empty_like(t)
     L.call("sm_sparse_head_bwd", L.dtype_code(t.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(t), L.ptr(E),
-           L.ptr(dt), L.ptr(dE), L.ptr(dbias), B, S, H, V, int(use_l0), L.stream_ptr())
+           L.ptr(dt), L.ptr(dE), L.ptr(dbias), B, S, H, V, int(use_l0), _rag_ref(rag), L.stream_ptr())
     return dt
 
 

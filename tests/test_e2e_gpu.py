@@ -210,7 +210,7 @@ def _mid_case(dtype, inf_free, ibn, loss_types, use_l0=False, thr=None, S=64):
     idf = torch.exp(torch.rand(1000, generator=g) * 6 - 3)
     model = SparseModel(bb, idf=idf, use_l0=use_l0)
     nq, k = 3, 4
-    ds = SyntheticTriplesDataset(nq, k, S, 16, 1000, seed=11, with_scores=True)
+    ds = SyntheticTriplesDataset(nq, k, S, 16, 1000, seed=11, with_scores=True, len_mean=S * 0.55, len_std=S * 0.3)
     batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
     margs = ModelArguments(model_name_or_path="x", inf_free=inf_free, use_l0=use_l0)
     dargs = DataTrainingArguments(loss_types=loss_types, use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
