@@ -83,6 +83,7 @@ class KernelTimer:
         self.module, self.name = module, name
         self.orig = getattr(module, name)
         self.events = []
+        self.rows = []
         self.enabled = False
 
     def __enter__(self):
@@ -94,6 +95,7 @@ class KernelTimer:
             out = self.orig(*a, **kw)
             e1.record()
             self.events.append((e0, e1))
+            self.rows.append(int(a[0].shape[0]))  # token rows the launch actually processed
             return out
         setattr(self.module, self.name, wrapped)
         return self
@@ -179,9 +181,10 @@ def main():
     elapsed = float(tmax.item())
 
     k = args.negs + 1
-    T = args.bs * k * args.seq
+    T_padded = args.bs * k * args.seq
+    T = sum(kt.rows) / max(1, len(kt.rows))  # rows per launch: the ragged layout skips padding tokens
     H, V = cfg.hidden_size, cfg.vocab_size
-    head_flops = 2.0 * T * H * V  # algorithmic FLOPs of one fused decoder launch (2THV)
+    head_flops = 2.0 * T * H * V  # executed FLOPs of one fused decoder launch (2THV, T = computed rows)
     achieved = head_flops / (head_ms * 1e-3)
     peak = MFMA_PEAK[args.dtype]
     result = {
@@ -194,12 +197,14 @@ def main():
         "dtype": args.dtype, "data": "synthetic MS-MARCO-shaped triples, random-init weights",
         "config": {"workload": "configs[1]: config_infonce.yaml recipe, v2-mini-shaped encoder (6L/384H/12A/1536I/V30522), "
                                f"bs={args.bs} x (1 pos + {args.negs} negs), seq {args.seq}, inference-free queries, "
-                               "InfoNCE in-batch negatives + FLOPS, dropout " + ("off" if args.no_dropout else "0.1") + ", fused AdamW",
+                               "InfoNCE in-batch negatives + FLOPS, dropout " + ("off" if args.no_dropout else "0.1") + ", fused AdamW; "
+                               f"documents padded to {args.seq} by the collator, padding tokens skipped on the device "
+                               f"({T:.0f} of {T_padded} token rows computed per step)",
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
                    "parallelism": f"dp{world}"},
         "roofline": {"kernel": "sparse_head_fwd_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
                      "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel_ms": head_ms},
+                     "traffic": None, "kernel_ms": head_ms, "rows_per_launch": T},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

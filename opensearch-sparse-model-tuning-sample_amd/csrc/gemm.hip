@@ -528,7 +528,7 @@ __global__ void head_unpack_kernel(const unsigned long long* __restrict__ packed
 // reduction of the generic kernel.
 // ---------------------------------------------------------------------------------------
 constexpr int AR_K = 384, AR_NST = 16, AR_SLICES = AR_K / 32;
-constexpr int AR_LDS = AR_NST * GL_STAGE + 8 * 128 * 4;
+constexpr int AR_LDS = AR_NST * GL_STAGE + 8 * 4 * 128 * 4;  // ring + reduction scratch (ragged: 8 blocks x 4 lane groups)
 
 // s_waitcnt vmcnt(2 * n) for a run-time n in [0, AR_NST - 3] (the count must be an immediate)
 __device__ __forceinline__ void wait_younger(int n) {
@@ -541,15 +541,17 @@ __device__ __forceinline__ void wait_younger(int n) {
   }
 }
 
-template <int DBG>
+template <int DBG, bool RAG>
 __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf16* __restrict__ Tn, const bf16* __restrict__ E,
                                                                         const float* __restrict__ bias, const uint8_t* __restrict__ mask,
                                                                         float* __restrict__ rep, uint16_t* __restrict__ argmax,
-                                                                        int Bdocs, int S, int V, int use_l0) {
+                                                                        int Bdocs, int S, int V, int use_l0,
+                                                                        const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
+                                                                        int rag_rows, unsigned long long* __restrict__ packed) {
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   char* const ring = dsmem;
   float* const redv = reinterpret_cast<float*>(ring + AR_NST * GL_STAGE);
-  const int Ttot = Bdocs * S;
+  const int Ttot = RAG ? rag_rows : Bdocs * S;
   const int m0 = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
@@ -613,43 +615,90 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
   // Epilogue pipelining: the in-lane (max, argmax) reduction of a tile (64 accumulators -> 4
   // candidates per lane) runs right after its last MFMA; the LDS exchange and the finalisation
   // (bias, log1p, stores) of tile vt-1 ride inside tile vt's K-loop, behind its slice barriers.
-  // (max, argmax) travel as ONE float: the row-in-tile index (7 bits) replaces the low mantissa
-  // bits of the candidate, so a plain v_max3_f32 chain carries the arg-max along (the value keeps
-  // 17 mantissa bits, a 2^-17 relative perturbation, far inside the bf16 error of the inputs).
+  // (max, argmax) travel as ONE float: the row index (7 bits in the dense layout: row in tile; 8 bits in
+  // the ragged layout: position in the document) replaces the low mantissa bits of the candidate, so
+  // a plain v_max_f32 chain carries the arg-max along (the value keeps >= 16 mantissa bits, far
+  // inside the bf16 error of the inputs).
+  constexpr uint32_t IDX_MASK = RAG ? 0xFFu : 0x7Fu;
+  constexpr int NC = RAG ? 4 : 1;  // candidates per lane and column block: per 16-row block / per 64 rows
   f32x4 acc[4][4];
-  float cand[4];
+  float cand[4][NC];
   float mneg[4][4];  // 0 for attended rows, -3e38 for padded rows of this lane
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mneg[i][r] = ((mrow[i] >> (8 * r)) & 0xFFu) ? 0.f : -3.0e38f;  // finite: -inf | index bits would be a NaN
-  const int rbase = wm * 64 + g * 4;
+  // index of this lane's row r of block i: row in tile (dense) or position in its document (ragged)
+  int ibase[4];
+  const int nblk_tot = Ttot / 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rt = wm * 64 + i * 16 + g * 4;
+    if (RAG) {
+      const int blk = min(m0 / 16 + wm * 4 + i, nblk_tot - 1);
+      ibase[i] = m0 + rt - doc_off[blk_doc[blk]];
+    } else {
+      ibase[i] = rt;
+    }
+  }
 
   auto finalize = [&](int vt) {
     if (threadIdx.x < 128) {
       const int col = vt * 128 + threadIdx.x;
-      float c[8];
+      if constexpr (RAG) {
+        // per 16-row block: max over the 4 lane groups, then merge consecutive blocks of one document
+        // and fold into the 64-bit (relu(max + bias) bits, 0xFFFF - position) scratch with atomicMax
+        int cur = -1;
+        unsigned long long best = 0ull;
+        const int blk0 = m0 / 16;
+        for (int blk = 0; blk < 8 && blk0 + blk < nblk_tot; ++blk) {
+          const float* rb = redv + blk * 512 + threadIdx.x;
+          const float c = fmaxf(fmaxf(rb[0], rb[128]), fmaxf(rb[256], rb[384]));
+          const int d = blk_doc[blk0 + blk];
+          if (d != cur) {
+            if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+            cur = d;
+            best = 0ull;
+          }
+          if (c > -1.0e37f && col < V) {
+            const uint32_t bits = __float_as_uint(c);
+            const float y = fmaxf(__uint_as_float(bits & ~IDX_MASK) + bias[col], 0.f);
+            const unsigned long long w64 = ((unsigned long long)__float_as_uint(y) << 32) | (0xFFFFu - (bits & IDX_MASK));
+            if (y > 0.f && w64 > best) best = w64;
+          }
+        }
+        if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+      } else {
+        float c[8];
 #pragma unroll
-      for (int grp = 0; grp < 8; ++grp) c[grp] = redv[grp * 128 + threadIdx.x];
-      const float lo = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), hi = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
-      const int ndoc = 128 / S;  // S is 64 or 128 here: a document is one or both 64-row wave blocks
-      for (int dd = 0; dd < ndoc; ++dd) {
-        const int b = m0 / S + dd;
-        const float best = ndoc == 2 ? (dd ? hi : lo) : fmaxf(lo, hi);
-        if (b < Bdocs && col < V) {
-          const uint32_t bits = __float_as_uint(best);
-          float y = best < -1.0e37f ? 0.f : fmaxf(__uint_as_float(bits & 0xFFFFFF80u) + bias[col], 0.f);
-          y = log1pf(y);
-          if (use_l0) y = log1pf(y);
-          rep[(size_t)b * V + col] = y;
-          argmax[(size_t)b * V + col] = (uint16_t)((int)(bits & 0x7Fu) - dd * S);
+        for (int grp = 0; grp < 8; ++grp) c[grp] = redv[grp * 128 + threadIdx.x];
+        const float lo = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), hi = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+        const int ndoc = 128 / S;  // S is 64 or 128 here: a document is one or both 64-row wave blocks
+        for (int dd = 0; dd < ndoc; ++dd) {
+          const int b = m0 / S + dd;
+          const float best = ndoc == 2 ? (dd ? hi : lo) : fmaxf(lo, hi);
+          if (b < Bdocs && col < V) {
+            const uint32_t bits = __float_as_uint(best);
+            float y = best < -1.0e37f ? 0.f : fmaxf(__uint_as_float(bits & ~IDX_MASK) + bias[col], 0.f);
+            y = log1pf(y);
+            if (use_l0) y = log1pf(y);
+            rep[(size_t)b * V + col] = y;
+            argmax[(size_t)b * V + col] = (uint16_t)((int)(bits & IDX_MASK) - dd * S);
+          }
         }
       }
     }
   };
-  auto publish = [&]() {  // candidates of the previous tile -> LDS (4 lane groups x 2 wave rows)
+  auto publish = [&]() {  // candidates of the previous tile -> LDS
 #pragma unroll
-    for (int j = 0; j < 4; ++j) redv[(wm * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j];
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (RAG) {  // [block = wm*4 + i][lane group g][128 cols]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) redv[((wm * 4 + i) * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j][i];
+      } else {              // [wm*4 + g][128 cols]
+        redv[(wm * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j][0];
+      }
+    }
   };
 
   for (int vt = 0; vt < nvt; ++vt) {
@@ -675,18 +724,22 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
     }
-    // in-lane reduction: 16 rows per lane and column block, index packed into the low mantissa bits
+    // in-lane reduction, index packed into the low mantissa bits: over the lane's 16 rows (dense) or
+    // per 16-row block (ragged: blocks of one tile may belong to different documents)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float best = -3.0e38f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (RAG) best = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = acc[i][j][r] + mneg[i][r];
-          best = fmaxf(best, __uint_as_float((__float_as_uint(v) & 0xFFFFFF80u) | (uint32_t)(rbase + i * 16 + r)));
+          best = fmaxf(best, __uint_as_float((__float_as_uint(v) & ~IDX_MASK) | (uint32_t)(ibase[i] + r)));
         }
-      cand[j] = best;
+        if (RAG) cand[j][i] = best;
+      }
+      if (!RAG) cand[j][0] = best;
     }
   }
   if (!(DBG & 1)) {  // epilogue of the last tile
@@ -695,8 +748,8 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     finalize(nvt - 1);
-  } else if (cand[0] + cand[1] + cand[2] + cand[3] == 12345.678f) {
-    rep[threadIdx.x] = cand[0];
+  } else if (cand[0][0] + cand[1][0] + cand[2][0] + cand[3][0] == 12345.678f) {
+    rep[threadIdx.x] = cand[0][0];
   }
 }
 
@@ -1164,7 +1217,12 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     const int mtiles = sm_cdiv(rag->rows, 128);
     dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
     unsigned long long* pk = reinterpret_cast<unsigned long long*>(scratch);
-    if (dtype == SM_BF16)
+    if (ares_on && dtype == SM_BF16 && H == AR_K && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
+      auto kern = sparse_head_fwd_ares_kernel<0, true>;
+      SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));
+      hipLaunchKernelGGL(kern, dim3(mtiles), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, V,
+                         use_l0, rag->doc_off, rag->blk_doc, rag->rows, pk);
+    } else if (dtype == SM_BF16)
       hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax,
                          B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
     else
@@ -1183,10 +1241,11 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
 #define SM_ARES_LAUNCH(D)                                                                                                   \
     {                                                                                                                       \
-      auto kern = sparse_head_fwd_ares_kernel<D>;                                                                           \
+      auto kern = sparse_head_fwd_ares_kernel<D, false>;                                                                    \
       SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));             \
       hipLaunchKernelGGL(kern, dim3(sm_cdiv(T, 128)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias,     \
-                         mask, rep, argmax, B, S, V, use_l0);                                                               \
+                         mask, rep, argmax, B, S, V, use_l0, (const int32_t*)nullptr, (const int32_t*)nullptr, 0,          \
+                         (unsigned long long*)nullptr);                                                                     \
     }
     switch (dbg) {
       case 1: SM_ARES_LAUNCH(1) break;

@@ -386,3 +386,78 @@ def test_sparse_query_scores_match_dense(ops, pairs):
     close(dq, dq_ref * (qv != 0), 1e-4, "dq (restricted to q's support)")
     over = ops.row_compact(dev(qv), 8)
     assert int(over[3].item()) > 0, "rows with more than cap non-zeros must be flagged"
+
+
+def _ragged(lens):
+    """host-side packing metadata exactly as sparse_hip.encoder.pack_documents builds it"""
+    lens = np.asarray(lens)
+    L16 = (lens + 15) // 16 * 16
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(L16, out=off[1:])
+    rows = int(off[-1])
+    row_doc = np.repeat(np.arange(len(lens)), L16)
+    pos = np.arange(rows) - np.repeat(off[:-1], L16)
+    return lens, off, rows, row_doc, pos, pos < lens[row_doc]
+
+
+@pytest.mark.parametrize("dtype,H", [(torch.float32, 128), (torch.bfloat16, 128), (torch.bfloat16, 384)])
+@pytest.mark.parametrize("use_l0", [False, True])
+def test_sparse_head_ragged_layout(ops, dtype, H, use_l0):
+    """un-padded documents (each a multiple of 16 rows, spanning row tiles arbitrarily): the fused head
+    and its backward must equal the per-document dense computation"""
+    lens, off, rows, row_doc, pos, valid = _ragged([37, 128, 16, 90, 5, 64, 100, 128, 77, 3, 250])
+    B, V = len(lens), 700
+    rag = ops.Ragged(dev(off.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, 256)
+    t = q(rnd(rows, H, seed=1), dtype)
+    E = q(rnd(V, H, seed=2, scale=0.3 if H < 384 else 0.15), dtype)
+    bias = rnd(V, seed=3, scale=0.5)
+    mask = torch.from_numpy(valid.astype(np.uint8))
+    rep, am = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask), B, 256, V, use_l0, rag)
+    tr, Er, br = t.clone().requires_grad_(True), E.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    refs, tops = [], []
+    for b in range(B):
+        lg = tr[off[b]:off[b] + lens[b]] @ Er.t() + br
+        refs.append(O.sparse_activation(lg[None], torch.ones(1, int(lens[b]), dtype=torch.long), use_l0)[0])
+        tops.append(lg.detach())
+    ref = torch.stack(refs)
+    tol = TOL[dtype] * 2
+    close(rep, ref, tol, "rep")
+    posn = am.cpu().long() & 0xFFFF
+    for b in range(B):
+        live = ref[b] > 0
+        assert (posn[b][live] < int(lens[b])).all()
+        picked = tops[b].gather(0, posn[b].clamp(max=int(lens[b]) - 1)[None])[0]
+        assert (picked[live] >= tops[b].max(0).values[live] - (1e-4 if dtype == torch.float32 else 6e-2)).all()
+    up = rnd(B, V, seed=4)
+    (ref * up).sum().backward()
+    dE, dbias = torch.zeros(V, H, device="cuda"), torch.zeros(V, device="cuda")
+    dt = ops.sparse_head_bwd(dev(up), rep, am, dev(t, dtype), dev(E, dtype), dE, dbias, B, 256, V, use_l0, rag)
+    want_dt = tr.grad.clone()
+    want_dt[~torch.from_numpy(valid)] = 0
+    close(dt, want_dt, tol * 2, "dt")
+    close(dE, Er.grad, tol * 2, "dE")
+    close(dbias, br.grad, tol * 2, "dbias")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_ragged_layout(ops, dtype):
+    lens, off, rows, row_doc, pos, valid = _ragged([37, 128, 16, 90, 5, 64])
+    B, A, dh, S = len(lens), 2, 32, 128
+    H = A * dh
+    rag = ops.Ragged(dev(off.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, S)
+    qkv = q(rnd(rows, 3 * H, seed=1), dtype)
+    dctx = q(rnd(rows, H, seed=2), dtype)
+    mask = torch.from_numpy(valid.astype(np.uint8))
+    ctx, lse = ops.attention_fwd(dev(qkv, dtype), dev(mask), B, S, A, None, rag)
+    xr = qkv.clone().requires_grad_(True)
+    want = torch.zeros(rows, H)
+    for b in range(B):
+        n = int(lens[b])
+        cr, _ = ref_attention(xr[off[b]:off[b] + n], torch.ones(1, n), 1, n, A, dh)
+        want[off[b]:off[b] + n] = cr
+    tol = TOL[dtype] * 2
+    vm = torch.from_numpy(valid)
+    close(ctx.float().cpu()[vm], want.detach()[vm], tol, "ctx")
+    (want * dctx).sum().backward()
+    dqkv = ops.attention_bwd(dev(qkv, dtype), dev(mask), ctx, dev(dctx * vm[:, None], dtype), lse, B, S, A, None, rag)
+    close(dqkv.float().cpu()[vm], xr.grad[vm], tol * 2, "dqkv")
