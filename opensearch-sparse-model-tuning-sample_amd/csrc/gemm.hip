@@ -555,7 +555,13 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
   const int m0 = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
-  const int nvt = (V + 127) / 128, nslice = nvt * AR_SLICES;
+  // blockIdx.y selects a contiguous range of vocab tiles: more, shorter workgroups so that a tile count
+  // that is not a multiple of the CU count does not leave most of the chip idle in the last round
+  const int nvt_all = (V + 127) / 128;
+  const int per = (nvt_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int vt0 = blockIdx.y * per, vt1 = min(nvt_all, vt0 + per);
+  if (vt0 >= vt1) return;
+  const int nvt = vt1 - vt0, nslice = nvt * AR_SLICES;
 
   // per-lane source offsets of this wave's two 1-KiB pieces of a stage (elements, within a vocab
   // tile): row = piece*16 + lane/4, swizzled 16-byte chunk; the stream position (vocab tile, k
@@ -566,11 +572,11 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
     erow[p] = (w * 2 + p) * 16 + (lane >> 2);
     eoff[p] = erow[p] * AR_K + (((lane & 3) ^ ((0 - (erow[p] >> 2)) & 3)) << 3);
   }
-  int ivt = 0, iks = 0, istage = 0;
+  int ivt = vt0, iks = 0, istage = 0;
   auto issue_next = [&]() {
     const bf16* src = E + (size_t)ivt * 128 * AR_K + iks * 32;
     char* st = ring + istage * GL_STAGE + w * 2048;
-    if (ivt == nvt - 1) {  // last vocab tile: rows past V are clamped (their columns are never stored)
+    if (ivt == nvt_all - 1) {  // last vocab tile: rows past V are clamped (their columns are never stored)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int r = min(ivt * 128 + erow[p], V - 1) - ivt * 128;
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
       if (!(DBG & 2) && gs + AR_NST - 1 < nslice) issue_next();
       if (gs + 1 < nslice) load_b(gs + 1, fb[(ks + 1) & 1]);
       if (!(DBG & 1) && vt > 0 && ks == 0) publish();
-      if (!(DBG & 1) && vt > 0 && ks == 1) finalize(vt - 1);
+      if (!(DBG & 1) && vt > 0 && ks == 1) finalize(vt0 + vt - 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    finalize(nvt - 1);
+    finalize(vt0 + nvt - 1);
   } else if (cand[0][0] + cand[1][0] + cand[2][0] + cand[3][0] == 12345.678f) {
     rep[threadIdx.x] = cand[0][0];
   }
@@ -1200,6 +1206,10 @@ extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, 
   return SM_OK;
 }
 
+// vocab-range split of the persistent head kernel: 1 when the row tiles already fill whole rounds of the
+// 256 CUs, otherwise 8 ranges (~30 vocab tiles each) so the last round is short
+static int ares_vsplit(int mtiles) { return (mtiles % 256 == 0) ? 1 : 8; }
+
 extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
                                   float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, const sm_ragged* rag,
                                   uint64_t* scratch, void* stream) {
@@ -1220,7 +1230,7 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     if (ares_on && dtype == SM_BF16 && H == AR_K && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
       auto kern = sparse_head_fwd_ares_kernel<0, true>;
       SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));
-      hipLaunchKernelGGL(kern, dim3(mtiles), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, V,
+      hipLaunchKernelGGL(kern, dim3(mtiles, ares_vsplit(mtiles)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, V,
                          use_l0, rag->doc_off, rag->blk_doc, rag->rows, pk);
     } else if (dtype == SM_BF16)
       hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax,
@@ -1243,7 +1253,7 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     {                                                                                                                       \
       auto kern = sparse_head_fwd_ares_kernel<D, false>;                                                                    \
       SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));             \
-      hipLaunchKernelGGL(kern, dim3(sm_cdiv(T, 128)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias,     \
+      hipLaunchKernelGGL(kern, dim3(sm_cdiv(T, 128), ares_vsplit(sm_cdiv(T, 128))), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias,     \
                          mask, rep, argmax, B, S, V, use_l0, (const int32_t*)nullptr, (const int32_t*)nullptr, 0,          \
                          (unsigned long long*)nullptr);                                                                     \
     }
