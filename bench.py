@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--negs", type=int, default=15)
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     ap.add_argument("--no-dropout", action="store_true")
     return ap.parse_args()
 
@@ -107,14 +109,46 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask and cgroup CPU quota, capped at 32 (the
+    oracle's matrices are too small to scale further; oversubscribing a quota is catastrophic)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(args):
+    """Run the CPU leg in a child process with a hard wall-clock bound so the GPU bench line is never
+    held hostage by a slow host (the child never touches the GPU)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--negs", str(args.negs), "--seq", str(args.seq),
+           "--bs", str(args.bs)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout, env=env)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "CPU leg failed: " + (out.stderr.strip().splitlines() or ["no output"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port",
+                "sample": f"CPU oracle did not finish 2 queries x {args.negs + 1} docs in {args.cpu_baseline_timeout:.0f} s"}
+
+
+def cpu_baseline_child(args):
     """CPU oracle (the 'port') on a bounded sample of the same workload: the same model
     shape, sequence length and 16 docs per query, but 2 queries per step so one step is
-    ~10-30 s of host work.  Forward + backward + AdamW, fp32, dropout on, all host threads."""
+    ~5-30 s of host work.  Forward + backward + AdamW, fp32, dropout on."""
     from oracle import sparse_oracle as O  # baseline leg only
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     oc = O.BertShape()
     params = {k: v.requires_grad_(True) for k, v in O.init_params(oc, seed=0).items()}
     g = torch.Generator().manual_seed(7)
@@ -146,6 +180,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_child(args)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
