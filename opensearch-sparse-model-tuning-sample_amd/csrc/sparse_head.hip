@@ -2,6 +2,8 @@
 // backward of the fused MLM head, ratio prune, inference-free query encoder, FLOPS / L0
 // regulariser, dense score matrices, ranking losses, teacher ensemble normalisation.
 // Every reduction is a 64-lane wave reduction; every global access is coalesced along V.
+#include <stdlib.h>
+
 #include "common.h"
 
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
@@ -463,14 +465,27 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
-    if (rc != SM_OK) return rc;
+  // Fork / join: the two halves of the head backward are independent -- dt = G.E is MFMA-bound, the
+  // dE / dbias gather is L2/MALL-bandwidth-bound -- so the gather runs on a side stream next to the
+  // GEMM.  Events only (no host synchronisation); the side stream and events live for the process.
+  static thread_local hipStream_t side = nullptr;
+  static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static const int overlap = getenv("SM_HEAD_OVERLAP") ? atoi(getenv("SM_HEAD_OVERLAP")) : 1;
+  hipStream_t st_de = st;
+  if (overlap) {
+    if (side == nullptr) {
+      SM_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      SM_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      SM_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    SM_HIP_CHECK(hipEventRecord(ev_fork, st));
+    SM_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+    st_de = side;
   }
   const int nc = H / 64;
   dim3 grid(sm_cdiv(V, 16));
 #define LAUNCH_DE(T, NC) \
-  hipLaunchKernelGGL((head_de_kernel<T, NC>), grid, dim3(256), 0, st, grad_rep, rep, argmax, (const T*)t, dE, dbias, B, S, H, V, use_l0, rag ? rag->doc_off : nullptr)
+  hipLaunchKernelGGL((head_de_kernel<T, NC>), grid, dim3(256), 0, st_de, grad_rep, rep, argmax, (const T*)t, dE, dbias, B, S, H, V, use_l0, rag ? rag->doc_off : nullptr)
 #define DISPATCH_NC(T)                                                         \
   switch (nc) {                                                                \
     case 1: LAUNCH_DE(T, 1); break;                                            \
@@ -486,6 +501,14 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
 #undef DISPATCH_NC
 #undef LAUNCH_DE
   SM_LAUNCH_CHECK();
+  {
+    const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
+    if (rc != SM_OK) return rc;
+  }
+  if (overlap) {
+    SM_HIP_CHECK(hipEventRecord(ev_join, side));
+    SM_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+  }
   return SM_OK;
 }
 

@@ -412,6 +412,31 @@ class HipBertMLM(torch.nn.Module):
         self._invocation = 0
 
 
+class _WgradStream:
+    """Weight-gradient GEMMs (and their bias-gradient column sums) are off the critical path of the
+    backward chain: they are enqueued on a side HIP stream, ordered after the kernels that produced
+    their inputs (event fork) and joined back before anything reads the flat gradient buffer."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.enabled = os.environ.get("SM_WGRAD_STREAM", "1") != "0"
+
+    def run(self, a: Tensor, b: Tensor, out: Tensor, colsum: Optional[Tensor]):
+        if not self.enabled:
+            ops.gemm_tn_acc(a, b, out, colsum=colsum)
+            return
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            ops.gemm_tn_acc(a, b, out, colsum=colsum)
+        a.record_stream(self.stream)  # the caching allocator must not recycle the operands early
+        b.record_stream(self.stream)
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad, rag):
@@ -447,15 +472,19 @@ class _EncodeFn(torch.autograd.Function):
         g = lambda n: model.view(n, grad=True)
         c = "cls.predictions."
         e = "bert.embeddings."
+        if model._wgrad is None:
+            model._wgrad = _WgradStream(model.device)
+        wg = model._wgrad
         grad_rep = grad_rep.contiguous().float()
         dtn = ops.sparse_head_bwd(grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"),
                                   B, S, cfg.vocab_size, use_l0, rag)
         dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
                                    g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
         dft = ops.gelu_bwd(dgt, ft)
-        ops.gemm_tn_acc(dft, x_last, g(c + "transform.dense.weight"), colsum=g(c + "transform.dense.bias"))
+        wg.run(dft, x_last, g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
         dx = ops.gemm_nt(dft, st["tT"])
         if model._layer_hook is not None:
+            wg.join()
             model._layer_hook("head")
         for l in reversed(range(cfg.num_hidden_layers)):
             p = f"bert.encoder.layer.{l}."
@@ -467,20 +496,21 @@ class _EncodeFn(torch.autograd.Function):
                                           g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"),
                                           d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
-            ops.gemm_tn_acc(a2, ga, g(p + "output.dense.weight"), colsum=g(p + "output.dense.bias"))
+            wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
             df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
-            ops.gemm_tn_acc(df1, x1, g(p + "intermediate.dense.weight"), colsum=g(p + "intermediate.dense.bias"))
+            wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
             dx1 = ops.gemm_nt(df1, st[f"w1T{l}"], residual=dz2)
             dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                           g(p + "attention.output.LayerNorm.weight"),
                                           g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
             a1 = dz1d if d_h1 is not None else dz1
-            ops.gemm_tn_acc(a1, ctxt, g(p + "attention.output.dense.weight"), colsum=g(p + "attention.output.dense.bias"))
+            wg.run(a1, ctxt, g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias"))
             dctx = ops.gemm_nt(a1, st[f"oT{l}"])
             dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at, rag)
-            ops.gemm_tn_acc(dqkv, x, model.qkv_weight(l, grad=True), colsum=model.qkv_bias(l, grad=True))
+            wg.run(dqkv, x, model.qkv_weight(l, grad=True), model.qkv_bias(l, grad=True))
             dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
             if model._layer_hook is not None:
+                wg.join()
                 model._layer_hook(l)
         z0, m0, r0 = ctx.saved["emb"]
         d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
@@ -490,10 +520,12 @@ class _EncodeFn(torch.autograd.Function):
                                    g(e + "LayerNorm.bias"))
         ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),
                       g(e + "token_type_embeddings.weight")[0], rag)
+        wg.join()
         ctx.saved = ctx.head = None
         model._reattach_grads()
         return (None,) * 12
 
 
 HipBertMLM._layer_hook = None
+HipBertMLM._wgrad = None
 HipBertMLM._argmax_log = None
