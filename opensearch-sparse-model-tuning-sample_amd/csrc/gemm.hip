@@ -648,33 +648,59 @@ __global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf
     }
   }
 
+  // ragged: documents of this thread's 4 blocks (half = threadIdx.x >> 7 picks wave row 0 / 1), fixed
+  // for the life of the workgroup, and the bias of the next tile's column (prefetched a tile ahead)
+  int bdoc[4];
+  float bias_next = 0.f;
+  if constexpr (RAG) {
+    const int half = threadIdx.x >> 7;
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const int blk = m0 / 16 + half * 4 + k2;
+      bdoc[k2] = blk < nblk_tot ? blk_doc[blk] : -1;
+    }
+    const int c0 = vt0 * 128 + (threadIdx.x & 127);
+    bias_next = c0 < V ? bias[c0] : 0.f;
+  }
   auto finalize = [&](int vt) {
+    if constexpr (RAG) {
+      // all 256 threads: thread = (column, wave row); per 16-row block max over the 4 lane groups, merge
+      // consecutive blocks of one document, fold into the 64-bit (relu(max + bias) bits, 0xFFFF - position)
+      // scratch with atomicMax (documents spanning wave rows / row tiles combine there)
+      const int tcol = threadIdx.x & 127, half = threadIdx.x >> 7;
+      const int col = vt * 128 + tcol;
+      const float bcol = bias_next;
+      const int cn = (vt + 1) * 128 + tcol;
+      bias_next = (vt + 1 < vt1 && cn < V) ? bias[cn] : 0.f;
+      float c[4];
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const float* rb = redv + (half * 4 + k2) * 512 + tcol;
+        c[k2] = fmaxf(fmaxf(rb[0], rb[128]), fmaxf(rb[256], rb[384]));
+      }
+      int cur = -1;
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const int d = bdoc[k2];
+        if (d != cur) {
+          if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+          cur = d;
+          best = 0ull;
+        }
+        if (d >= 0 && c[k2] > -1.0e37f) {
+          const uint32_t bits = __float_as_uint(c[k2]);
+          const float y = fmaxf(__uint_as_float(bits & ~IDX_MASK) + bcol, 0.f);
+          const unsigned long long w64 = ((unsigned long long)__float_as_uint(y) << 32) | (0xFFFFu - (bits & IDX_MASK));
+          if (y > 0.f && w64 > best) best = w64;
+        }
+      }
+      if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
+      return;
+    }
     if (threadIdx.x < 128) {
       const int col = vt * 128 + threadIdx.x;
-      if constexpr (RAG) {
-        // per 16-row block: max over the 4 lane groups, then merge consecutive blocks of one document
-        // and fold into the 64-bit (relu(max + bias) bits, 0xFFFF - position) scratch with atomicMax
-        int cur = -1;
-        unsigned long long best = 0ull;
-        const int blk0 = m0 / 16;
-        for (int blk = 0; blk < 8 && blk0 + blk < nblk_tot; ++blk) {
-          const float* rb = redv + blk * 512 + threadIdx.x;
-          const float c = fmaxf(fmaxf(rb[0], rb[128]), fmaxf(rb[256], rb[384]));
-          const int d = blk_doc[blk0 + blk];
-          if (d != cur) {
-            if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
-            cur = d;
-            best = 0ull;
-          }
-          if (c > -1.0e37f && col < V) {
-            const uint32_t bits = __float_as_uint(c);
-            const float y = fmaxf(__uint_as_float(bits & ~IDX_MASK) + bias[col], 0.f);
-            const unsigned long long w64 = ((unsigned long long)__float_as_uint(y) << 32) | (0xFFFFu - (bits & IDX_MASK));
-            if (y > 0.f && w64 > best) best = w64;
-          }
-        }
-        if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
-      } else {
+      {
         float c[8];
 #pragma unroll
         for (int grp = 0; grp < 8; ++grp) c[grp] = redv[grp * 128 + threadIdx.x];
@@ -1228,7 +1254,8 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
     unsigned long long* pk = reinterpret_cast<unsigned long long*>(scratch);
     if (ares_on && dtype == SM_BF16 && H == AR_K && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
-      auto kern = sparse_head_fwd_ares_kernel<0, true>;
+      static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
+      auto kern = dbg == 1 ? sparse_head_fwd_ares_kernel<1, true> : sparse_head_fwd_ares_kernel<0, true>;
       SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));
       hipLaunchKernelGGL(kern, dim3(mtiles, ares_vsplit(mtiles)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, V,
                          use_l0, rag->doc_off, rag->blk_doc, rag->rows, pk);
