@@ -303,3 +303,88 @@ def test_product_path_refuses_cpu_tensors():
     from sparse_hip.lib import SparseHipError
     with pytest.raises(SparseHipError):
         F.flops_value(torch.ones(4, 8), 2)
+
+
+def test_kd_ensemble_teachers_match_oracle():
+    """a13/a14: frozen sparse (MLM max-pool, special tokens zeroed) + dense ([CLS], L2-normalised) teachers ->
+    per-row min-max, mean over teachers, x score_scale (bi_encoder_wrapper.py:117-146) -> KLDiv student loss"""
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    kw = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+              max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    oc = O.BertShape(1000, 128, 2, 4, 256, 128)
+    params = [O.init_params(oc, seed=s, std=0.08) for s in (3, 4, 5)]  # student, dense teacher, sparse teacher
+    bbs = []
+    for p in params:
+        bb = HipBertMLM(BertConfigLite(**kw), compute_dtype=torch.float32, device="cuda", init_seed=None)
+        bb.load_hf_state_dict(p)
+        bbs.append(bb)
+    g = torch.Generator().manual_seed(5)
+    idf = torch.exp(torch.rand(1000, generator=g) * 6 - 3)
+    model = SparseModel(bbs[0], idf=idf, use_l0=False)
+    nq, k = 3, 4
+    ds = SyntheticTriplesDataset(nq, k, 64, 16, 1000, seed=11, len_mean=40, len_std=15)
+    batch = PreTokenizedCollator(n_teachers=2)([ds[i] for i in range(nq)])
+    margs = ModelArguments(model_name_or_path="x", inf_free=True)
+    dargs = DataTrainingArguments(loss_types=["kldiv"], use_in_batch_negatives=False, flops_d_lambda=0.05, flops_d_T=10,
+                                  kd_ensemble_teacher_kwargs={"types": ["dense", "sparse"], "model_ids": [bbs[1], bbs[2]], "score_scale": 30})
+    targs = TrainingArguments(output_dir="/tmp/sm_test_out", logging_steps=1000)
+    trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
+                                 loss_functions=[LOSS_CLS_MAP["kldiv"](use_in_batch_negatives=False, weight=1, temperature=1.0)])
+    trainer.set_bi_encoder_teacher()
+    trainer.state.global_step = 4
+    inp = trainer._prepare_inputs(batch)
+    loss, out = trainer.compute_loss(trainer.model, inp, return_outputs=True)
+    q, d = batch["query"][0], batch["docs"][0]
+    # oracle teachers
+    _, hid_q, _ = O.bert_mlm_logits(params[1], q["input_ids"], q["attention_mask"], oc, return_hidden=True)
+    _, hid_d, _ = O.bert_mlm_logits(params[1], d["input_ids"], d["attention_mask"], oc, return_hidden=True)
+    dq = torch.nn.functional.normalize(hid_q[:, 0], p=2, dim=1)
+    dd = torch.nn.functional.normalize(hid_d[:, 0], p=2, dim=1)
+    sq = O.encode_teacher_sparse(params[2], q["input_ids"], q["attention_mask"], oc, SPECIAL)
+    sd = O.encode_teacher_sparse(params[2], d["input_ids"], d["attention_mask"], oc, SPECIAL)
+    teacher = O.ensemble_scores([O.teacher_score(dq, dd, False), O.teacher_score(sq, sd, False)], 30)
+    close_out(inp["scores"], teacher, 1e-3, "ensemble teacher scores")
+    lc = O.LossConfig(loss_types=("kldiv",), use_in_batch_negatives=False, flops_d_lambda=0.05, flops_d_T=10)
+    oloss = O.compute_loss(params[0], oc, idf, SPECIAL, q["input_ids"], q["attention_mask"], d["input_ids"], d["attention_mask"],
+                           teacher, lc, 4)[0]
+    close_out(loss, oloss, 1e-3, "kd-ensemble loss")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bert_base_shaped_layer_matches_oracle(dtype):
+    """config-4/5 model family: H=768, 12 heads (head dim 64), I=3072 (one layer to keep the oracle fast)"""
+    from scripts.model.sparse_encoders import SparseModel
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM, pack_documents
+    from scripts.dataset.synthetic import SyntheticTriplesDataset
+    cfg = BertConfigLite(vocab_size=2000, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                         max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    oc = O.BertShape(2000, 768, 1, 12, 3072, 128)
+    p = O.init_params(oc, seed=7, std=0.04)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None)
+    bb.load_hf_state_dict(p)
+    m = SparseModel(bb, use_l0=False)
+    m.train()
+    ds = SyntheticTriplesDataset(6, 1, 128, 16, 2000, seed=3, len_mean=70, len_std=30)
+    ids = torch.from_numpy(ds.d_ids[:, 0])
+    mask = (ids != 0).long()
+    up = rnd_like = torch.randn(6, 2000, generator=torch.Generator().manual_seed(1))
+    for packed in (None, pack_documents(ids, mask, "cuda")):
+        bb.zero_grad()
+        bb._argmax_log = []
+        rep = m(inf_free=False, input_ids=ids.cuda(), attention_mask=mask.cuda(), packed=packed)
+        (rep * up.cuda()).sum().backward()
+        route = bb._argmax_log[0].cpu().long() & 0xFFFF
+        bb._argmax_log = None
+        pr = {n: (v.to(dtype).float() if v.dim() == 2 and "position" not in n and "token_type" not in n else v.clone()).requires_grad_(True)
+              for n, v in p.items()}
+        ref = O.encode_docs(pr, ids, mask, oc, route=route)
+        (ref * up).sum().backward()
+        close_out(rep, ref, TOL[dtype], "rep")
+        for n in ("bert.encoder.layer.0.attention.self.value.weight", "bert.encoder.layer.0.intermediate.dense.weight",
+                  "bert.encoder.layer.0.output.LayerNorm.weight", "cls.predictions.transform.dense.weight"):
+            close(bb.view(n, grad=True), pr[n].grad, TOL[dtype] * 3, "grad " + n)
