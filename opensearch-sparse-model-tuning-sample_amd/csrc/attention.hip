@@ -90,14 +90,16 @@ template <int NT> struct SeqProd<bf16, NT> {
   }
 };
 template <int NT> struct SeqProd<float, NT> {
-  __device__ static __forceinline__ f32x4 run(const char* tbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
+  // fp32 parity mode keeps no transposed LDS images (they would not fit for head dim 64): the A operand
+  // element (row = trow of the transposed view, k = sequence index) is read from the row-major image
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float a = *reinterpret_cast<const float*>(tbase + trow * rs + (t * 16 + 4 * g + r) * 4);
+          const float a = *reinterpret_cast<const float*>(rowbase + (t * 16 + 4 * g + r) * rs + trow * 4);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[t][r], acc, 0, 0, 0);
         }
       }
@@ -159,10 +161,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
   char* sK = smem;                          // [S][DH] row-major
   char* sVt = sK + S * L::RS;               // [DH][S] transposed
-  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + DH * L::rst(S));
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + (sizeof(T) == 2 ? DH * L::rst(S) : S * L::RS));
   const T* base = qkv + (size_t)row0 * ld + h * DH;
   stage<T, DH>(base + H, ld, Lr, nkt * 16, sK, L::RS, nullptr, 0);
-  stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, nullptr, 0, sVt, L::rst(S));
+  constexpr bool TR = sizeof(T) == 2;  // bf16 keeps transposed images, fp32 reads the row-major ones
+  if constexpr (TR) stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, nullptr, 0, sVt, L::rst(S));
+  else stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, sVt, L::RS, nullptr, 0);
   for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::rst(S), dt * 16 + li, g, p, nkt);
+      const f32x4 o = SeqProd<T, NKT>::run(sVt, TR ? L::rst(S) : L::RS, dt * 16 + li, g, p, nkt);
       store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
     }
   }
@@ -245,18 +249,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   char* sV = sK + S * L::RS;
   char* sDO = sV + S * L::RS;
   char* sQt = sDO + S * L::RS;
-  char* sKt = sQt + DH * rst;
-  char* sDOt = sKt + DH * rst;
-  float* sLse = reinterpret_cast<float*>(sDOt + DH * rst);
+  char* sKt = sQt + (sizeof(T) == 2 ? DH * rst : 0);
+  char* sDOt = sKt + (sizeof(T) == 2 ? DH * rst : 0);
+  float* sLse = reinterpret_cast<float*>(sDOt + (sizeof(T) == 2 ? DH * rst : 0));
   float* sDelta = sLse + S;
   uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
   const T* base = qkv + (size_t)row0 * ld + h * DH;
   const T* dob = dctx + (size_t)row0 * H + h * DH;
   const T* ob = ctx + (size_t)row0 * H + h * DH;
-  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, sQt, rst);
-  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, sKt, rst);
+  constexpr bool TR = sizeof(T) == 2;  // bf16 keeps transposed images, fp32 reads the row-major ones
+  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, TR ? sQt : nullptr, rst);
+  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, TR ? sKt : nullptr, rst);
   stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sV, L::RS, nullptr, 0);
-  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, sDOt, rst);
+  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, TR ? sDOt : nullptr, rst);
+  const char* tK = TR ? sKt : sK;
+  const char* tQ = TR ? sQt : sQ;
+  const char* tDO = TR ? sDOt : sDO;
+  const int trs = TR ? rst : L::RS;
   for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
     float d = 0.f;
     if (i < Lr)
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sKt, rst, dt * 16 + li, g, ds, nt);
+      const f32x4 o = SeqProd<T, NKT>::run(tK, trs, dt * 16 + li, g, ds, nt);
       store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, o);
     }
   }
@@ -340,8 +349,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 dv = SeqProd<T, NKT>::run(sDOt, rst, dt * 16 + li, g, pd, nt);
-      const f32x4 dk = SeqProd<T, NKT>::run(sQt, rst, dt * 16 + li, g, ds, nt);
+      const f32x4 dv = SeqProd<T, NKT>::run(tDO, trs, dt * 16 + li, g, pd, nt);
+      const f32x4 dk = SeqProd<T, NKT>::run(tQ, trs, dt * 16 + li, g, ds, nt);
       store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv);
       store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk);
     }
@@ -349,9 +358,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 }
 
 template <typename T, int DH>
-size_t fwd_lds(int S) { return (size_t)S * Lay<T, DH>::RS + (size_t)DH * Lay<T, DH>::rst(S) + S; }
+size_t fwd_lds(int S) {
+  const size_t second = sizeof(T) == 2 ? (size_t)DH * Lay<T, DH>::rst(S) : (size_t)S * Lay<T, DH>::RS;
+  return (size_t)S * Lay<T, DH>::RS + second + S;
+}
 template <typename T, int DH>
-size_t bwd_lds(int S) { return 4 * (size_t)S * Lay<T, DH>::RS + 3 * (size_t)DH * Lay<T, DH>::rst(S) + 8 * (size_t)S + S; }
+size_t bwd_lds(int S) {
+  const size_t tr = sizeof(T) == 2 ? 3 * (size_t)DH * Lay<T, DH>::rst(S) : 0;
+  return 4 * (size_t)S * Lay<T, DH>::RS + tr + 8 * (size_t)S + S;
+}
 
 constexpr size_t LDS_MAX = 160 * 1024;
 

@@ -380,7 +380,7 @@ def test_bert_base_shaped_layer_matches_oracle(dtype):
         (rep * up.cuda()).sum().backward()
         route = bb._argmax_log[0].cpu().long() & 0xFFFF
         bb._argmax_log = None
-        pr = {n: (v.to(dtype).float() if v.dim() == 2 and "position" not in n and "token_type" not in n else v.clone()).requires_grad_(True)
+        pr = {n: (v.to(dtype).float().clone() if v.dim() == 2 and "position" not in n and "token_type" not in n else v.clone()).requires_grad_(True)
               for n, v in p.items()}
         ref = O.encode_docs(pr, ids, mask, oc, route=route)
         (ref * up).sum().backward()
