@@ -67,23 +67,32 @@ __device__ __forceinline__ f32x4 dh_product(const char* abase, int rs, int arow,
 // B = accumulator-layout tiles p[0..nt) (rows = sequence index, col = lane & 15).
 template <typename T, int NT> struct SeqProd;
 template <int NT> struct SeqProd<bf16, NT> {
-  __device__ static __forceinline__ f32x4 run(const char* tbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
+  // A operand = X^T (rows = head-dim index trow0 .. trow0+15, k = sequence index) read straight from the
+  // ROW-MAJOR image X[seq][dh] with the transposing LDS read: for the 16-lane group g the block rows are
+  // the 4 sequence rows R0 .. R0+3 and the block columns the 16 head-dim columns trow0 .. trow0+15; lane
+  // (q = li >> 2, p = li & 3) supplies the address of row R0 + q, columns 4p .. 4p+3 and receives column
+  // li of the 4 rows.  Two reads (sequence tiles 2t and 2t+1) fill the 8 k-slots in the same permuted
+  // order in which the accumulator tiles p[2t], p[2t+1] provide the B operand.
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const f32x4 (&p)[NT], int nt) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int q = li >> 2, pp = li & 3;
+    const char* lane_base = rowbase + (4 * g + q) * rs + (trow0 + 4 * pp) * 2;
 #pragma unroll
     for (int t2 = 0; t2 < NT / 2; ++t2) {
       if (2 * t2 < nt) {
-        const char* a = tbase + trow * rs;
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(a + ((2 * t2) * 16 + 4 * g) * 2);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(a + ((2 * t2 + 1) * 16 + 4 * g) * 2);
-        bf16x8 fa, fb;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base + (2 * t2) * 16 * rs));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base + (2 * t2 + 1) * 16 * rs));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } fa;
+        fa.s.a = lo;
+        fa.s.b = hi;
+        bf16x8 fb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          fa[j] = lo[j];
-          fa[4 + j] = hi[j];
           fb[j] = (bf16)p[2 * t2][j];
           fb[4 + j] = (bf16)p[2 * t2 + 1][j];
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb, acc, 0, 0, 0);
       }
     }
     return acc;
@@ -92,8 +101,9 @@ template <int NT> struct SeqProd<bf16, NT> {
 template <int NT> struct SeqProd<float, NT> {
   // fp32 parity mode keeps no transposed LDS images (they would not fit for head dim 64): the A operand
   // element (row = trow of the transposed view, k = sequence index) is read from the row-major image
-  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow, int g, const f32x4 (&p)[NT], int nt) {
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const f32x4 (&p)[NT], int nt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int trow = trow0 + li;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
@@ -160,13 +170,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   const int nqb = Lr / 16;             // query blocks that exist
   const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
   char* sK = smem;                          // [S][DH] row-major
-  char* sVt = sK + S * L::RS;               // [DH][S] transposed
-  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + (sizeof(T) == 2 ? DH * L::rst(S) : S * L::RS));
+  char* sVt = sK + S * L::RS;               // V, [S][DH] row-major (consumed through transposing reads)
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + S * L::RS);
   const T* base = qkv + (size_t)row0 * ld + h * DH;
   stage<T, DH>(base + H, ld, Lr, nkt * 16, sK, L::RS, nullptr, 0);
-  constexpr bool TR = sizeof(T) == 2;  // bf16 keeps transposed images, fp32 reads the row-major ones
-  if constexpr (TR) stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, nullptr, 0, sVt, L::rst(S));
-  else stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, sVt, L::RS, nullptr, 0);
+  stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, sVt, L::RS, nullptr, 0);  // row-major; read transposed
   for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sVt, TR ? L::rst(S) : L::RS, dt * 16 + li, g, p, nkt);
+      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::RS, dt * 16, g, li, p, nkt);
       store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
     }
   }
@@ -243,29 +251,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
   const int nblk = Lr / 16;            // 16-row blocks that exist (outputs are written for these)
   const int nt = (nblk + 1) & ~1;      // tiles of the LDS images, rounded up to a pair (zero-filled)
-  const int rst = L::rst(S);
   char* sQ = smem;
   char* sK = sQ + S * L::RS;
   char* sV = sK + S * L::RS;
   char* sDO = sV + S * L::RS;
-  char* sQt = sDO + S * L::RS;
-  char* sKt = sQt + (sizeof(T) == 2 ? DH * rst : 0);
-  char* sDOt = sKt + (sizeof(T) == 2 ? DH * rst : 0);
-  float* sLse = reinterpret_cast<float*>(sDOt + (sizeof(T) == 2 ? DH * rst : 0));
+  float* sLse = reinterpret_cast<float*>(sDO + S * L::RS);
   float* sDelta = sLse + S;
   uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
   const T* base = qkv + (size_t)row0 * ld + h * DH;
   const T* dob = dctx + (size_t)row0 * H + h * DH;
   const T* ob = ctx + (size_t)row0 * H + h * DH;
-  constexpr bool TR = sizeof(T) == 2;  // bf16 keeps transposed images, fp32 reads the row-major ones
-  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, TR ? sQt : nullptr, rst);
-  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, TR ? sKt : nullptr, rst);
+  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, nullptr, 0);
+  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, nullptr, 0);
   stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sV, L::RS, nullptr, 0);
-  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, TR ? sDOt : nullptr, rst);
-  const char* tK = TR ? sKt : sK;
-  const char* tQ = TR ? sQt : sQ;
-  const char* tDO = TR ? sDOt : sDO;
-  const int trs = TR ? rst : L::RS;
+  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, nullptr, 0);
   for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
     float d = 0.f;
     if (i < Lr)
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(tK, trs, dt * 16 + li, g, ds, nt);
+      const f32x4 o = SeqProd<T, NKT>::run(sK, L::RS, dt * 16, g, li, ds, nt);
       store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, o);
     }
   }
@@ -349,8 +348,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 dv = SeqProd<T, NKT>::run(tDO, trs, dt * 16 + li, g, pd, nt);
-      const f32x4 dk = SeqProd<T, NKT>::run(tQ, trs, dt * 16 + li, g, ds, nt);
+      const f32x4 dv = SeqProd<T, NKT>::run(sDO, L::RS, dt * 16, g, li, pd, nt);
+      const f32x4 dk = SeqProd<T, NKT>::run(sQ, L::RS, dt * 16, g, li, ds, nt);
       store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv);
       store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk);
     }
@@ -358,15 +357,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 }
 
 template <typename T, int DH>
-size_t fwd_lds(int S) {
-  const size_t second = sizeof(T) == 2 ? (size_t)DH * Lay<T, DH>::rst(S) : (size_t)S * Lay<T, DH>::RS;
-  return (size_t)S * Lay<T, DH>::RS + second + S;
-}
+size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, DH>::RS + S; }
 template <typename T, int DH>
-size_t bwd_lds(int S) {
-  const size_t tr = sizeof(T) == 2 ? 3 * (size_t)DH * Lay<T, DH>::rst(S) : 0;
-  return 4 * (size_t)S * Lay<T, DH>::RS + tr + 8 * (size_t)S + S;
-}
+size_t bwd_lds(int S) { return 4 * (size_t)S * Lay<T, DH>::RS + 8 * (size_t)S + S; }
 
 constexpr size_t LDS_MAX = 160 * 1024;
 

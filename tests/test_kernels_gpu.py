@@ -164,7 +164,7 @@ def ref_attention(qkv, mask, B, S, A, dh):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,A,dh", [(3, 32, 2, 32), (2, 64, 3, 32), (2, 128, 2, 64), (2, 128, 12, 32), (1, 256, 2, 32)])
+@pytest.mark.parametrize("B,S,A,dh", [(3, 32, 2, 32), (2, 64, 3, 32), (2, 128, 2, 64), (2, 128, 12, 32), (1, 256, 2, 32), (2, 256, 3, 64)])
 def test_attention_fwd_bwd(ops, dtype, B, S, A, dh):
     if dtype == torch.float32 and S * dh > 128 * 64:
         pytest.skip("fp32 parity mode: the backward's LDS images cap S*dh at 128*64")
