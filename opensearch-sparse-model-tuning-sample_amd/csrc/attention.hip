@@ -63,6 +63,26 @@ __device__ __forceinline__ f32x4 dh_product(const char* abase, int rs, int arow,
   return acc;
 }
 
+// A probability / score-gradient tile in the form the sequence-dim products consume it: bf16 mode
+// rounds to bf16 as soon as the tile is final (2 registers per tile instead of 4 -- what lets the
+// S = 512 backward keep two 32-tile arrays in registers), fp32 parity mode keeps the accumulator.
+template <typename T> struct PT;
+template <> struct PT<bf16> {
+  using type = bf16x4;
+  __device__ static __forceinline__ type pack(f32x4 v) {
+    type o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+    return o;
+  }
+  __device__ static __forceinline__ type zero() { return pack(f32x4{0.f, 0.f, 0.f, 0.f}); }
+};
+template <> struct PT<float> {
+  using type = f32x4;
+  __device__ static __forceinline__ type pack(f32x4 v) { return v; }
+  __device__ static __forceinline__ type zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+
 // acc (16 x 16) = sum over the sequence dim: A = rows of a transposed [DH][S] LDS image,
 // B = accumulator-layout tiles p[0..nt) (rows = sequence index, col = lane & 15).
 template <typename T, int NT> struct SeqProd;
@@ -73,7 +93,7 @@ template <int NT> struct SeqProd<bf16, NT> {
   // (q = li >> 2, p = li & 3) supplies the address of row R0 + q, columns 4p .. 4p+3 and receives column
   // li of the 4 rows.  Two reads (sequence tiles 2t and 2t+1) fill the 8 k-slots in the same permuted
   // order in which the accumulator tiles p[2t], p[2t+1] provide the B operand.
-  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const f32x4 (&p)[NT], int nt) {
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const bf16x4 (&p)[NT], int nt) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int q = li >> 2, pp = li & 3;
@@ -86,13 +106,10 @@ template <int NT> struct SeqProd<bf16, NT> {
         union { struct { s16x4 a, b; } s; bf16x8 v; } fa;
         fa.s.a = lo;
         fa.s.b = hi;
-        bf16x8 fb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          fb[j] = (bf16)p[2 * t2][j];
-          fb[4 + j] = (bf16)p[2 * t2 + 1][j];
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb, acc, 0, 0, 0);
+        union { struct { bf16x4 a, b; } s; bf16x8 v; } fb;
+        fb.s.a = p[2 * t2];
+        fb.s.b = p[2 * t2 + 1];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, acc, 0, 0, 0);
       }
     }
     return acc;
@@ -227,9 +244,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
           p[kt][r] = v;
         }
     if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
+    typename PT<T>::type pp[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) pp[kt] = PT<T>::pack(p[kt]);
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::RS, dt * 16, g, li, p, nkt);
+      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::RS, dt * 16, g, li, pp, nkt);
       store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
     }
   }
@@ -251,24 +271,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
   const int nblk = Lr / 16;            // 16-row blocks that exist (outputs are written for these)
   const int nt = (nblk + 1) & ~1;      // tiles of the LDS images, rounded up to a pair (zero-filled)
-  char* sQ = smem;
-  char* sK = sQ + S * L::RS;
-  char* sV = sK + S * L::RS;
-  char* sDO = sV + S * L::RS;
-  float* sLse = reinterpret_cast<float*>(sDO + S * L::RS);
+  // two [S][DH] images, used twice: K,V while phase A runs, then Q,dO for phase B (the per-block
+  // operand of each phase -- Q,dO rows in A, K,V rows in B -- comes straight from global memory)
+  char* sX = smem;
+  char* sY = sX + S * L::RS;
+  float* sLse = reinterpret_cast<float*>(sY + S * L::RS);
   float* sDelta = sLse + S;
   uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
   const T* base = qkv + (size_t)row0 * ld + h * DH;
   const T* dob = dctx + (size_t)row0 * H + h * DH;
   const T* ob = ctx + (size_t)row0 * H + h * DH;
-  stage<T, DH>(base, ld, Lr, nt * 16, sQ, L::RS, nullptr, 0);
-  stage<T, DH>(base + H, ld, Lr, nt * 16, sK, L::RS, nullptr, 0);
-  stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sV, L::RS, nullptr, 0);
-  stage<T, DH>(dob, H, Lr, nt * 16, sDO, L::RS, nullptr, 0);
+  stage<T, DH>(base + H, ld, Lr, nt * 16, sX, L::RS, nullptr, 0);
+  stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sY, L::RS, nullptr, 0);
   for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
     float d = 0.f;
-    if (i < Lr)
-      for (int c = 0; c < DH; ++c) d += to_f32<T>(dob[(size_t)i * H + c]) * to_f32<T>(ob[(size_t)i * H + c]);
+    if (i < Lr) {
+      constexpr int EPC = 16 / (int)sizeof(T);
+#pragma unroll
+      for (int c = 0; c < DH; c += EPC) {
+        const uint4 a = *reinterpret_cast<const uint4*>(dob + (size_t)i * H + c);
+        const uint4 o = *reinterpret_cast<const uint4*>(ob + (size_t)i * H + c);
+        const T* ea = reinterpret_cast<const T*>(&a);
+        const T* eo = reinterpret_cast<const T*>(&o);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) d += to_f32<T>(ea[j]) * to_f32<T>(eo[j]);
+      }
+    }
     sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
     sLse[i] = i < Lr ? lse[(size_t)(b * A + h) * S + i] : 0.f;
     sDelta[i] = d;
@@ -285,35 +313,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     typename AT<T>::Frag fq[NKS], fdo[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      fq[ks] = row_frag<T>(sQ, L::RS, q, ks, g);
-      fdo[ks] = row_frag<T>(sDO, L::RS, q, ks, g);
+      fq[ks] = grow_frag<T>(base, ld, q, ks, g);
+      fdo[ks] = grow_frag<T>(dob, H, q, ks, g);
     }
     const float lq = sLse[q], dl = sDelta[q];
     const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
-    f32x4 ds[NKT];
+    typename PT<T>::type ds[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nt) {
-        const f32x4 s = dh_product<T, DH>(sK, L::RS, kt * 16 + li, g, fq);
-        const f32x4 dp = dh_product<T, DH>(sV, L::RS, kt * 16 + li, g, fdo);
+        const f32x4 s = dh_product<T, DH>(sX, L::RS, kt * 16 + li, g, fq);
+        const f32x4 dp = dh_product<T, DH>(sY, L::RS, kt * 16 + li, g, fdo);
+        f32x4 dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;
           const float pv = sM[key] ? __expf(s[r] * scale - lq) : 0.f;
           float dpv = dp[r];
           if (drop.thresh16) dpv = drop_keep1(drop, ebase + key) ? dpv * drop.scale : 0.f;
-          ds[kt][r] = pv * (dpv - dl) * scale;
+          dsv[r] = pv * (dpv - dl) * scale;
         }
+        ds[kt] = PT<T>::pack(dsv);
       } else {
-        ds[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[kt] = PT<T>::zero();
       }
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sK, L::RS, dt * 16, g, li, ds, nt);
+      const f32x4 o = SeqProd<T, NKT>::run(sX, L::RS, dt * 16, g, li, ds, nt);
       store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, o);
     }
   }
+  __syncthreads();  // every wave is done with the K,V images
+  stage<T, DH>(base, ld, Lr, nt * 16, sX, L::RS, nullptr, 0);
+  stage<T, DH>(dob, H, Lr, nt * 16, sY, L::RS, nullptr, 0);
+  __syncthreads();
 
   // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
   for (int kb = w; kb < nblk; kb += 4) {
@@ -321,16 +355,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     typename AT<T>::Frag fk[NKS], fv[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      fk[ks] = row_frag<T>(sK, L::RS, key, ks, g);
-      fv[ks] = row_frag<T>(sV, L::RS, key, ks, g);
+      fk[ks] = grow_frag<T>(base + H, ld, key, ks, g);
+      fv[ks] = grow_frag<T>(base + 2 * H, ld, key, ks, g);
     }
     const bool kvalid = sM[key] != 0;
-    f32x4 pd[NKT], ds[NKT];
+    typename PT<T>::type pd[NKT], ds[NKT];
 #pragma unroll
     for (int qt = 0; qt < NKT; ++qt) {
       if (qt < nt) {
-        const f32x4 s = dh_product<T, DH>(sQ, L::RS, qt * 16 + li, g, fk);
-        const f32x4 dp = dh_product<T, DH>(sDO, L::RS, qt * 16 + li, g, fv);
+        const f32x4 s = dh_product<T, DH>(sX, L::RS, qt * 16 + li, g, fk);
+        const f32x4 dp = dh_product<T, DH>(sY, L::RS, qt * 16 + li, g, fv);
+        f32x4 pdv, dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + 4 * g + r;
@@ -338,18 +373,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
           float keepf = 1.f;
           if (drop.thresh16)
             keepf = drop_keep1(drop, ((uint64_t)(b * A + h) * S + q) * (uint64_t)S + key) ? drop.scale : 0.f;
-          pd[qt][r] = pv * keepf;
-          ds[qt][r] = pv * (dp[r] * keepf - sDelta[q]) * scale;
+          pdv[r] = pv * keepf;
+          dsv[r] = pv * (dp[r] * keepf - sDelta[q]) * scale;
         }
+        pd[qt] = PT<T>::pack(pdv);
+        ds[qt] = PT<T>::pack(dsv);
       } else {
-        pd[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ds[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pd[qt] = PT<T>::zero();
+        ds[qt] = PT<T>::zero();
       }
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 dv = SeqProd<T, NKT>::run(sDO, L::RS, dt * 16, g, li, pd, nt);
-      const f32x4 dk = SeqProd<T, NKT>::run(sQ, L::RS, dt * 16, g, li, ds, nt);
+      const f32x4 dv = SeqProd<T, NKT>::run(sY, L::RS, dt * 16, g, li, pd, nt);
+      const f32x4 dk = SeqProd<T, NKT>::run(sX, L::RS, dt * 16, g, li, ds, nt);
       store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv);
       store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk);
     }
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 template <typename T, int DH>
 size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, DH>::RS + S; }
 template <typename T, int DH>
-size_t bwd_lds(int S) { return 4 * (size_t)S * Lay<T, DH>::RS + 8 * (size_t)S + S; }
+size_t bwd_lds(int S) { return 2 * (size_t)S * Lay<T, DH>::RS + 8 * (size_t)S + S; }
 
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -387,22 +424,24 @@ int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* 
 int check_shape(const char* who, int dtype, int B, int S, int A, int dh) {
   SM_REQUIRE(B > 0 && A > 0, "%s: empty batch", who);
   SM_REQUIRE(dh == 32 || dh == 64, "%s: head dim %d unsupported (32 or 64)", who, dh);
-  SM_REQUIRE(S % 32 == 0 && S >= 32 && S <= 256, "%s: S=%d must be a multiple of 32 in [32, 256] (pad the batch)", who, S);
+  SM_REQUIRE(S % 32 == 0 && S >= 32 && S <= 512, "%s: S=%d must be a multiple of 32 in [32, 512] (pad the batch)", who, S);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "%s: bad dtype %d", who, dtype);
   return SM_OK;
 }
 
 }  // namespace
 
+#define ATT_BY_S(FN, TT, DHH, ...) \
+  (S <= 128 ? FN<TT, DHH, 8>(__VA_ARGS__) : S <= 256 ? FN<TT, DHH, 16>(__VA_ARGS__) : FN<TT, DHH, 32>(__VA_ARGS__))
 #define ATT_DISPATCH(FN, ...)                                                                   \
   do {                                                                                          \
     int rc;                                                                                     \
     if (dtype == SM_BF16) {                                                                     \
-      if (dh == 32) rc = S <= 128 ? FN<bf16, 32, 8>(__VA_ARGS__) : FN<bf16, 32, 16>(__VA_ARGS__); \
-      else rc = S <= 128 ? FN<bf16, 64, 8>(__VA_ARGS__) : FN<bf16, 64, 16>(__VA_ARGS__);        \
+      if (dh == 32) rc = ATT_BY_S(FN, bf16, 32, __VA_ARGS__);                                   \
+      else rc = ATT_BY_S(FN, bf16, 64, __VA_ARGS__);                                            \
     } else {                                                                                    \
-      if (dh == 32) rc = S <= 128 ? FN<float, 32, 8>(__VA_ARGS__) : FN<float, 32, 16>(__VA_ARGS__); \
-      else rc = S <= 128 ? FN<float, 64, 8>(__VA_ARGS__) : FN<float, 64, 16>(__VA_ARGS__);      \
+      if (dh == 32) rc = ATT_BY_S(FN, float, 32, __VA_ARGS__);                                  \
+      else rc = ATT_BY_S(FN, float, 64, __VA_ARGS__);                                           \
     }                                                                                           \
     if (rc != SM_OK) return rc;                                                                 \
   } while (0)

@@ -834,18 +834,42 @@ __device__ __forceinline__ void r2s_tn(char* tile, const uint4 regs[4]) {
   for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + (r0 + RSTEP * i) * Tn<T>::RS + c * 16) = regs[i];
 }
 
+// Block -> (output tile, token split) map of the weight-gradient kernels.  Workgroups are handed to the
+// 8 XCDs round-robin in launch order and each XCD has its own L2.  All tiles of one token split read the
+// same rows of A and B, so the work items (split-major, tile-minor) are dealt to the XCDs in 8 contiguous
+// runs: an XCD then works on one split (two at a seam) and fetches those rows from HBM once instead of
+// every XCD fetching every split.  The grid is 8 * ceil(items / 8) blocks; nsplit < 0 keeps launch order.
+struct TnBlock { int kt, nt, z; };
+__device__ __forceinline__ TnBlock tn_block_map(int tiles_k, int tiles_n, int nsplit) {
+  const int tiles = tiles_k * tiles_n;
+  const int L = blockIdx.x;
+  int item = L;
+  if (nsplit > 0) {
+    const int per = (tiles * nsplit + 7) >> 3;
+    const int j = L >> 3;
+    item = j < per ? (L & 7) * per + j : tiles * nsplit;
+  } else {
+    nsplit = -nsplit;
+  }
+  if (item >= tiles * nsplit) return TnBlock{0, 0, -1};
+  const int t = item % tiles;
+  return TnBlock{t % tiles_k, t / tiles_k, item / tiles};
+}
+
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                                            float* __restrict__ C, int ldc, int M, int N, int Kc,
-                                                           int rows_per_split, float* __restrict__ colsum) {
+                                                           int rows_per_split, float* __restrict__ colsum, int nsplit) {
   using MM = Mma<T>;
   constexpr int BKM = Tn<T>::BKM, RS = Tn<T>::RS, NS = BKM / MM::KSTEP;
   constexpr int STAGE = BKM * RS;
   __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];
   char* const sA = smem;
   char* const sB = smem + 2 * STAGE;
-  const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-  const int mbeg = blockIdx.z * rows_per_split;
+  const TnBlock blk = tn_block_map((Kc + 127) / 128, (N + 127) / 128, nsplit);
+  const int n0 = blk.nt * 128, k0 = blk.kt * 128;
+  if (blk.z < 0) return;
+  const int mbeg = blk.z * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   if (mbeg >= mend) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -855,7 +879,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(const T* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = colsum != nullptr && blk.kt == 0;
   float csum = 0.f;
   uint4 ra[4], rb[4];
   const int nst = (mend - mbeg + BKM - 1) / BKM;
@@ -1049,8 +1073,24 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
 // the 8 rows a 32-lane half touches per transposing read land on 8 distinct slots.
 // Requires M % 32 == 0, N % 128 == 0, Kc % 128 == 0 (every stage is a full tile: no zero fill).
 // ---------------------------------------------------------------------------------------
-constexpr int TG_BKM = 32, TG_STAGE = TG_BKM * 256, TG_NST = 4;
+constexpr int TG_BKM = 32, TG_STAGE = TG_BKM * 256;
 __device__ __forceinline__ int tg_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// tail of a ring whose stages are 4 loads each: wait until at most `younger` stages are in flight
+__device__ __forceinline__ void wait_vm_dyn4(int younger) {
+  switch (younger) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<4>(); break;
+    case 2: wait_vm<8>(); break;
+    case 3: wait_vm<12>(); break;
+    case 4: wait_vm<16>(); break;
+    case 5: wait_vm<20>(); break;
+    case 6: wait_vm<24>(); break;
+    case 7: wait_vm<28>(); break;
+    default: wait_vm<32>(); break;
+  }
+}
 
 __device__ __forceinline__ bf16x8 tg_load(const char* st, int colbase, int g, int li) {
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
@@ -1067,14 +1107,43 @@ __device__ __forceinline__ bf16x8 tg_load(const char* st, int colbase, int g, in
   return u.v;
 }
 
+// Transposing LDS read issued as inline assembly.  The compiler's wait-count pass makes every LDS read
+// it knows about wait for ALL outstanding LDS-DMA loads (vmcnt(0)) -- it cannot tell which ring stage a
+// read touches -- which would drain the ring at every stage; reads it cannot see leave the counted
+// vmcnt waits below in charge.  The price: the lgkmcnt waits are ours too (tg_wait).
+__device__ __forceinline__ s16x4 lds_tr16(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+union TgFrag { struct { s16x4 lo, hi; } s; bf16x8 v; };
+// wait until at most N LDS reads are outstanding; the fragments go through the statement so that no
+// MFMA that consumes them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void tg_wait(TgFrag& a, TgFrag& b, TgFrag& c, TgFrag& d, TgFrag& e) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(a.s.lo), "+v"(a.s.hi), "+v"(b.s.lo), "+v"(b.s.hi), "+v"(c.s.lo), "+v"(c.s.hi), "+v"(d.s.lo), "+v"(d.s.hi),
+                 "+v"(e.s.lo), "+v"(e.s.hi)
+               : "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tg_wait1(TgFrag& a) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.s.lo), "+v"(a.s.hi) : "n"(N) : "memory");
+}
+
+template <int TG_NST>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_glds_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                                 float* __restrict__ C, int ldc, int M, int N, int Kc,
-                                                                int rows_per_split, float* __restrict__ colsum) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * TG_NST * TG_STAGE];
+                                                                int rows_per_split, float* __restrict__ colsum, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
   char* const sA = smem;
   char* const sB = smem + TG_NST * TG_STAGE;
-  const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-  const int mbeg = blockIdx.z * rows_per_split;
+  const TnBlock blk = tn_block_map(Kc / 128, N / 128, nsplit);
+  const int n0 = blk.nt * 128, k0 = blk.kt * 128;
+  if (blk.z < 0) return;
+  const int mbeg = blk.z * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   if (mbeg >= mend) return;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1099,41 +1168,73 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_glds_kernel(const bf16* __re
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + boff[p] + (size_t)st * TG_BKM * ldb), (lds_void_t*)(db + p * 1024), 16, 0, 0);
     }
   };
-  f32x4 acc[4][4];
+  // per-lane LDS byte offsets (within a stage) of the two transposing reads of each fragment
+  uint32_t ra[4][2], rb[4][2];
+  {
+    const int q = li >> 2, p = li & 3;
+    const int r0 = 8 * g + q, r1 = r0 + 4;
+    const uint32_t baseA = (uint32_t)(uintptr_t)(lds_char*)sA, baseB = (uint32_t)(uintptr_t)(lds_char*)sB;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const int cba = (wm * 64 + i * 16) * 2 + 8 * p, cbb = (wn * 64 + i * 16) * 2 + 8 * p;
+      ra[i][0] = baseA + r0 * 256 + ((((cba >> 5) ^ tg_f(r0)) << 5) | (cba & 31));
+      ra[i][1] = baseA + r1 * 256 + ((((cba >> 5) ^ tg_f(r1)) << 5) | (cba & 31));
+      rb[i][0] = baseB + r0 * 256 + ((((cbb >> 5) ^ tg_f(r0)) << 5) | (cbb & 31));
+      rb[i][1] = baseB + r1 * 256 + ((((cbb >> 5) ^ tg_f(r1)) << 5) | (cbb & 31));
+    }
+  }
+  f32x4 acc[4][4], cacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = colsum != nullptr && blockIdx.x == 0;
-  float csum = 0.f;
+  }
+  // column sums of A (the bias gradient) ride on the matrix pipe: A^T . ones, one extra MFMA per fragment
+  const bool do_colsum = colsum != nullptr && blk.kt == 0 && wn == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
 #pragma unroll
   for (int s = 0; s < TG_NST - 1; ++s)
     if (s < nst) issue(s);
   for (int st = 0; st < nst; ++st) {
     const int younger = min(TG_NST - 2, nst - 1 - st);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (younger >= TG_NST - 2) wait_vm<4 * (TG_NST - 2)>();
+    else wait_vm_dyn4(younger);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (st + TG_NST - 1 < nst) issue(st + TG_NST - 1);
-    const char* a = sA + (st % TG_NST) * TG_STAGE;
-    const char* b = sB + (st % TG_NST) * TG_STAGE;
-    bf16x8 fa[4], fb[4];
+    const uint32_t so = (uint32_t)((st % TG_NST) * TG_STAGE);
+    TgFrag fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      fa[i] = tg_load(a, wm * 64 + i * 16, g, li);
-      fb[i] = tg_load(b, wn * 64 + i * 16, g, li);
+      fa[i].s.lo = lds_tr16(ra[i][0] + so);
+      fa[i].s.hi = lds_tr16(ra[i][1] + so);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      fb[i].s.lo = lds_tr16(rb[i][0] + so);
+      fb[i].s.hi = lds_tr16(rb[i][1] + so);
+    }
+    tg_wait<6>(fa[0], fa[1], fa[2], fa[3], fb[0]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    if (do_colsum && threadIdx.x < 128) {
-      const int cb = threadIdx.x * 2;
-#pragma unroll 8
-      for (int m = 0; m < TG_BKM; ++m)
-        csum += (float)*reinterpret_cast<const bf16*>(a + m * 256 + ((((cb >> 5) ^ tg_f(m)) << 5) | (cb & 31)));
+    for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[0].v, acc[i][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait1<4>(fb[1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[1].v, acc[i][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait1<2>(fb[2]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[2].v, acc[i][2], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait1<0>(fb[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[3].v, acc[i][3], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, ones, cacc[i], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -1147,7 +1248,185 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_glds_kernel(const bf16* __re
         atomicAdd(&C[(size_t)row * ldc + col], acc[i][j][r]);
       }
     }
-  if (do_colsum && threadIdx.x < 128) atomicAdd(&colsum[n0 + threadIdx.x], csum);
+  if (do_colsum && li == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&colsum[n0 + wm * 64 + i * 16 + g * 4 + r], cacc[i][r]);
+  }
+}
+
+// Producer / consumer variant: 8 waves -- waves 4..7 only issue the LDS-DMA loads (an LDS-DMA instruction
+// holds its wave's issue slot for 60-180 cycles, time the MFMA waves of the kernel above lose per stage),
+// waves 0..3 only read fragments and issue MFMAs, double-buffering the fragments so that the LDS reads of
+// stage st fly under the MFMAs of stage st-1.  One s_barrier per stage hands a landed stage to the
+// consumers and a drained slot back to the loaders.
+template <int N>
+__device__ __forceinline__ void tg_wait_all(TgFrag (&fa)[4], TgFrag (&fb)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(fa[0].s.lo), "+v"(fa[0].s.hi), "+v"(fa[1].s.lo), "+v"(fa[1].s.hi), "+v"(fa[2].s.lo), "+v"(fa[2].s.hi),
+                 "+v"(fa[3].s.lo), "+v"(fa[3].s.hi), "+v"(fb[0].s.lo), "+v"(fb[0].s.hi), "+v"(fb[1].s.lo), "+v"(fb[1].s.hi),
+                 "+v"(fb[2].s.lo), "+v"(fb[2].s.hi), "+v"(fb[3].s.lo), "+v"(fb[3].s.hi)
+               : "n"(N)
+               : "memory");
+}
+
+__device__ uint4 g_tn_zero16;  // zero-initialised: source of LDS-DMA lanes whose token row is past the end
+
+template <int TG_NST>
+__global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int N, int Kc, int rows_per_split,
+                                                         float* __restrict__ colsum, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  char* const sA = smem;
+  char* const sB = smem + TG_NST * TG_STAGE;
+  const TnBlock blk = tn_block_map(Kc / 128, N / 128, nsplit);
+  const int n0 = blk.nt * 128, k0 = blk.kt * 128;
+  if (blk.z < 0) return;
+  const int mbeg = blk.z * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  if (mbeg >= mend) return;
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nst = (mend - mbeg + TG_BKM - 1) / TG_BKM;  // the last stage may be partial: its missing rows read zeros
+  if (w8 >= 4) {
+    // ---------------- loader waves ----------------
+    const int w = w8 - 4;
+    size_t aoff[2], boff[2];
+    int lrow[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (w * 2 + p) * 4 + (lane >> 4);
+      const int cphys = lane & 15;
+      const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
+      lrow[p] = mbeg + row;
+      aoff[p] = (size_t)(mbeg + row) * lda + n0 + clog;
+      boff[p] = (size_t)(mbeg + row) * ldb + k0 + clog;
+    }
+    const bf16* const zsrc = reinterpret_cast<const bf16*>(&g_tn_zero16);
+    auto issue = [&](int st) {
+      char* da = sA + (st % TG_NST) * TG_STAGE + w * 2048;
+      char* db = sB + (st % TG_NST) * TG_STAGE + w * 2048;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const bool in = lrow[p] + st * TG_BKM < mend;
+        const bf16* pa = in ? A + aoff[p] + (size_t)st * TG_BKM * lda : zsrc;
+        const bf16* pb = in ? B + boff[p] + (size_t)st * TG_BKM * ldb : zsrc;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)pa, (lds_void_t*)(da + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)pb, (lds_void_t*)(db + p * 1024), 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < TG_NST - 1; ++s)
+      if (s < nst) issue(s);
+    for (int st = 0; st < nst; ++st) {
+      const int younger = min(TG_NST - 2, nst - 1 - st);
+      if (younger >= TG_NST - 2) wait_vm<4 * (TG_NST - 2)>();
+      else wait_vm_dyn4(younger);
+      __builtin_amdgcn_s_barrier();  // stage st landed for everyone; the slot of stage st-1 is drained
+      asm volatile("" ::: "memory");
+      if (st + TG_NST - 1 < nst) issue(st + TG_NST - 1);
+    }
+    return;
+  }
+  // ---------------- consumer waves ----------------
+  const int w = w8;
+  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
+  uint32_t ra[4][2], rb[4][2];
+  {
+    const int q = li >> 2, p = li & 3;
+    const int r0 = 8 * g + q, r1 = r0 + 4;
+    const uint32_t baseA = (uint32_t)(uintptr_t)(lds_char*)sA, baseB = (uint32_t)(uintptr_t)(lds_char*)sB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cba = (wm * 64 + i * 16) * 2 + 8 * p, cbb = (wn * 64 + i * 16) * 2 + 8 * p;
+      ra[i][0] = baseA + r0 * 256 + ((((cba >> 5) ^ tg_f(r0)) << 5) | (cba & 31));
+      ra[i][1] = baseA + r1 * 256 + ((((cba >> 5) ^ tg_f(r1)) << 5) | (cba & 31));
+      rb[i][0] = baseB + r0 * 256 + ((((cbb >> 5) ^ tg_f(r0)) << 5) | (cbb & 31));
+      rb[i][1] = baseB + r1 * 256 + ((((cbb >> 5) ^ tg_f(r1)) << 5) | (cbb & 31));
+    }
+  }
+  f32x4 acc[4][4], cacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_colsum = colsum != nullptr && blk.kt == 0 && wn == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
+  auto rd = [&](TgFrag (&fa)[4], TgFrag (&fb)[4], int st) {
+    const uint32_t so = (uint32_t)((st % TG_NST) * TG_STAGE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i].s.lo = lds_tr16(ra[i][0] + so);
+      fa[i].s.hi = lds_tr16(ra[i][1] + so);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fb[i].s.lo = lds_tr16(rb[i][0] + so);
+      fb[i].s.hi = lds_tr16(rb[i][1] + so);
+    }
+  };
+  auto mm = [&](TgFrag (&fa)[4], TgFrag (&fb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, ones, cacc[i], 0, 0, 0);
+    }
+  };
+  TgFrag fa0[4], fb0[4], fa1[4], fb1[4];
+  __builtin_amdgcn_s_barrier();
+  rd(fa0, fb0, 0);
+  tg_wait_all<0>(fa0, fb0);
+  int st = 1;
+  for (; st + 1 < nst; st += 2) {
+    __builtin_amdgcn_s_barrier();
+    rd(fa1, fb1, st);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait_all<0>(fa1, fb1);
+    __builtin_amdgcn_s_barrier();
+    rd(fa0, fb0, st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait_all<0>(fa0, fb0);
+  }
+  if (st < nst) {
+    __builtin_amdgcn_s_barrier();
+    rd(fa1, fb1, st);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    tg_wait_all<0>(fa1, fb1);
+    mm(fa1, fb1);
+  } else {
+    mm(fa0, fb0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = k0 + wn * 64 + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n0 + wm * 64 + i * 16 + g * 4 + r;
+        atomicAdd(&C[(size_t)row * ldc + col], acc[i][j][r]);
+      }
+    }
+  if (do_colsum && li == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&colsum[n0 + wm * 64 + i * 16 + g * 4 + r], cacc[i][r]);
+  }
 }
 
 template <typename T>
@@ -1179,23 +1458,47 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
                    float* colsum, hipStream_t st) {
   const int tiles = sm_cdiv(N, 128) * sm_cdiv(Kc, 128);
   constexpr int BKM = Tn<T>::BKM;
-  int nsplit = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU in flight
-  const int max_split = (M + 4 * BKM - 1) / (4 * BKM);         // at least 4 stages per split
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit < 1) nsplit = 1;
-  int rows_per_split = ((M + nsplit - 1) / nsplit + BKM - 1) / BKM * BKM;
-  nsplit = (M + rows_per_split - 1) / rows_per_split;
-  dim3 grid(sm_cdiv(Kc, 128), sm_cdiv(N, 128), nsplit);
-  static const int tn_glds = getenv("SM_TN_GLDS") ? atoi(getenv("SM_TN_GLDS")) : 0;  // experimental: the register-staged kernel is still faster
+  static const int tn_glds = getenv("SM_TN_GLDS") ? atoi(getenv("SM_TN_GLDS")) : 4;  // LDS-DMA ring depth (0 = register-staged kernel)
+  static const int tn_blocks = getenv("SM_TN_BLOCKS") ? atoi(getenv("SM_TN_BLOCKS")) : (tn_glds ? 256 : 1024);
+  static const int tn_pc = getenv("SM_TN_PC") ? atoi(getenv("SM_TN_PC")) : 1;  // producer/consumer waves (0 = every wave loads and computes)
+  static const int tn_xcd = getenv("SM_TN_XCD") ? atoi(getenv("SM_TN_XCD")) : 1;
+  // token splits: about tn_blocks workgroups in total, at least 4 stages each, a multiple of 8 when there
+  // are enough of them so that tn_block_map can give every split its own XCD
+  auto plan = [&](int target, int bkm, int& nsplit, int& rps) {
+    nsplit = target / tiles;  // never more than `target` workgroups: a partial extra round costs a whole one
+    const int max_split = (M + 4 * bkm - 1) / (4 * bkm);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    rps = ((M + nsplit - 1) / nsplit + bkm - 1) / bkm * bkm;
+    nsplit = (M + rps - 1) / rps;
+  };
+  auto nblocks = [&](int nsplit) { return tn_xcd ? (tiles * nsplit + 7) / 8 * 8 : tiles * nsplit; };
+  int nsplit, rows_per_split;
   if constexpr (sizeof(T) == 2) {
-    if (tn_glds && M % TG_BKM == 0 && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
-      hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(NTHREADS), 0, st, (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, Kc,
-                         rows_per_split, colsum);
+    if (tn_glds && (tn_pc || M % TG_BKM == 0) && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
+      plan(tn_blocks, TG_BKM, nsplit, rows_per_split);
+      auto launch = [&](auto kern, int nstg, int nthr = NTHREADS) {
+        const int lds = 2 * nstg * TG_STAGE;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(nblocks(nsplit)), dim3(nthr), lds, st, (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, Kc,
+                           rows_per_split, colsum, tn_xcd ? nsplit : -nsplit);
+      };
+      if (tn_pc) {
+        if (tn_glds >= 8) launch(gemm_tn_pc_kernel<8>, 8, 512);
+        else if (tn_glds >= 6) launch(gemm_tn_pc_kernel<6>, 6, 512);
+        else launch(gemm_tn_pc_kernel<4>, 4, 512);
+        return 0;
+      }
+      if (tn_glds >= 9) launch(gemm_tn_glds_kernel<9>, 9);
+      else if (tn_glds >= 8) launch(gemm_tn_glds_kernel<8>, 8);
+      else if (tn_glds >= 6) launch(gemm_tn_glds_kernel<6>, 6);
+      else launch(gemm_tn_glds_kernel<4>, 4);
       return 0;
     }
   }
-  hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, Kc,
-                     rows_per_split, colsum);
+  plan(tn_blocks, BKM, nsplit, rows_per_split);
+  hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(nblocks(nsplit)), dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, Kc,
+                     rows_per_split, colsum, tn_xcd ? nsplit : -nsplit);
   return 0;
 }
 

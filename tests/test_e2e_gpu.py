@@ -198,8 +198,8 @@ def _mid_case(dtype, inf_free, ibn, loss_types, use_l0=False, thr=None, S=64):
     from sparse_hip.encoder import BertConfigLite, HipBertMLM
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
     cfg = BertConfigLite(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
-                         max_position_embeddings=256, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    oc = O.BertShape(1000, 128, 2, 4, 256, 256)
+                         max_position_embeddings=max(256, S), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    oc = O.BertShape(1000, 128, 2, 4, 256, max(256, S))
     p = O.init_params(oc, seed=3, std=0.08)
     g = torch.Generator().manual_seed(5)
     for k in p:
@@ -266,9 +266,10 @@ def test_mid_size_step_matches_oracle(dtype, inf_free, ibn, loss_types, use_l0, 
         close(bb.view(n, grad=True), want, tol * 3, "grad " + n)
 
 
-def test_seq128_and_256_documents():
-    """longer documents (S=128: one doc per decoder tile, S=256: two tiles per doc), bf16"""
-    for S in (128, 256):
+def test_seq128_to_512_documents():
+    """longer documents (S=128: one doc per decoder tile, S=256 / 512: two / four tiles per doc; 512 is the
+    sequence length of BASELINE.json configs[4]), bf16"""
+    for S in (128, 256, 512):
         loss, out, bb, oloss, oq, od, pr = _mid_case(torch.bfloat16, True, True, ["infonce"], S=S)
         close_out(out["d_rep"], od, 1e-2, f"d_rep S={S}")
         close_out(loss, oloss, 1e-2, f"loss S={S}")
