@@ -135,6 +135,39 @@ template <int NT> struct SeqProd<float, NT> {
   }
 };
 
+// One pair of sequence tiles (2*t2, 2*t2+1) of the same product, accumulated into `acc`: lets the backward
+// walk the sequence two tiles at a time with only those two probability tiles live in registers.
+template <typename T> struct SeqPair;
+template <> struct SeqPair<bf16> {
+  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int trow0, int g, int li, bf16x4 p0, bf16x4 p1, int t2) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const int q = li >> 2, pp = li & 3;
+    const char* lane_base = rowbase + (4 * g + q) * rs + (trow0 + 4 * pp) * 2 + (2 * t2) * 16 * rs;
+    union { struct { s16x4 a, b; } s; bf16x8 v; } fa;
+    fa.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base));
+    fa.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base + 16 * rs));
+    union { struct { bf16x4 a, b; } s; bf16x8 v; } fb;
+    fb.s.a = p0;
+    fb.s.b = p1;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, acc, 0, 0, 0);
+  }
+};
+template <> struct SeqPair<float> {
+  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int trow0, int g, int li, f32x4 p0, f32x4 p1, int t2) {
+    const int trow = trow0 + li;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 p = h ? p1 : p0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = *reinterpret_cast<const float*>(rowbase + ((2 * t2 + h) * 16 + 4 * g + r) * rs + trow * 4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[r], acc, 0, 0, 0);
+      }
+    }
+    return acc;
+  }
+};
+
 // cooperative staging of a [S][DH] slice (row stride `ld` elements in global) into LDS:
 // row-major image (stride rs bytes) and / or transposed image [DH][S] (stride rst bytes)
 template <typename T, int DH>
@@ -256,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------
-template <typename T, int DH, int NKT>
+template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop,
@@ -318,31 +351,34 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
     const float lq = sLse[q], dl = sDelta[q];
     const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
-    typename PT<T>::type ds[NKT];
+    f32x4 dq[DH / 16];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nt) {
+    for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int t2 = 0; t2 < nt / 2; ++t2) {
+      typename PT<T>::type ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * t2 + hh;
         const f32x4 s = dh_product<T, DH>(sX, L::RS, kt * 16 + li, g, fq);
         const f32x4 dp = dh_product<T, DH>(sY, L::RS, kt * 16 + li, g, fdo);
+        const uint32_t m4 = *reinterpret_cast<const uint32_t*>(sM + kt * 16 + 4 * g);
         f32x4 dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;
-          const float pv = sM[key] ? __expf(s[r] * scale - lq) : 0.f;
+          const float pv = ((m4 >> (8 * r)) & 0xFF) ? __expf(s[r] * scale - lq) : 0.f;
           float dpv = dp[r];
           if (drop.thresh16) dpv = drop_keep1(drop, ebase + key) ? dpv * drop.scale : 0.f;
           dsv[r] = pv * (dpv - dl) * scale;
         }
-        ds[kt] = PT<T>::pack(dsv);
-      } else {
-        ds[kt] = PT<T>::zero();
+        ds[hh] = PT<T>::pack(dsv);
       }
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = SeqPair<T>::acc(dq[dt], sX, L::RS, dt * 16, g, li, ds[0], ds[1], t2);
     }
 #pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sX, L::RS, dt * 16, g, li, ds, nt);
-      store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, o);
-    }
+    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, dq[dt]);
   }
   __syncthreads();  // every wave is done with the K,V images
   stage<T, DH>(base, ld, Lr, nt * 16, sX, L::RS, nullptr, 0);
@@ -359,36 +395,46 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       fv[ks] = grow_frag<T>(base + 2 * H, ld, key, ks, g);
     }
     const bool kvalid = sM[key] != 0;
-    typename PT<T>::type pd[NKT], ds[NKT];
+    f32x4 dv[DH / 16], dk[DH / 16];
 #pragma unroll
-    for (int qt = 0; qt < NKT; ++qt) {
-      if (qt < nt) {
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint64_t hbase = (uint64_t)(b * A + h) * S;
+#pragma unroll 2
+    for (int t2 = 0; t2 < nt / 2; ++t2) {
+      typename PT<T>::type pd[2], ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * t2 + hh;
         const f32x4 s = dh_product<T, DH>(sX, L::RS, qt * 16 + li, g, fk);
         const f32x4 dp = dh_product<T, DH>(sY, L::RS, qt * 16 + li, g, fv);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
         f32x4 pdv, dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + 4 * g + r;
-          const float pv = kvalid ? __expf(s[r] * scale - sLse[q]) : 0.f;
+          const float pv = kvalid ? __expf(s[r] * scale - l4[r]) : 0.f;
           float keepf = 1.f;
-          if (drop.thresh16)
-            keepf = drop_keep1(drop, ((uint64_t)(b * A + h) * S + q) * (uint64_t)S + key) ? drop.scale : 0.f;
+          if (drop.thresh16) keepf = drop_keep1(drop, (hbase + q) * (uint64_t)S + key) ? drop.scale : 0.f;
           pdv[r] = pv * keepf;
-          dsv[r] = pv * (dp[r] * keepf - sDelta[q]) * scale;
+          dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
         }
-        pd[qt] = PT<T>::pack(pdv);
-        ds[qt] = PT<T>::pack(dsv);
-      } else {
-        pd[qt] = PT<T>::zero();
-        ds[qt] = PT<T>::zero();
+        pd[hh] = PT<T>::pack(pdv);
+        ds[hh] = PT<T>::pack(dsv);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        dv[dt] = SeqPair<T>::acc(dv[dt], sY, L::RS, dt * 16, g, li, pd[0], pd[1], t2);
+        dk[dt] = SeqPair<T>::acc(dk[dt], sX, L::RS, dt * 16, g, li, ds[0], ds[1], t2);
       }
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 dv = SeqProd<T, NKT>::run(sY, L::RS, dt * 16, g, li, pd, nt);
-      const f32x4 dk = SeqProd<T, NKT>::run(sX, L::RS, dt * 16, g, li, ds, nt);
-      store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv);
-      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk);
+      store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv[dt]);
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt]);
     }
   }
 }
@@ -410,12 +456,12 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
 }
-template <typename T, int DH, int NKT>
+template <typename T, int DH>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
   const size_t lds = bwd_lds<T, DH>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-  auto kern = attn_bwd_kernel<T, DH, NKT>;
+  auto kern = attn_bwd_kernel<T, DH>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
   return SM_OK;
@@ -464,7 +510,12 @@ extern "C" int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keyma
   if (rc != SM_OK) return rc;
   const DropCfg d = make_drop(drop);
   hipStream_t st = (hipStream_t)stream;
-  ATT_DISPATCH(launch_bwd, qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, rag ? rag->doc_off : nullptr, st);
+  const int32_t* doc_off = rag ? rag->doc_off : nullptr;
+  if (dtype == SM_BF16) rc = dh == 32 ? launch_bwd<bf16, 32>(qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
+                                      : launch_bwd<bf16, 64>(qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
+  else rc = dh == 32 ? launch_bwd<float, 32>(qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
+                     : launch_bwd<float, 64>(qkv, keymask, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
+  if (rc != SM_OK) return rc;
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

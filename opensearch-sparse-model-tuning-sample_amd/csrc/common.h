@@ -102,10 +102,10 @@ struct DropCfg {
 };
 
 __device__ __forceinline__ bool drop_keep1(const DropCfg& d, uint64_t elem) {
-  uint32_t h = fmix32((uint32_t)elem ^ d.key);
-  h ^= (uint32_t)(elem >> 32) * 0x7FEB352Du;
-  h = (h ^ (h >> 15)) * 0x846CA68Bu;
-  h ^= h >> 16;
+  // one murmur3 finaliser (full avalanche; v_mul_lo_u32 is quarter rate, so two multiplies, not four); the
+  // high word of the element index is folded in rotated so that it cannot cancel against the low word
+  const uint32_t hi = (uint32_t)(elem >> 32);
+  const uint32_t h = fmix32((uint32_t)elem ^ d.key ^ ((hi << 16) | (hi >> 16)));
   return (h & 0xFFFFu) >= d.thresh16;
 }
 

@@ -32,7 +32,7 @@ from . import ops
 
 Tensor = torch.Tensor
 
-SUPPORTED_S = (32, 64, 128, 256)
+SUPPORTED_S = (32, 64, 128, 256, 384, 512)
 
 
 class PackedDocs:

@@ -56,7 +56,9 @@ def close(got, want, tol, what=""):
 
 # ------------------------------------------------------------------ GEMM NT
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (128, 128, 64), (77, 520, 192), (300, 64, 384)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (128, 128, 64), (77, 520, 192), (300, 64, 384),
+                                   # >= 64 output tiles with N % 128 == 0: bf16 takes the persistent producer/consumer kernel
+                                   (8200, 384, 384), (8197, 256, 128), (4100, 256, 1536)])
 def test_gemm_nt_plain_and_epilogues(ops, dtype, M, N, K):
     A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.5), dtype)
     bias = rnd(N, seed=3)
@@ -91,6 +93,20 @@ def test_gemm_nt_dropout_is_a_scaled_mask_and_reproducible(ops, dtype):
     assert abs(frac - 0.9) < 0.01, frac
     assert (d3 != 0).ne(keep).any()
     close(d1[keep], (full / 0.9)[keep], 2e-2 if dtype == torch.bfloat16 else 1e-3, "kept values are scaled by 1/(1-p)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_dropout_mask_is_the_one_the_backward_kernels_regenerate(ops, dtype):
+    """large (persistent-kernel) and small shapes must drop exactly the elements dropout_bwd drops for the same seed/site"""
+    from sparse_hip import lib
+    for M, N, K in ((8200, 384, 64), (96, 384, 64)):
+        A, B = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2), dtype)
+        drop = lib.dropout(0.1, 123, 7)
+        d1 = ops.gemm_nt(dev(A, dtype), dev(B, dtype), drop=drop).float()
+        mask = ops.dropout_bwd(torch.ones(M, N, dtype=dtype, device="cuda"), drop).float()
+        full = ops.gemm_nt(dev(A, dtype), dev(B, dtype)).float()
+        assert torch.equal(d1 != 0, (mask != 0) & (full != 0))
+        assert abs((mask != 0).float().mean().item() - 0.9) < 0.01
 
 
 # ------------------------------------------------------------------ GEMM TN
