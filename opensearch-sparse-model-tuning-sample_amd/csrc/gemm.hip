@@ -1612,6 +1612,215 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   return SM_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// dt = G . E for bf16 at H % 384 == 0: one 8-wave workgroup per CU owns a [192 rows x 384 cols] tile of dt
+// (waves 2 x 4, 96 x 96 each: 36 accumulator tiles) and walks the whole vocabulary in 32-column steps.
+//  * 229 workgroups for the bench's ~44k token rows = one round on 256 CUs (the 128 x 128 kernel above
+//    needs 1029 workgroups on 512 slots: three rounds, the last one nearly empty) and G is built once per
+//    step instead of once per 128-column block;
+//  * E streams through a 4-stage LDS-DMA ring (three [32 v][128 h] panels per stage in the weight-gradient
+//    kernel's swizzled layout, read back with the transposing LDS read): 24 KB of loads per 4.7 MFLOP;
+//  * the G slice [192][32] is (re)built per step by 384 (document, column) owner threads with the same
+//    set / clear scheme as above, double-buffered;
+//  * every LDS access after the first DMA is inline assembly: the compiler would otherwise drain the whole
+//    ring (vmcnt(0)) in front of each one.  The single counted wait per step (vmcnt(9): the three column
+//    loads of step k+1 are followed by exactly 9 younger loads) also covers the ring stage of step k+1.
+//  * operands are swapped (D = E-frag x G-frag) so a lane ends up with 4 consecutive columns of one row.
+// ---------------------------------------------------------------------------------------
+constexpr int DT_R = 192, DT_C = 384, DT_NST = 4, DT_ESTAGE = 3 * TG_STAGE, DT_G = DT_R * 64, DT_MAXDOC = 12;
+constexpr int DT_CSLOT = 3 * 512 * 4;  // per step: grad_rep, rep, argmax-pair words of the 512 (document, column) slots
+constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT;
+
+__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+
+__global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
+                                                         const uint16_t* __restrict__ argmax, const bf16* __restrict__ E,
+                                                         bf16* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0,
+                                                         const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
+                                                         int rag_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  char* const sE = smem;
+  char* const sG = smem + DT_NST * DT_ESTAGE;
+  char* const sC = sG + 2 * DT_G;
+  const bool ragged = doc_off != nullptr;
+  const int Ttot = ragged ? rag_rows : Bdocs * S;
+  const int m0 = blockIdx.y * DT_R, n0 = blockIdx.x * DT_C;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3, g = lane >> 4, li = lane & 15;
+  const int nk = (V + 31) / 32;
+
+  // documents with rows in this tile (at most 12: documents are 16-row aligned and at least 16 rows long)
+  int b0, ndoc;
+  if (ragged) {
+    const int blk0 = m0 / 16, blk1 = min(blk0 + DT_R / 16 - 1, Ttot / 16 - 1);
+    b0 = blk_doc[blk0];
+    ndoc = blk_doc[blk1] - b0 + 1;
+  } else {
+    b0 = m0 / S;
+    ndoc = min((m0 + DT_R - 1) / S, Bdocs - 1) - b0 + 1;
+  }
+  // owner threads: (document dd, column kk of the step); threads 384.. issue the same loads (clamped) so that
+  // every wave's vmcnt sees the same sequence
+  const int dd = min(tid >> 5, DT_MAXDOC - 1), kk = tid & 31;
+  const bool owner = tid < 32 * DT_MAXDOC && dd < ndoc && b0 + dd < Bdocs;
+  const int dsafe = min(b0 + dd, Bdocs - 1);
+  const int rbase = (ragged ? doc_off[dsafe] : dsafe * S) - m0;  // tile row of the document's position 0
+  const float* gp = grad_rep + (size_t)dsafe * V;
+  const float* rp = rep + (size_t)dsafe * V;
+  const uint16_t* ap = argmax + (size_t)dsafe * V;
+  const uint32_t gbase = (uint32_t)(uintptr_t)(lds_char*)sG, ebase = (uint32_t)(uintptr_t)(lds_char*)sE;
+
+  // zero both G images before any DMA is in flight (plain stores: the compiler may order them as it likes here)
+  for (int i = tid; i < 2 * DT_G / 16; i += 512) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  // ---- E loader: 24 one-KiB pieces per stage, 3 per wave ----
+  const bf16* esrc[3];
+  int erow[3];
+  uint32_t edst[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const int piece = w * 3 + p, panel = piece >> 3, pp = piece & 7;
+    const int row = pp * 4 + (lane >> 4), cphys = lane & 15;
+    const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
+    erow[p] = row;
+    esrc[p] = E + n0 + panel * 128 + clog;
+    edst[p] = panel * TG_STAGE + pp * 1024;
+  }
+  auto issue_e = [&](int k) {
+    const int kc = min(k, nk - 1);
+    char* d = sE + (k % DT_NST) * DT_ESTAGE;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int v = min(kc * 32 + erow[p], V - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(esrc[p] + (size_t)v * H), (lds_void_t*)(d + edst[p]), 16, 0, 0);
+    }
+  };
+  // the (grad_rep, rep, argmax) words of a step travel by LDS-DMA too (4 bytes per lane), two steps ahead:
+  // register loads that live across the loop back-edge make the compiler wait for vmcnt(0) at their use
+  const uint32_t cbase = (uint32_t)(uintptr_t)(lds_char*)sC;
+  auto issue_cols = [&](int k) {
+    const int v = min(k * 32 + kk, V - 1);
+    char* d = sC + (k % DT_NST) * DT_CSLOT + w * 256;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gp + v), (lds_void_t*)(d), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(rp + v), (lds_void_t*)(d + 2048), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ap + (v & ~1)), (lds_void_t*)(d + 4096), 4, 0, 0);
+  };
+  int prev0 = -1, prev1 = -1;
+  auto write_g = [&](int k) {  // landed columns of step k -> G image k & 1
+    const int v = k * 32 + kk;
+    const uint32_t ca0 = cbase + (k % DT_NST) * DT_CSLOT + w * 256 + lane * 4;
+    uint32_t ug = lds_r32(ca0), ur = lds_r32(ca0 + 2048), ua = lds_r32(ca0 + 4096);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ug), "+v"(ur), "+v"(ua) : : "memory");
+    const float cg = __uint_as_float(ug), cr = __uint_as_float(ur);
+    const uint32_t ca = (min(v, V - 1) & 1) ? (ua >> 16) : (ua & 0xFFFFu);
+    int off = -1;
+    uint32_t val = 0;
+    if (owner && v < V) {
+      const float gr = cg * head_fprime(cr, use_l0);
+      const int row = (int)ca + rbase;
+      if (gr != 0.f && row >= 0 && row < DT_R) {
+        off = row * 64 + ((((kk >> 3) ^ ((0 - (row >> 2)) & 3))) << 4) + (kk & 7) * 2;
+        union { bf16 h; uint16_t u; } cv;
+        cv.h = (bf16)gr;
+        val = cv.u;
+      }
+    }
+    const uint32_t base = gbase + (k & 1) * DT_G;
+    int& prev = (k & 1) ? prev1 : prev0;
+    if (prev >= 0) lds_w16(base + prev, 0u);
+    if (off >= 0) lds_w16(base + off, val);
+    prev = off;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- fragment addresses ----
+  uint32_t gaddr[6], eaddr[6][2];
+  {
+    const int q = li >> 2, pq = li & 3;
+    const int r0 = 8 * g + q, r1 = r0 + 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = wm * 96 + i * 16 + li;
+      gaddr[i] = gbase + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
+      const int c = wn * 96 + i * 16, panel = c >> 7, cb = (c & 127) * 2 + 8 * pq;
+      eaddr[i][0] = ebase + panel * TG_STAGE + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
+      eaddr[i][1] = ebase + panel * TG_STAGE + r1 * 256 + ((((cb >> 5) ^ tg_f(r1)) << 5) | (cb & 31));
+    }
+  }
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue (order fixes the vmcnt arithmetic of the loop) ----
+  issue_e(0);
+  issue_e(1);
+  issue_cols(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  write_g(0);
+  issue_cols(1);
+  issue_e(2);
+  for (int k = 0; k < nk; ++k) {
+    __builtin_amdgcn_s_barrier();  // G(k) written by every owner, E stage k landed for every wave (see 3.)
+    asm volatile("" ::: "memory");
+    // 1. next loads: columns of step k+2, E stage k+3 (its slot held stage k-1, drained before the barrier)
+    issue_cols(k + 2);
+    issue_e(k + 3);
+    // 2. this step's fragments and MFMAs
+    const uint32_t so = (uint32_t)((k % DT_NST) * DT_ESTAGE), go = (uint32_t)((k & 1) * DT_G);
+    bf16x8 fa[6];
+    TgFrag fb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa[i] = lds_b128(gaddr[i] + go);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      fb[j].s.lo = lds_tr16(eaddr[j][0] + so);
+      fb[j].s.hi = lds_tr16(eaddr[j][1] + so);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0].v), "+v"(fb[1].v),
+                   "+v"(fb[2].v), "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v)
+                 :
+                 : "memory");
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. the columns of step k+1 have exactly 9 younger loads behind them (E k+2, columns k+2, E k+3): once
+    //    they are here so is everything older -- including E stage k+1, which the next step reads
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    write_g(k + 1);
+  }
+  // ---- epilogue: lane = (row li, columns 4g..4g+3) of each 16 x 16 tile ----
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int row = m0 + wm * 96 + i * 16 + li;
+    if (row < Ttot) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
+        *reinterpret_cast<bf16x4*>(dt + (size_t)row * H + n0 + wn * 96 + j * 16 + 4 * g) = o;
+      }
+    }
+  }
+}
+
 // dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st) {
@@ -1621,6 +1830,14 @@ int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const 
   const int32_t* doc_off = rag ? rag->doc_off : nullptr;
   const int32_t* blk_doc = rag ? rag->blk_doc : nullptr;
   const int rrows = rag ? rag->rows : 0;
+  static const int dt192 = getenv("SM_DT192") ? atoi(getenv("SM_DT192")) : 1;
+  if (dt192 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
+    hipLaunchKernelGGL(head_dt192_kernel, dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
+                       B, S, H, V, use_l0, doc_off, blk_doc, rrows);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   if (rag) S = 128;
   dim3 grid(sm_cdiv(H, 128), sm_cdiv(T, 128));
   if (dtype == SM_BF16)
