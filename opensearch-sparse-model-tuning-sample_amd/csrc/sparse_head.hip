@@ -8,6 +8,8 @@
 
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
+int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t, float* dE,
+                      float* dbias, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
 
 namespace {
 
@@ -482,6 +484,8 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     SM_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
     st_de = side;
   }
+  const int de_rc = sm_head_de_launch(dtype, grad_rep, rep, argmax, t, dE, dbias, B, S, H, V, use_l0, rag, st_de);
+  if (de_rc < 0) return de_rc;
   const int nc = H / 64;
   dim3 grid(sm_cdiv(V, 16));
 #define LAUNCH_DE(T, NC) \
@@ -497,7 +501,9 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     case 16: LAUNCH_DE(T, 16); break;                                          \
     default: SM_REQUIRE(false, "sm_sparse_head_bwd: H=%d unsupported", H);     \
   }
-  if (dtype == SM_BF16) { DISPATCH_NC(bf16) } else { DISPATCH_NC(float) }
+  if (de_rc == 0) {
+    if (dtype == SM_BF16) { DISPATCH_NC(bf16) } else { DISPATCH_NC(float) }
+  }
 #undef DISPATCH_NC
 #undef LAUNCH_DE
   SM_LAUNCH_CHECK();
