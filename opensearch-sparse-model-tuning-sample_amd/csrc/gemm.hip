@@ -1116,6 +1116,24 @@ __device__ __forceinline__ s16x4 lds_tr16(uint32_t addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 lds_r128f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_w128f(uint32_t addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+
 union TgFrag { struct { s16x4 lo, hi; } s; bf16x8 v; };
 // wait until at most N LDS reads are outstanding; the fragments go through the statement so that no
 // MFMA that consumes them can be scheduled above the wait
@@ -1630,18 +1648,6 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
 constexpr int DT_R = 192, DT_C = 384, DT_NST = 4, DT_ESTAGE = 3 * TG_STAGE, DT_G = DT_R * 64, DT_MAXDOC = 12;
 constexpr int DT_CSLOT = 3 * 512 * 4;  // per step: grad_rep, rep, argmax-pair words of the 512 (document, column) slots
 constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT;
-
-__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
-  uint32_t v;
-  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
 __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
                                                          const uint16_t* __restrict__ argmax, const bf16* __restrict__ E,
