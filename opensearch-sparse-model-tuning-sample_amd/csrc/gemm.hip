@@ -2011,15 +2011,18 @@ __global__ __launch_bounds__(512) void head_de128_kernel(const float* __restrict
   if (owner && blockIdx.x == 0 && bsum != 0.f) atomicAdd(dbias + v0 + vv, bsum);
 }
 
+int sm_head_de_eligible(int dtype, const void* t, const float* dE, int B, int S, int H, int V, const sm_ragged* rag) {
+  static const int de128 = getenv("SM_DE128") ? atoi(getenv("SM_DE128")) : 1;
+  const long T = rag ? rag->rows : (long)B * S;
+  return de128 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && B <= 65535 && T % 16 == 0 && T / 16 <= DE_MAXBLK &&
+         ((uintptr_t)t % 16) == 0 && ((uintptr_t)dE % 16) == 0 && (rag || S % 16 == 0);
+}
+
 // dE / dbias on the matrix pipe when the shapes allow it; returns 1 when launched, 0 to let the caller use
 // the gather kernel (sparse_head.hip), < 0 on error
 int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t, float* dE,
                       float* dbias, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st) {
-  static const int de128 = getenv("SM_DE128") ? atoi(getenv("SM_DE128")) : 1;
-  const long T = rag ? rag->rows : (long)B * S;
-  if (!de128 || dtype != SM_BF16 || H % DT_C != 0 || V % 2 != 0 || B > 65535 || T % 16 != 0 || T / 16 > DE_MAXBLK ||
-      ((uintptr_t)t % 16) != 0 || ((uintptr_t)dE % 16) != 0 || (!rag && S % 16 != 0))
-    return 0;
+  if (!sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag)) return 0;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_de128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DE_LDS));
   hipLaunchKernelGGL(head_de128_kernel, dim3(H / DT_C, sm_cdiv(V, DE_VT)), dim3(512), DE_LDS, st, grad_rep, rep, argmax, (const bf16*)t, dE, dbias,
                      B, S, H, V, use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0);

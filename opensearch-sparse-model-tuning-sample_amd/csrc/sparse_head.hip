@@ -8,6 +8,7 @@
 
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
+int sm_head_de_eligible(int dtype, const void* t, const float* dE, int B, int S, int H, int V, const sm_ragged* rag);
 int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t, float* dE,
                       float* dbias, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
 
@@ -467,12 +468,14 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  // Fork / join: the two halves of the head backward are independent -- dt = G.E is MFMA-bound, the
-  // dE / dbias gather is L2/MALL-bandwidth-bound -- so the gather runs on a side stream next to the
-  // GEMM.  Events only (no host synchronisation); the side stream and events live for the process.
+  // Fork / join: the two halves of the head backward are independent.  When dE falls back to the gather kernel
+  // (L2/MALL-bandwidth-bound) it runs on a side stream next to the MFMA-bound dt GEMM; events only (no host
+  // synchronisation), the side stream and events live for the process.  When both halves are the one-workgroup-
+  // per-CU MFMA kernels they cannot share a CU anyway and simply follow each other on the caller's stream.
   static thread_local hipStream_t side = nullptr;
   static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  static const int overlap = getenv("SM_HEAD_OVERLAP") ? atoi(getenv("SM_HEAD_OVERLAP")) : 1;
+  static const int overlap_env = getenv("SM_HEAD_OVERLAP") ? atoi(getenv("SM_HEAD_OVERLAP")) : 1;
+  const bool overlap = overlap_env && !sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag);
   hipStream_t st_de = st;
   if (overlap) {
     if (side == nullptr) {
