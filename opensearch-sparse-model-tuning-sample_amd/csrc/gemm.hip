@@ -949,7 +949,6 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
   constexpr int BK = MM::BK, NS = BK / MM::KSTEP;
   constexpr int ESTAGE = BK * Tn<T>::RS;
   constexpr int TPC = NTHREADS / BK;   // threads sharing one vocab column of the G tile
-  constexpr int RPT = 128 / TPC;       // G rows written per thread
   constexpr int MAXDOC = 8;            // 128 / 16
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 2 * ESTAGE];
   char* const sG = smem;
@@ -1071,7 +1070,7 @@ __global__ __launch_bounds__(NTHREADS) void head_dt_mfma_kernel(const float* __r
 // back with the transposing ds_read_b64_tr_b16.  LDS rows are 256 B = one full bank row, so the
 // 32-byte slot index is XOR-swizzled with f(row) = (row & 3) | ((row >> 3) & 1) << 2, which makes
 // the 8 rows a 32-lane half touches per transposing read land on 8 distinct slots.
-// Requires M % 32 == 0, N % 128 == 0, Kc % 128 == 0 (every stage is a full tile: no zero fill).
+// Requires N % 128 == 0, Kc % 128 == 0; token rows past the end of the last stage are DMA'd from a zero word.
 // ---------------------------------------------------------------------------------------
 constexpr int TG_BKM = 32, TG_STAGE = TG_BKM * 256;
 __device__ __forceinline__ int tg_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -1092,21 +1091,6 @@ __device__ __forceinline__ void wait_vm_dyn4(int younger) {
   }
 }
 
-__device__ __forceinline__ bf16x8 tg_load(const char* st, int colbase, int g, int li) {
-  typedef __attribute__((address_space(3))) s16x4 lds_v4;
-  const int q = li >> 2, p = li & 3;
-  const int r0 = 8 * g + q, r1 = r0 + 4;
-  const int cb = colbase * 2 + 8 * p;  // byte offset of this lane's 4 columns within the 256-B row
-  const char* a0 = st + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
-  const char* a1 = st + r1 * 256 + ((((cb >> 5) ^ tg_f(r1)) << 5) | (cb & 31));
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)a0);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)a1);
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo;
-  u.s.b = hi;
-  return u.v;
-}
-
 // Transposing LDS read issued as inline assembly.  The compiler's wait-count pass makes every LDS read
 // it knows about wait for ALL outstanding LDS-DMA loads (vmcnt(0)) -- it cannot tell which ring stage a
 // read touches -- which would drain the ring at every stage; reads it cannot see leave the counted
@@ -1121,12 +1105,6 @@ __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
-__device__ __forceinline__ f32x4 lds_r128f(uint32_t addr) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_w128f(uint32_t addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -1135,147 +1113,8 @@ __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
 __device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
 union TgFrag { struct { s16x4 lo, hi; } s; bf16x8 v; };
-// wait until at most N LDS reads are outstanding; the fragments go through the statement so that no
-// MFMA that consumes them can be scheduled above the wait
-template <int N>
-__device__ __forceinline__ void tg_wait(TgFrag& a, TgFrag& b, TgFrag& c, TgFrag& d, TgFrag& e) {
-  asm volatile("s_waitcnt lgkmcnt(%10)"
-               : "+v"(a.s.lo), "+v"(a.s.hi), "+v"(b.s.lo), "+v"(b.s.hi), "+v"(c.s.lo), "+v"(c.s.hi), "+v"(d.s.lo), "+v"(d.s.hi),
-                 "+v"(e.s.lo), "+v"(e.s.hi)
-               : "n"(N)
-               : "memory");
-}
-template <int N>
-__device__ __forceinline__ void tg_wait1(TgFrag& a) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.s.lo), "+v"(a.s.hi) : "n"(N) : "memory");
-}
-
-template <int TG_NST>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_glds_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
-                                                                float* __restrict__ C, int ldc, int M, int N, int Kc,
-                                                                int rows_per_split, float* __restrict__ colsum, int nsplit) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) char lds_char;
-  char* const sA = smem;
-  char* const sB = smem + TG_NST * TG_STAGE;
-  const TnBlock blk = tn_block_map(Kc / 128, N / 128, nsplit);
-  const int n0 = blk.nt * 128, k0 = blk.kt * 128;
-  if (blk.z < 0) return;
-  const int mbeg = blk.z * rows_per_split;
-  const int mend = min(M, mbeg + rows_per_split);
-  if (mbeg >= mend) return;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
-  const int nst = (mend - mbeg) / TG_BKM;
-  // this wave's two 1-KiB pieces per operand and stage: 4 token rows x 256 B each
-  size_t aoff[2], boff[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int row = (w * 2 + p) * 4 + (lane >> 4);
-    const int cphys = lane & 15;
-    const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;  // logical column (elements)
-    aoff[p] = (size_t)(mbeg + row) * lda + n0 + clog;
-    boff[p] = (size_t)(mbeg + row) * ldb + k0 + clog;
-  }
-  auto issue = [&](int st) {
-    char* da = sA + (st % TG_NST) * TG_STAGE + w * 2048;
-    char* db = sB + (st % TG_NST) * TG_STAGE + w * 2048;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + aoff[p] + (size_t)st * TG_BKM * lda), (lds_void_t*)(da + p * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + boff[p] + (size_t)st * TG_BKM * ldb), (lds_void_t*)(db + p * 1024), 16, 0, 0);
-    }
-  };
-  // per-lane LDS byte offsets (within a stage) of the two transposing reads of each fragment
-  uint32_t ra[4][2], rb[4][2];
-  {
-    const int q = li >> 2, p = li & 3;
-    const int r0 = 8 * g + q, r1 = r0 + 4;
-    const uint32_t baseA = (uint32_t)(uintptr_t)(lds_char*)sA, baseB = (uint32_t)(uintptr_t)(lds_char*)sB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cba = (wm * 64 + i * 16) * 2 + 8 * p, cbb = (wn * 64 + i * 16) * 2 + 8 * p;
-      ra[i][0] = baseA + r0 * 256 + ((((cba >> 5) ^ tg_f(r0)) << 5) | (cba & 31));
-      ra[i][1] = baseA + r1 * 256 + ((((cba >> 5) ^ tg_f(r1)) << 5) | (cba & 31));
-      rb[i][0] = baseB + r0 * 256 + ((((cbb >> 5) ^ tg_f(r0)) << 5) | (cbb & 31));
-      rb[i][1] = baseB + r1 * 256 + ((((cbb >> 5) ^ tg_f(r1)) << 5) | (cbb & 31));
-    }
-  }
-  f32x4 acc[4][4], cacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // column sums of A (the bias gradient) ride on the matrix pipe: A^T . ones, one extra MFMA per fragment
-  const bool do_colsum = colsum != nullptr && blk.kt == 0 && wn == 0;
-  bf16x8 ones;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
-#pragma unroll
-  for (int s = 0; s < TG_NST - 1; ++s)
-    if (s < nst) issue(s);
-  for (int st = 0; st < nst; ++st) {
-    const int younger = min(TG_NST - 2, nst - 1 - st);
-    if (younger >= TG_NST - 2) wait_vm<4 * (TG_NST - 2)>();
-    else wait_vm_dyn4(younger);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (st + TG_NST - 1 < nst) issue(st + TG_NST - 1);
-    const uint32_t so = (uint32_t)((st % TG_NST) * TG_STAGE);
-    TgFrag fa[4], fb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i].s.lo = lds_tr16(ra[i][0] + so);
-      fa[i].s.hi = lds_tr16(ra[i][1] + so);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fb[i].s.lo = lds_tr16(rb[i][0] + so);
-      fb[i].s.hi = lds_tr16(rb[i][1] + so);
-    }
-    tg_wait<6>(fa[0], fa[1], fa[2], fa[3], fb[0]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[0].v, acc[i][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tg_wait1<4>(fb[1]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[1].v, acc[i][1], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tg_wait1<2>(fb[2]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[2].v, acc[i][2], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tg_wait1<0>(fb[3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, fb[3].v, acc[i][3], 0, 0, 0);
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].v, ones, cacc[i], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = k0 + wn * 64 + j * 16 + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = n0 + wm * 64 + i * 16 + g * 4 + r;
-        atomicAdd(&C[(size_t)row * ldc + col], acc[i][j][r]);
-      }
-    }
-  if (do_colsum && li == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&colsum[n0 + wm * 64 + i * 16 + g * 4 + r], cacc[i][r]);
-  }
-}
-
-// Producer / consumer variant: 8 waves -- waves 4..7 only issue the LDS-DMA loads (an LDS-DMA instruction
-// holds its wave's issue slot for 60-180 cycles, time the MFMA waves of the kernel above lose per stage),
+// Producer / consumer structure: 8 waves -- waves 4..7 only issue the LDS-DMA loads (an LDS-DMA instruction
+// holds its wave's issue slot for 60-180 cycles, which waves that also issue MFMAs lose per stage),
 // waves 0..3 only read fragments and issue MFMAs, double-buffering the fragments so that the LDS reads of
 // stage st fly under the MFMAs of stage st-1.  One s_barrier per stage hands a landed stage to the
 // consumers and a drained slot back to the loaders.
@@ -1478,7 +1317,6 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
   constexpr int BKM = Tn<T>::BKM;
   static const int tn_glds = getenv("SM_TN_GLDS") ? atoi(getenv("SM_TN_GLDS")) : 4;  // LDS-DMA ring depth (0 = register-staged kernel)
   static const int tn_blocks = getenv("SM_TN_BLOCKS") ? atoi(getenv("SM_TN_BLOCKS")) : (tn_glds ? 256 : 1024);
-  static const int tn_pc = getenv("SM_TN_PC") ? atoi(getenv("SM_TN_PC")) : 1;  // producer/consumer waves (0 = every wave loads and computes)
   static const int tn_xcd = getenv("SM_TN_XCD") ? atoi(getenv("SM_TN_XCD")) : 1;
   // token splits: about tn_blocks workgroups in total, at least 4 stages each, a multiple of 8 when there
   // are enough of them so that tn_block_map can give every split its own XCD
@@ -1493,7 +1331,7 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
   auto nblocks = [&](int nsplit) { return tn_xcd ? (tiles * nsplit + 7) / 8 * 8 : tiles * nsplit; };
   int nsplit, rows_per_split;
   if constexpr (sizeof(T) == 2) {
-    if (tn_glds && (tn_pc || M % TG_BKM == 0) && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
+    if (tn_glds && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
       plan(tn_blocks, TG_BKM, nsplit, rows_per_split);
       auto launch = [&](auto kern, int nstg, int nthr = NTHREADS) {
         const int lds = 2 * nstg * TG_STAGE;
@@ -1501,16 +1339,9 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
         hipLaunchKernelGGL(kern, dim3(nblocks(nsplit)), dim3(nthr), lds, st, (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, Kc,
                            rows_per_split, colsum, tn_xcd ? nsplit : -nsplit);
       };
-      if (tn_pc) {
-        if (tn_glds >= 8) launch(gemm_tn_pc_kernel<8>, 8, 512);
-        else if (tn_glds >= 6) launch(gemm_tn_pc_kernel<6>, 6, 512);
-        else launch(gemm_tn_pc_kernel<4>, 4, 512);
-        return 0;
-      }
-      if (tn_glds >= 9) launch(gemm_tn_glds_kernel<9>, 9);
-      else if (tn_glds >= 8) launch(gemm_tn_glds_kernel<8>, 8);
-      else if (tn_glds >= 6) launch(gemm_tn_glds_kernel<6>, 6);
-      else launch(gemm_tn_glds_kernel<4>, 4);
+      if (tn_glds >= 8) launch(gemm_tn_pc_kernel<8>, 8, 512);
+      else if (tn_glds >= 6) launch(gemm_tn_pc_kernel<6>, 6, 512);
+      else launch(gemm_tn_pc_kernel<4>, 4, 512);
       return 0;
     }
   }

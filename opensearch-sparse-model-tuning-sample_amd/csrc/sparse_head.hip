@@ -14,48 +14,8 @@ int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const 
 
 namespace {
 
-// ---- backward of the fused head, part 1: dt[b,l,:] = sum_{v: argmax[b,v]=l} g[b,v] E[v,:] ----
-// grid (B, H/CW), CW = 64*CPL columns; the [S][CW] fp32 slice of dt accumulates in LDS (ds_add_f32).
-template <typename T, int CPL>
-__global__ __launch_bounds__(256) void head_dt_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
-                                                      const uint16_t* __restrict__ argmax, const T* __restrict__ E,
-                                                      T* __restrict__ dt, int S, int H, int V, int use_l0) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CW = 64 * CPL;
-  float* acc = reinterpret_cast<float*>(smem);  // [S][CW]
-  const int b = blockIdx.x, hc = blockIdx.y * CW;
-  for (int i = threadIdx.x; i < S * CW; i += 256) acc[i] = 0.f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t rb = (size_t)b * V;
-  for (int v0 = w * 64; v0 < V; v0 += 256) {
-    const int v = v0 + lane;
-    float gv = 0.f;
-    int l = 0;
-    if (v < V) {
-      const float r = rep[rb + v];
-      gv = grad_rep[rb + v] * head_fprime(r, use_l0);
-      l = argmax[rb + v];
-    }
-    unsigned long long nz = __ballot(gv != 0.f);
-    while (nz) {
-      const int i = __ffsll((long long)nz) - 1;
-      nz &= nz - 1;
-      const float gi = __shfl(gv, i, 64);
-      const int li = __shfl(l, i, 64);
-      const T* er = E + (size_t)(v0 + i) * H + hc + lane * CPL;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) atomicAdd(&acc[li * CW + lane * CPL + c], gi * to_f32<T>(er[c]));
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < S * CW; i += 256) {
-    const int l = i / CW, c = i % CW;
-    dt[((size_t)b * S + l) * H + hc + c] = from_f32<T>(acc[i]);
-  }
-}
-
-// ---- part 2: dE[v,:] += sum_b g[b,v] t[b, argmax[b,v], :],  dbias[v] += sum_b g[b,v] ----
+// ---- backward of the fused head, gather form (fallback of head_de128_kernel in gemm.hip):
+// dE[v,:] += sum_b g[b,v] t[b, argmax[b,v], :],  dbias[v] += sum_b g[b,v] ----
 // block = 16 vocab rows (4 per wave); g / argmax tiles for 256 documents at a time in LDS.
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_de_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
