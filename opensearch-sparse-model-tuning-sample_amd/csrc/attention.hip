@@ -204,33 +204,41 @@ struct Lay {  // LDS strides (bytes); +16 keeps 16-byte alignment and rotates ba
 };
 
 // ------------------------------------------------------------------------------------
-template <typename T, int DH, int NKT>
+// HP = heads per workgroup.  With head dim 32 a (row, head) slice is 64 B -- half a cache line, the other half
+// being the neighbouring head -- so one head per workgroup fetches every line of q/k/v twice (measured: 2x
+// the algorithmic HBM traffic forward, 3.5x backward); two adjacent heads per workgroup use whole lines.
+template <typename T, int DH, int NKT, int HP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = Lay<T, DH>;
+  using L = Lay<T, HP * DH>;  // LDS images hold the HP heads side by side
   constexpr int NKS = DH / AT<T>::KSTEP;
   const int H = A * DH;
   const size_t ld = 3 * (size_t)H;
-  const int b = blockIdx.x / A, h = blockIdx.x % A;
+  const int AP = A / HP;
+  const int b = blockIdx.x / AP, h0 = (blockIdx.x % AP) * HP;
   // dense layout: document b = rows [b*S, b*S+S); ragged: rows [doc_off[b], doc_off[b+1]), a multiple of 16
   const int row0 = doc_off ? doc_off[b] : b * S;
   const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
   const int nqb = Lr / 16;             // query blocks that exist
   const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
-  char* sK = smem;                          // [S][DH] row-major
-  char* sVt = sK + S * L::RS;               // V, [S][DH] row-major (consumed through transposing reads)
-  uint8_t* sM = reinterpret_cast<uint8_t*>(sVt + S * L::RS);
-  const T* base = qkv + (size_t)row0 * ld + h * DH;
-  stage<T, DH>(base + H, ld, Lr, nkt * 16, sK, L::RS, nullptr, 0);
-  stage<T, DH>(base + 2 * H, ld, Lr, nkt * 16, sVt, L::RS, nullptr, 0);  // row-major; read transposed
+  char* sK0 = smem;                         // [S][HP*DH] row-major
+  char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sV0 + S * L::RS);
+  const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
+  stage<T, HP * DH>(base0 + H, ld, Lr, nkt * 16, sK0, L::RS, nullptr, 0);
+  stage<T, HP * DH>(base0 + 2 * H, ld, Lr, nkt * 16, sV0, L::RS, nullptr, 0);
   for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const float scale = rsqrtf((float)DH);
-  for (int qb = w; qb < nqb; qb += 4) {
+  for (int u = w; u < nqb * HP; u += 4) {  // units = (query block, head)
+    const int qb = u / HP, hh = u % HP, h = h0 + hh;
+    const T* base = base0 + hh * DH;
+    const char* sK = sK0 + hh * DH * (int)sizeof(T);
+    const char* sVt = sV0 + hh * DH * (int)sizeof(T);
     typename AT<T>::Frag fq[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fq[ks] = grow_frag<T>(base, ld, qb * 16 + li, ks, g);
@@ -289,59 +297,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------
-template <typename T, int DH>
+template <typename T, int DH, int HP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = Lay<T, DH>;
+  using L = Lay<T, HP * DH>;
   constexpr int NKS = DH / AT<T>::KSTEP;
   const int H = A * DH;
   const size_t ld = 3 * (size_t)H;
-  const int b = blockIdx.x / A, h = blockIdx.x % A;
+  const int AP = A / HP;
+  const int b = blockIdx.x / AP, h0 = (blockIdx.x % AP) * HP;
   const int row0 = doc_off ? doc_off[b] : b * S;
   const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
   const int nblk = Lr / 16;            // 16-row blocks that exist (outputs are written for these)
   const int nt = (nblk + 1) & ~1;      // tiles of the LDS images, rounded up to a pair (zero-filled)
   // two [S][DH] images, used twice: K,V while phase A runs, then Q,dO for phase B (the per-block
   // operand of each phase -- Q,dO rows in A, K,V rows in B -- comes straight from global memory)
-  char* sX = smem;
-  char* sY = sX + S * L::RS;
-  float* sLse = reinterpret_cast<float*>(sY + S * L::RS);
-  float* sDelta = sLse + S;
-  uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta + S);
-  const T* base = qkv + (size_t)row0 * ld + h * DH;
-  const T* dob = dctx + (size_t)row0 * H + h * DH;
-  const T* ob = ctx + (size_t)row0 * H + h * DH;
-  stage<T, DH>(base + H, ld, Lr, nt * 16, sX, L::RS, nullptr, 0);
-  stage<T, DH>(base + 2 * H, ld, Lr, nt * 16, sY, L::RS, nullptr, 0);
-  for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
+  char* sX0 = smem;
+  char* sY0 = sX0 + S * L::RS;
+  float* sLse0 = reinterpret_cast<float*>(sY0 + S * L::RS);  // [HP][S]
+  float* sDelta0 = sLse0 + HP * S;                            // [HP][S]
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sDelta0 + HP * S);
+  const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
+  const T* dob0 = dctx + (size_t)row0 * H + h0 * DH;
+  const T* ob0 = ctx + (size_t)row0 * H + h0 * DH;
+  stage<T, HP * DH>(base0 + H, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
+  stage<T, HP * DH>(base0 + 2 * H, ld, Lr, nt * 16, sY0, L::RS, nullptr, 0);
+  for (int idx = threadIdx.x; idx < HP * nt * 16; idx += blockDim.x) {
+    const int hh = idx / (nt * 16), i = idx % (nt * 16);
     float d = 0.f;
     if (i < Lr) {
       constexpr int EPC = 16 / (int)sizeof(T);
 #pragma unroll
       for (int c = 0; c < DH; c += EPC) {
-        const uint4 a = *reinterpret_cast<const uint4*>(dob + (size_t)i * H + c);
-        const uint4 o = *reinterpret_cast<const uint4*>(ob + (size_t)i * H + c);
+        const uint4 a = *reinterpret_cast<const uint4*>(dob0 + (size_t)i * H + hh * DH + c);
+        const uint4 o = *reinterpret_cast<const uint4*>(ob0 + (size_t)i * H + hh * DH + c);
         const T* ea = reinterpret_cast<const T*>(&a);
         const T* eo = reinterpret_cast<const T*>(&o);
 #pragma unroll
         for (int j = 0; j < EPC; ++j) d += to_f32<T>(ea[j]) * to_f32<T>(eo[j]);
       }
     }
-    sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
-    sLse[i] = i < Lr ? lse[(size_t)(b * A + h) * S + i] : 0.f;
-    sDelta[i] = d;
+    if (hh == 0) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
+    sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] : 0.f;
+    sDelta0[hh * S + i] = d;
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const float scale = rsqrtf((float)DH);
-  T* dq_out = dqkv + (size_t)row0 * ld + h * DH;
+  T* dq_out0 = dqkv + (size_t)row0 * ld + h0 * DH;
 
   // ---- phase A: per query block, S^T orientation (rows = keys, col = query) -> dQ ----
-  for (int qb = w; qb < nblk; qb += 4) {
+  for (int u = w; u < nblk * HP; u += 4) {  // units = (query block, head)
+    const int qb = u / HP, hh = u % HP, h = h0 + hh;
+    const int cof = hh * DH * (int)sizeof(T);
+    const char* sX = sX0 + cof;
+    const char* sY = sY0 + cof;
+    const T* base = base0 + hh * DH;
+    const T* dob = dob0 + hh * DH;
+    T* dq_out = dq_out0 + hh * DH;
     const int q = qb * 16 + li;
     typename AT<T>::Frag fq[NKS], fdo[NKS];
 #pragma unroll
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       fq[ks] = grow_frag<T>(base, ld, q, ks, g);
       fdo[ks] = grow_frag<T>(dob, H, q, ks, g);
     }
-    const float lq = sLse[q], dl = sDelta[q];
+    const float lq = sLse0[hh * S + q], dl = sDelta0[hh * S + q];
     const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
     f32x4 dq[DH / 16];
 #pragma unroll
@@ -381,12 +398,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, dq[dt]);
   }
   __syncthreads();  // every wave is done with the K,V images
-  stage<T, DH>(base, ld, Lr, nt * 16, sX, L::RS, nullptr, 0);
-  stage<T, DH>(dob, H, Lr, nt * 16, sY, L::RS, nullptr, 0);
+  stage<T, HP * DH>(base0, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
+  stage<T, HP * DH>(dob0, H, Lr, nt * 16, sY0, L::RS, nullptr, 0);
   __syncthreads();
 
   // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
-  for (int kb = w; kb < nblk; kb += 4) {
+  for (int u = w; u < nblk * HP; u += 4) {  // units = (key block, head)
+    const int kb = u / HP, hh = u % HP, h = h0 + hh;
+    const int cof = hh * DH * (int)sizeof(T);
+    const char* sX = sX0 + cof;
+    const char* sY = sY0 + cof;
+    const T* base = base0 + hh * DH;
+    T* dq_out = dq_out0 + hh * DH;
+    const float* sLse = sLse0 + hh * S;
+    const float* sDelta = sDelta0 + hh * S;
     const int key = kb * 16 + li;
     typename AT<T>::Frag fk[NKS], fv[NKS];
 #pragma unroll
@@ -439,19 +464,31 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   }
 }
 
+template <typename T, int DH, int HP>
+size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + S; }
+template <typename T, int DH, int HP>
+size_t bwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + HP * 8 * (size_t)S + S; }
+// two heads per workgroup where a head's row is half a cache line and the pair's images fit
 template <typename T, int DH>
-size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, DH>::RS + S; }
-template <typename T, int DH>
-size_t bwd_lds(int S) { return 2 * (size_t)S * Lay<T, DH>::RS + 8 * (size_t)S + S; }
+constexpr bool pair_heads(int A, int S) { return false; }
+template <> constexpr bool pair_heads<bf16, 32>(int A, int S) { return A % 2 == 0; }
 
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename T, int DH, int NKT>
 int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B, int S, int A, const DropCfg& d, const int32_t* doc_off,
                hipStream_t st) {
-  const size_t lds = fwd_lds<T, DH>(S);
+  if (pair_heads<T, DH>(A, S)) {
+    const size_t lds = fwd_lds<T, DH, 2>(S);
+    SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
+    auto kern = attn_fwd_kernel<T, DH, NKT, 2>;
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
+    return SM_OK;
+  }
+  const size_t lds = fwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
-  auto kern = attn_fwd_kernel<T, DH, NKT>;
+  auto kern = attn_fwd_kernel<T, DH, NKT, 1>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
@@ -459,9 +496,17 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
 template <typename T, int DH>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
-  const size_t lds = bwd_lds<T, DH>(S);
+  if (pair_heads<T, DH>(A, S)) {
+    const size_t lds = bwd_lds<T, DH, 2>(S);
+    SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
+    auto kern = attn_bwd_kernel<T, DH, 2>;
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
+    return SM_OK;
+  }
+  const size_t lds = bwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-  auto kern = attn_bwd_kernel<T, DH>;
+  auto kern = attn_bwd_kernel<T, DH, 1>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
   return SM_OK;
