@@ -268,13 +268,17 @@ class SparseModelTrainer:
         self._slices["emb"] = (0, self._slices[0][0])
         bb._layer_hook = self._reduce_slice_async
 
-    def _reduce_slice_async(self, key):
+    def _reduce_slice_async(self, key, wgrad_event=None):
+        """All-reduce one slice of the flat gradient on the communication stream, ordered after the backward
+        kernels enqueued so far on the main stream and (``wgrad_event``) on the weight-gradient stream."""
         bb = self.model.sparse_model.backbone
         a, b = self._slices[key]
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
+            if wgrad_event is not None:
+                self._comm_stream.wait_event(wgrad_event)
             self._pending.append(dist.all_reduce(bb.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def _finish_grad_reduce(self):

@@ -436,6 +436,16 @@ class _WgradStream:
         if self.enabled:
             torch.cuda.current_stream().wait_stream(self.stream)
 
+    def mark(self):
+        """Event after everything enqueued on the side stream so far (None when the side stream is off): lets
+        a consumer on a third stream (the gradient all-reduce) wait for the weight gradients without making
+        the backward chain on the main stream wait for them."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
 
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
@@ -484,8 +494,7 @@ class _EncodeFn(torch.autograd.Function):
         wg.run(dft, x_last, g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
         dx = ops.gemm_nt(dft, st["tT"])
         if model._layer_hook is not None:
-            wg.join()
-            model._layer_hook("head")
+            model._layer_hook("head", wg.mark())
         for l in reversed(range(cfg.num_hidden_layers)):
             p = f"bert.encoder.layer.{l}."
             x, qkv, ctxt, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2 = ctx.saved["layers"][l]
@@ -510,8 +519,7 @@ class _EncodeFn(torch.autograd.Function):
             wg.run(dqkv, x, model.qkv_weight(l, grad=True), model.qkv_bias(l, grad=True))
             dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
             if model._layer_hook is not None:
-                wg.join()
-                model._layer_hook(l)
+                model._layer_hook(l, wg.mark())
         z0, m0, r0 = ctx.saved["emb"]
         d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
         if d_emb is not None:
