@@ -160,3 +160,147 @@ def gather_rep(rep: Tensor, accelerator=None, group=None) -> Tensor:
     if world == 1:
         return rep
     return _GatherFn.apply(rep, rank, world, group)
+
+
+# ---------------------------------------------------------------------------------------
+# Data-parallel loss head with the CHEAP exchange (SURVEY 8e "alternative worth measuring"): the reference
+# all-gathers d_rep [B_d, V] (62.5 MB per rank at config 2) and evaluates the whole loss on every rank
+# (trainer.py:101-141, utils.py:16-23).  The same loss and the same gradients follow from
+#   * all-gather of q_rep (small) and of the per-rank score blocks  S_r = q_all . d_local^T  [N*bs, B_d],
+#   * all-reduce of the FLOPS column means [k, V],
+# because the ranking loss depends on d only through the scores and FLOPS only through the column means.
+# Per rank the traffic drops from (N-1) x 62.5 MB to a few MB and the loss kernels keep working on the LOCAL
+# documents (at N = 8 the dense form costs 2.1 ms of loss kernels on the gathered tensors against 0.27 ms).
+# The dense all-gather stays available as the parity mode (gather_rep + the single-process functions above).
+class _DistLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d_local: Tensor, q_local: Tensor, teacher: Optional[Tensor], cfg: dict):
+        group = cfg.get("group")
+        N, rank = dist.get_world_size(group), dist.get_rank(group)
+        d, q = _f32c(d_local), _f32c(q_local)
+        nq, nd, V = q.shape[0], d.shape[0], d.shape[1]
+        if nd % nq:
+            raise L.SparseHipError(f"d_rep rows {nd} must be a multiple of q_rep rows {nq}")
+        k = nd // nq
+        thr, cap = cfg.get("flops_threshold"), cfg.get("q_cap")
+        q_all = torch.empty((N * nq, V), dtype=torch.float32, device=q.device)
+        dist.all_gather_into_tensor(q_all, q, group=group)
+
+        # FLOPS regulariser: global column means = mean of the per-rank column means (equal local batch sizes)
+        _, cm_d, keep_d = ops.flops_fwd(d, k, thr)
+        dist.all_reduce(cm_d, group=group)
+        cm_d.div_(N)
+        d_flops = (cm_d * cm_d).sum()
+        total = d_flops * float(cfg["lambda_d"])
+        cm_q = keep_q = None
+        if cfg.get("lambda_q") is not None:
+            _, cm_q, keep_q = ops.flops_fwd(q, 1, thr)
+            dist.all_reduce(cm_q, group=group)
+            cm_q.div_(N)
+            total = total + (cm_q * cm_q).sum() * float(cfg["lambda_q"])
+
+        losses = cfg["losses"]  # [(kind, weight, ibn, tau)]
+        ranking = torch.zeros((), dtype=torch.float32, device=d.device)
+        ds_ibn = ds_pairs = csr_all = csr_loc = None
+        if any(ibn for _, _, ibn, _ in losses):
+            csr_all = ops.row_compact(q_all, int(cap)) if cap else None
+            s_r = ops.scores_csr_fwd(csr_all, d, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, d, pairs=False)
+            s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
+            dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
+            scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
+            ds_full = torch.zeros_like(scores)
+            for kind, w, ibn, tau in losses:
+                if not ibn:
+                    continue
+                if kind == "infonce":
+                    l, g = ops.infonce(scores, k, pairs=False)
+                else:
+                    t = _f32c(teacher)
+                    if tuple(t.shape) != tuple(scores.shape):
+                        raise L.SparseHipError(f"teacher scores {tuple(t.shape)} do not match student scores {tuple(scores.shape)}")
+                    l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(scores, t, tau)
+                ranking = ranking + l.reshape(()) * float(w)
+                ds_full.add_(g, alpha=float(w))
+            ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous()
+        if any(not ibn for _, _, ibn, _ in losses):
+            csr_loc = ops.row_compact(q, int(cap)) if cap else None
+            sp = ops.scores_csr_fwd(csr_loc, d, pairs=True) if csr_loc is not None else ops.scores_fwd(q, d, pairs=True)
+            ds_pairs = torch.zeros_like(sp)
+            lp = torch.zeros((), dtype=torch.float32, device=d.device)
+            for kind, w, ibn, tau in losses:
+                if ibn:
+                    continue
+                if kind == "infonce":
+                    l, g = ops.infonce(sp, k, pairs=True)
+                else:
+                    t = _f32c(teacher)[rank * nq:(rank + 1) * nq].contiguous()  # teacher arrives gathered [N*bs, k]
+                    l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(sp, t, tau)
+                lp = lp + l.reshape(()) * float(w)
+                ds_pairs.add_(g, alpha=float(w))
+            lp_all = lp.reshape(1).clone()
+            dist.all_reduce(lp_all, group=group)  # mean over all queries = mean of the per-rank means
+            ranking = ranking + lp_all.reshape(()) / N
+            ds_pairs.div_(N)
+        total = total + ranking
+        cfg["out"] = {"d_flops": d_flops.detach(), "ranking": ranking.detach()}
+        ctx.cfg, ctx.N, ctx.rank, ctx.k = cfg, N, rank, k
+        ctx.csr_all, ctx.csr_loc, ctx.group = csr_all, csr_loc, group
+        ctx.has = (ds_ibn is not None, ds_pairs is not None, keep_d is not None, cm_q is not None, keep_q is not None)
+        e = torch.empty(0, device=d.device)
+        ctx.save_for_backward(d, q, q_all, cm_d, ds_ibn if ds_ibn is not None else e, ds_pairs if ds_pairs is not None else e,
+                              keep_d if keep_d is not None else e, cm_q if cm_q is not None else e,
+                              keep_q if keep_q is not None else e)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        d, q, q_all, cm_d, ds_ibn, ds_pairs, keep_d, cm_q, keep_q = ctx.saved_tensors
+        has_ibn, has_pairs, has_keep_d, has_cmq, has_keep_q = ctx.has
+        N, rank, k, cfg, group = ctx.N, ctx.rank, ctx.k, ctx.cfg, ctx.group
+        nq, nd = q.shape[0], d.shape[0]
+        gs = _f32c(grad_out).reshape(1)
+        need_q = ctx.needs_input_grad[1]
+        dd = torch.empty_like(d)
+        dq = torch.zeros_like(q) if need_q else None
+        wrote = False
+        if has_ibn:
+            ds = ops.scale_by(ds_ibn.clone(), gs)
+            dq_all = torch.empty_like(q_all) if need_q else None
+            if ctx.csr_all is not None:
+                ops.scores_csr_bwd(ctx.csr_all, d, ds, False, dq_all, dd)
+            else:
+                ops.scores_bwd(q_all, d, ds, False, dq_all, dd, False)
+            wrote = True
+            if need_q:  # every rank holds the part of dL/dq_all that flows through ITS documents
+                dist.all_reduce(dq_all, group=group)
+                dq.add_(dq_all[rank * nq:(rank + 1) * nq])
+        if has_pairs:
+            ds = ops.scale_by(ds_pairs.clone(), gs)
+            dd2 = torch.empty_like(d) if wrote else dd
+            dq2 = torch.empty_like(q) if need_q else None
+            if ctx.csr_loc is not None:
+                ops.scores_csr_bwd(ctx.csr_loc, d, ds, True, dq2, dd2)
+            else:
+                ops.scores_bwd(q, d, ds, True, dq2, dd2, False)
+            if wrote:
+                dd.add_(dd2)
+            wrote = True
+            if need_q:
+                dq.add_(dq2)
+        # FLOPS: d value / d rep = 2 * colmean_global / (N * n_local) * sign(rep) * keep -> the local kernel with 1/N folded in
+        gsc = gs * (float(cfg["lambda_d"]) / N)
+        ops.flops_bwd(d, cm_d, keep_d if has_keep_d else None, gsc, k, 0, nd, dd, wrote)
+        if has_cmq and need_q:
+            gq = gs * (float(cfg["lambda_q"]) / N)
+            ops.flops_bwd(q, cm_q, keep_q if has_keep_q else None, gq, 1, 0, nq, dq, True)
+        return dd, dq, None, None
+
+
+def distributed_loss(d_local: Tensor, q_local: Tensor, teacher: Optional[Tensor], cfg: dict) -> Tensor:
+    """Global ranking + FLOPS loss from LOCAL representations (see _DistLossFn).  cfg: losses = [(kind, weight,
+    in_batch_negatives, temperature)], lambda_d, lambda_q (None when the queries are inference-free), flops_threshold,
+    q_cap, group.  After the call cfg["out"] holds {"d_flops", "ranking"} for logging."""
+    for kind, _, _, _ in cfg["losses"]:
+        if kind not in ("infonce", "kldiv", "marginmse"):
+            raise KeyError(kind)
+    return _DistLossFn.apply(d_local, q_local, teacher, cfg)

@@ -71,11 +71,16 @@ cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_at
 bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None)
 bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
 model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
-margs = ModelArguments(model_name_or_path="x", inf_free=True)
-dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10)
+case = os.environ.get("SM_TEST_CASE", "infonce_ibn")
+inf_free = case != "learned_queries"
+ibn = case != "kd_pairs"
+kind = "kldiv" if case == "kd_pairs" else "infonce"
+margs = ModelArguments(model_name_or_path="x", inf_free=inf_free)
+dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
+                              flops_q_lambda=0.03, flops_q_T=10, flops_threshold=3 if case == "kd_pairs" else None)
 targs = TrainingArguments(output_dir="/tmp/sm_dist", logging_steps=1000, learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, max_steps=6)
 trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
-                             loss_functions=[LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1)])
+                             loss_functions=[LOSS_CLS_MAP[kind](use_in_batch_negatives=ibn, weight=0.7, temperature=2.0)])
 # global batch: 3 queries x 4 docs from the golden fixture, twice (6 queries); rank r takes queries [3r, 3r+3)
 t = lambda k: torch.tensor(g6["infonce_ibn/" + k])
 q_ids, q_mask = torch.cat([t("q_ids"), t("q_ids").flip(0)]), torch.cat([t("q_mask"), t("q_mask").flip(0)])
@@ -84,6 +89,8 @@ nq = 6 // world
 sl_q, sl_d = slice(rank * nq, (rank + 1) * nq), slice(rank * nq * 4, (rank + 1) * nq * 4)
 inp = {"query": [{"input_ids": q_ids[sl_q].cuda(), "attention_mask": q_mask[sl_q].cuda()}],
        "docs": [{"input_ids": d_ids[sl_d].cuda(), "attention_mask": d_mask[sl_d].cuda()}]}
+if kind == "kldiv":
+    inp["scores"] = (torch.randn(6, 4, generator=torch.Generator().manual_seed(3)) * 3)[sl_q]
 trainer.state.global_step = 3
 loss = trainer.training_step(inp)
 torch.cuda.synchronize()
@@ -96,22 +103,30 @@ print("done", rank)
 
 
 @pytest.mark.gpu
-def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_path):
+@pytest.mark.parametrize("case", ["infonce_ibn", "kd_pairs", "learned_queries"])
+def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_path, case):
+    """both exchange modes: "gather" (the reference's dense all-gather of the representations) and "scores" (queries,
+    score blocks and FLOPS column means only) must reproduce the single-process step; cases: inference-free InfoNCE
+    with in-batch negatives, KL distillation on per-query pairs with a row threshold in FLOPS, learned queries (the
+    query gradient crosses ranks, FLOPS on queries too)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_TEST_CASE=case)
+    one = str(tmp_path / "one.npz")
     r1 = subprocess.run([sys.executable, str(script), ROOT, PKG, one], capture_output=True, text=True, timeout=600, env=env)
     assert r1.returncode == 0, r1.stdout + r1.stderr
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                         "127.0.0.1", "--master-port", "29541", str(script), ROOT, PKG, two],
-                        capture_output=True, text=True, timeout=600, env=env)
-    assert r2.returncode == 0, r2.stdout + r2.stderr
-    a, b = np.load(one), np.load(two)
-    # each rank reports loss x num_processes (trainer.py:139-141)
-    assert abs(float(b["loss"]) - 2 * float(a["loss"])) <= 2e-3 * abs(float(a["loss"]))
-    diff = np.abs(a["flat"] - b["flat"])
-    # Adam turns rounding noise on exactly-zero gradients (key biases) into +-lr steps: allow lr-sized
-    # differences on a handful of elements, everything else must agree to fp32 accuracy
-    assert (diff > 1e-4).sum() <= 1e-3 * diff.size, int((diff > 1e-4).sum())
-    assert diff.max() <= 2.5e-3
+    a = np.load(one)
+    for port, mode in ((29541, "gather"), (29543, "scores")):
+        two = str(tmp_path / f"two_{mode}.npz")
+        r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                             "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two],
+                            capture_output=True, text=True, timeout=600, env=dict(env, SM_EXCHANGE=mode))
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        b = np.load(two)
+        # each rank reports loss x num_processes (trainer.py:139-141)
+        assert abs(float(b["loss"]) - 2 * float(a["loss"])) <= 2e-3 * abs(float(a["loss"])), mode
+        diff = np.abs(a["flat"] - b["flat"])
+        # Adam turns rounding noise on exactly-zero gradients (key biases) into +-lr steps: allow lr-sized
+        # differences on a handful of elements, everything else must agree to fp32 accuracy
+        assert (diff > 1e-4).sum() <= 1e-3 * diff.size, (mode, int((diff > 1e-4).sum()))
+        assert diff.max() <= 2.5e-3, mode
