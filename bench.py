@@ -238,8 +238,9 @@ def main():
                                f"documents padded to {args.seq} by the collator, padding tokens skipped on the device "
                                f"({T:.0f} of {T_padded} token rows computed per step)",
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
-                   "parallelism": f"dp{world}"},
-        "roofline": {"kernel": "sparse_head_fwd_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
+                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks: queries, score blocks and "
+                                                      "FLOPS column means exchanged over RCCL; flat-gradient all-reduce overlapped with backward)")},
+        "roofline": {"kernel": "sparse_head_fwd_ares_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
                      "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "kernel_ms": head_ms, "rows_per_launch": T},
     }
