@@ -224,6 +224,16 @@ def main():
     head_flops = 2.0 * T * H * V  # executed FLOPs of one fused decoder launch (2THV, T = computed rows)
     achieved = head_flops / (head_ms * 1e-3)
     peak = MFMA_PEAK[args.dtype]
+    # HBM-side bytes per launch of the roofline kernel: not measurable from inside this process (PMC counters need
+    # rocprofv3); taken from the committed PMC passes of this same command (tools/pmc_summary.py), null if absent
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
+        if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
+            traffic = pmc["kernels"]["sparse_head_fwd_ares_kernel"]["bytes_per_launch"]
+            traffic_src = "profiles/r1_pmc_traffic.json: " + pmc["source"]
+    except (OSError, KeyError, ValueError):
+        pass
     result = {
         "metric": "training samples/sec (q+1pos+15neg, seq128)",
         "value": world * args.bs * args.steps / elapsed,
@@ -242,7 +252,8 @@ def main():
                                                       "FLOPS column means exchanged over RCCL; flat-gradient all-reduce overlapped with backward)")},
         "roofline": {"kernel": "sparse_head_fwd_ares_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
                      "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel_ms": head_ms, "rows_per_launch": T},
+                     "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
+                     "kernel_ms": head_ms, "rows_per_launch": T},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
