@@ -59,10 +59,13 @@ class PreTokenizedCollator:
 
     def __call__(self, batch):
         q, d, s = zip(*batch)
-        q = torch.from_numpy(np.stack(q))[:, :self.max_length]
-        d = torch.from_numpy(np.concatenate(d, axis=0))[:, :self.max_length]
-        enc_q = {"input_ids": q, "attention_mask": (q != 0).long()}
-        enc_d = {"input_ids": d, "attention_mask": (d != 0).long()}
+        # numpy, not torch, for the element-wise host work: a torch CPU op fans out to every visible core, which
+        # on a CPU-quota'd container costs 5-30 ms per 64k-element op (measured: the step went 11.8 -> 41.7 ms)
+        qn = np.ascontiguousarray(np.stack(q)[:, :self.max_length])
+        dn = np.ascontiguousarray(np.concatenate(d, axis=0)[:, :self.max_length])
+        q, d = torch.from_numpy(qn), torch.from_numpy(dn)
+        enc_q = {"input_ids": q, "attention_mask": torch.from_numpy((qn != 0).astype(np.int64))}
+        enc_d = {"input_ids": d, "attention_mask": torch.from_numpy((dn != 0).astype(np.int64))}
         out = {"query": [enc_q] + [dict(enc_q) for _ in range(self.n_teachers)],
                "docs": [enc_d] + [dict(enc_d) for _ in range(self.n_teachers)]}
         if s[0] is not None:

@@ -67,9 +67,10 @@ def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_
     pids = np.where(valid, ids[row_doc, np.minimum(pos, S - 1)], pad_token_id).astype(np.int64)
     smax = next(s for s in SUPPORTED_S if s >= int(L16.max()))
     dev = torch.device(device)
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev, non_blocking=True)
-    rag = ops.Ragged(t(doc_off, torch.int32), t(row_doc[::16], torch.int32), t(pos, torch.int32), rows, B, smax)
-    return PackedDocs(t(pids, torch.int64), t(valid, torch.uint8), rag)
+    # dtype conversions in numpy: a torch CPU op fans out to every visible core (slow on a CPU-quota'd host)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)
+    rag = ops.Ragged(t(doc_off, np.int32), t(row_doc[::16], np.int32), t(pos, np.int32), rows, B, smax)
+    return PackedDocs(t(pids, np.int64), t(valid, np.uint8), rag)
 
 
 @dataclass
