@@ -13,6 +13,8 @@ import logging
 import os
 from typing import Optional
 
+import itertools
+
 import torch
 
 from sparse_hip import functional as F
@@ -119,3 +121,73 @@ class SparseModel(torch.nn.Module):
 
     def _encode_inf_free(self, **kwargs):
         return F.inf_free_encode(kwargs["input_ids"], self.idf_vector, self._special)
+
+
+# ---------------------------------------------------------------------------------------
+# Inference encode for ingest / search (reference sparse_encoders.py:130-181).  Same forward as
+# training (no_grad); the reference's post-processing -- torch.nonzero + fancy indexing + bincount + three
+# .tolist() device syncs -- becomes ONE device kernel (ballot-prefix row compaction, sm_row_compact) and one D2H copy.
+class SparsePostProcessor(object):
+    def __init__(self, tokenizer, max_nnz: int = 2048):
+        self.tokenizer = tokenizer
+        self.id_to_token = ["" for _ in range(len(tokenizer.vocab) + 100)]
+        for token, _id in tokenizer.vocab.items():
+            self.id_to_token[_id] = token
+        self.max_nnz = int(max_nnz)
+
+    def extract(self, sparse_vector):
+        """CSR of the batch on the host: (token ids int32 [nnz_total], weights f32 [nnz_total], per-row counts int32 [B]);
+        rows are in increasing token id and exclude column 0, like the reference output."""
+        from sparse_hip import ops
+        x = sparse_vector.float().contiguous()
+        if x.shape[1] > 1 and bool((x[:, 0] != 0).any()):
+            x = x.clone()
+            x[:, 0] = 0  # the reference writes 1 here and then drops the entry: net effect = column 0 never appears
+        cap = min(self.max_nnz, x.shape[1])
+        while True:
+            cols, vals, nnz, overflow = ops.row_compact(x, cap)
+            live = torch.arange(cap, device=x.device)[None, :] < nnz[:, None]
+            flat = torch.cat([nnz, overflow, cols[live], vals[live].view(torch.int32)]).cpu().numpy()  # one D2H copy
+            B = x.shape[0]
+            if flat[B] == 0 or cap >= x.shape[1]:
+                break
+            cap = x.shape[1]  # some row has more than max_nnz entries (untrained model): one retry at full width
+        n = flat[:B]
+        tot = int(n.sum())
+        return flat[B + 1:B + 1 + tot], flat[B + 1 + tot:B + 1 + 2 * tot].view("float32"), n
+
+    def __call__(self, sparse_vector):
+        cols, vals, nnz = self.extract(sparse_vector)
+        id_to_token = self.id_to_token
+        tokens = [id_to_token[t] for t in cols.tolist()]
+        weights = vals.tolist()
+        ends = list(itertools.accumulate([0] + nnz.tolist()))
+        return [dict(zip(tokens[ends[i]:ends[i + 1]], weights[ends[i]:ends[i + 1]])) for i in range(len(ends) - 1)]
+
+
+class SparseEncoder:
+    def __init__(self, sparse_model, max_length, do_count=True):
+        self.model = sparse_model
+        self.tokenizer = sparse_model.tokenizer
+        self.post_processor = SparsePostProcessor(tokenizer=sparse_model.tokenizer)
+        self.do_count = do_count
+        self.max_length = max_length
+        self.device = self.model.backbone.device
+        self.count_tensor = torch.zeros(self.model.vocab_size, device=self.device)
+
+    def reset_count(self):
+        self.count_tensor = torch.zeros(self.model.vocab_size, device=self.device)
+
+    def encode(self, texts, inf_free=False):
+        features = self.tokenizer(list(texts), padding=True, truncation=True, return_tensors="pt",
+                                  return_token_type_ids=False, max_length=self.max_length)
+        return self.encode_features(features, inf_free=inf_free)
+
+    def encode_features(self, features, inf_free=False):
+        """same as encode() from already tokenised input_ids / attention_mask"""
+        features = {k: v.to(self.device) for k, v in features.items()}
+        with torch.no_grad():
+            output = self.model(inf_free=inf_free, **features)
+        if self.do_count:
+            self.count_tensor += (output > 0).sum(dim=0)
+        return self.post_processor(output)

@@ -392,3 +392,17 @@ def init_params(cfg: BertShape, seed: int = 0, std: float = 0.02) -> Dict[str, T
     p[c + "transform.LayerNorm.bias"] = torch.zeros(H)
     p[c + "bias"] = torch.zeros(V)
     return p
+
+
+def postprocess_rows(sparse_vector: Tensor):
+    """Restatement of SparsePostProcessor.__call__ (scripts/model/sparse_encoders.py:137-150) without the
+    tokenizer: per row the (token id, weight) pairs it emits -- every non-zero column except column 0 (the
+    reference forces column 0 to 1 so that each row has an entry, then drops it), in increasing token id."""
+    x = sparse_vector.clone().float()
+    x[:, 0] = 1.0
+    out = []
+    for row in x:
+        idx = torch.nonzero(row).flatten()
+        idx = idx[idx != 0]
+        out.append((idx.tolist(), row[idx].tolist()))
+    return out

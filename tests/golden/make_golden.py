@@ -18,6 +18,8 @@ Fixtures (names follow SURVEY.md section 8c):
   g6_compute_loss.npz  SparseModelTrainer.compute_loss end to end at 3 steps
   g7_gather.npz   2-process gloo gather_rep + losses vs 1-process concatenation
   g8_adamw.npz    3 optimiser steps (AdamW wd on all params + linear warm-up)
+  g9_postprocess.npz  SparsePostProcessor (sparse_encoders.py:130-150) on a small sparse matrix:
+                  per row the (token id, weight) pairs it emits      [python make_golden.py g9]
 """
 import importlib.machinery
 import json
@@ -402,5 +404,34 @@ def g6_g8(tmp, idf, rng):
     return res
 
 
+def g9():
+    """inference-side extraction: what the reference's post-processor returns per row"""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from scripts.model.sparse_encoders import SparsePostProcessor
+
+    class Tok:
+        vocab = {t: i for i, t in enumerate(vocab_tokens())}
+
+    rng = np.random.default_rng(9)
+    x = rng.random((6, V)).astype(np.float32)
+    x[x < 0.93] = 0.0
+    x[2] = 0.0          # a row without any non-zero
+    x[3, 0] = 0.5       # column 0 is overwritten with 1 and dropped by the post-processor
+    out = SparsePostProcessor(Tok())(torch.tensor(x).clone())
+    nnz = np.array([len(d) for d in out], dtype=np.int32)
+    cols = np.full((len(out), int(nnz.max())), -1, dtype=np.int32)
+    vals = np.zeros((len(out), int(nnz.max())), dtype=np.float32)
+    for i, d in enumerate(out):
+        for j, (t, w) in enumerate(d.items()):
+            cols[i, j] = Tok.vocab[t]
+            vals[i, j] = w
+    np.savez_compressed(os.path.join(HERE, "g9_postprocess.npz"), x=x, nnz=nnz, cols=cols, vals=vals)
+    print("g9_postprocess.npz", nnz.tolist())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9()
+    else:
+        main()

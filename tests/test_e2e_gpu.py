@@ -389,3 +389,44 @@ def test_bert_base_shaped_layer_matches_oracle(dtype):
         for n in ("bert.encoder.layer.0.attention.self.value.weight", "bert.encoder.layer.0.intermediate.dense.weight",
                   "bert.encoder.layer.0.output.LayerNorm.weight", "cls.predictions.transform.dense.weight"):
             close(bb.view(n, grad=True), pr[n].grad, TOL[dtype] * 3, "grad " + n)
+
+
+def test_inference_postprocessor_matches_reference_golden_and_oracle():
+    """device-side extraction (one kernel + one D2H copy) == the reference's post-processor (G9),
+    also when rows overflow the first-pass capacity; then the whole encode path on the tiny model vs the oracle"""
+    from scripts.model.sparse_encoders import SparseEncoder, SparseModel, SparsePostProcessor
+    from sparse_hip.encoder import HipBertMLM
+    g = load("g9_postprocess.npz")
+
+    class Tok:
+        vocab = {f"t{i}": i for i in range(g["x"].shape[1])}
+
+    for cap in (2048, 8):  # 8 < max nnz: exercises the overflow retry
+        pp = SparsePostProcessor(Tok(), max_nnz=cap)
+        out = pp(torch.tensor(g["x"]).cuda())
+        assert [len(d) for d in out] == g["nnz"].tolist()
+        for i, d in enumerate(out):
+            n = int(g["nnz"][i])
+            assert list(d.keys()) == [f"t{t}" for t in g["cols"][i, :n].tolist()]
+            np.testing.assert_array_equal(np.array(list(d.values()), dtype=np.float32), g["vals"][i, :n])
+    # encode path: forward (no grad) + extraction, against the oracle's rows on the same representation
+    g1 = load("g1_encode.npz")
+    bb = HipBertMLM(tiny_cfg(), compute_dtype=torch.float32, device="cuda", init_seed=None)
+    bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
+    m = SparseModel(bb, use_l0=False)
+    m.tokenizer = Tok2 = type("Tok2", (), {"vocab": {f"t{i}": i for i in range(520)}})()
+    enc = SparseEncoder(m, max_length=32)
+    feats = {"input_ids": torch.tensor(g1["input_ids"]), "attention_mask": torch.tensor(g1["attention_mask"])}
+    out = enc.encode_features(feats)
+    want = O.postprocess_rows(torch.tensor(g1["rep_l00_prune0"]))
+    assert len(out) == len(want)
+    for d, (ids, w) in zip(out, want):
+        got_ids = [int(t[1:]) for t in d.keys()]
+        # fp32 path: the support may differ only where the golden value is within rounding of zero
+        assert set(got_ids) ^ set(ids) <= {i for i, x in zip(ids, w) if abs(x) < 1e-4}
+        ref = dict(zip(ids, w))
+        for t, x in zip(got_ids, d.values()):
+            if t in ref:
+                assert abs(x - ref[t]) <= 1e-3 * (1 + abs(ref[t]))
+    # do_count: per-token document frequencies of the batch (column 0 is never emitted)
+    assert int(enc.count_tensor[1:].sum()) == sum(len(d) for d in out)

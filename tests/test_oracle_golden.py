@@ -188,3 +188,13 @@ def test_g8_adamw_three_steps():
         assert abs((a * a).sum() - float(g8["sumsq/" + n])) < 1e-4 * max(1.0, float(g8["sumsq/" + n])), n
     for k in [k for k in g8.files if k.startswith("final/")]:
         close(p[k[len("final/"):]].detach(), g8[k], 2e-5)
+
+
+def test_g9_postprocess_rows_match_reference():
+    g = load("g9_postprocess.npz")
+    rows = O.postprocess_rows(torch.tensor(g["x"]))
+    assert [len(r[0]) for r in rows] == g["nnz"].tolist()
+    for i, (ids, w) in enumerate(rows):
+        n = int(g["nnz"][i])
+        assert ids == g["cols"][i, :n].tolist()
+        np.testing.assert_allclose(np.array(w, dtype=np.float32), g["vals"][i, :n], rtol=0, atol=0)
