@@ -190,6 +190,15 @@ int sm_adamw(float* param, const float* grad, float* m, float* v, long n, float 
 /* fp32 master [rows,cols] -> dtype copy (ld_out >= cols) and optional transposed copy [cols,rows] */
 int sm_cast_weight(int dtype, const float* w, int rows, int cols, void* out, int ld_out, void* out_t,
                    int ld_out_t, void* stream);
+/* the same for a whole table of tensors in one launch.  descs_dev: DEVICE array of n descriptors sorted by
+ * tile_begin (prefix sum of ceil(rows/32)*ceil(cols/32)); total_tiles = the grand total. */
+typedef struct sm_cast_desc {
+  const float* w;
+  void* out;    /* may be NULL */
+  void* out_t;  /* may be NULL */
+  int rows, cols, ld_out, ld_out_t, tile_begin, _pad;
+} sm_cast_desc;
+int sm_cast_weights_multi(int dtype, const sm_cast_desc* descs_dev, int n, int total_tiles, void* stream);
 /* scalar helpers on device: out = a*x + b*y (all device scalars or arrays of n) */
 int sm_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
 /* x[i] *= s[0] * c with s a DEVICE scalar (autograd's upstream gradient): no host sync */

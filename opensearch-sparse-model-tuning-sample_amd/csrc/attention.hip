@@ -371,7 +371,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     f32x4 dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
     for (int t2 = 0; t2 < nt / 2; ++t2) {
       typename PT<T>::type ds[2];
 #pragma unroll
@@ -427,7 +426,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const uint64_t hbase = (uint64_t)(b * A + h) * S;
-#pragma unroll 2
     for (int t2 = 0; t2 < nt / 2; ++t2) {
       typename PT<T>::type pd[2], ds[2];
 #pragma unroll

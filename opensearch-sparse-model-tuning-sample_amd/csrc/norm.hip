@@ -7,7 +7,6 @@
 namespace {
 
 constexpr int MAXC = 16;  // H <= 1024 (scalar-column mapping of the embedding backward)
-constexpr int MAXCH = 8;  // 16-byte chunks of 8 elements per lane in the vector mapping (H <= 1024)
 
 // Vector mapping: a 64-lane wave works on 4 rows at once, 16 lanes per row; lane `sl` of a
 // row group holds chunks sl, sl+16, ... of 8 consecutive elements (16 B of bf16), so each

@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
   }
 }
 
+// all staging copies of a step in ONE launch: blockIdx.x -> (tensor, 32 x 32 tile) through the tile prefix table
+// (the 26 separate launches of the v2-mini step cost ~0.3 ms of exposed launch latency at the step boundary,
+// where the queue is empty and every 6-microsecond kernel waits for the host)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_multi_kernel(const sm_cast_desc* __restrict__ descs, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;  // last descriptor with tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sm_cast_desc d = descs[lo];
+  const int t = blockIdx.x - d.tile_begin, tiles_x = (d.cols + 31) / 32;
+  const int r0 = (t / tiles_x) * 32, c0 = (t % tiles_x) * 32;
+  const float* w = d.w;
+  T* out = reinterpret_cast<T*>(d.out);
+  T* out_t = reinterpret_cast<T*>(d.out_t);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    const float x = (r < d.rows && c < d.cols) ? w[(size_t)r * d.cols + c] : 0.f;
+    tile[rr][tx] = x;
+    if (out && r < d.rows && c < d.cols) out[(size_t)r * d.ld_out + c] = from_f32<T>(x);
+  }
+  if (out_t) {
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (c < d.cols && r < d.rows) out_t[(size_t)c * d.ld_out_t + r] = from_f32<T>(tile[tx][cc]);
+    }
+  }
+}
+
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y, float* __restrict__ out, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = a * (x ? x[i] : 0.f) + b * (y ? y[i] : 0.f);
@@ -105,6 +138,16 @@ extern "C" int sm_cast_weight(int dtype, const float* w, int rows, int cols, voi
   else if (dtype == SM_F32)
     hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, st, w, rows, cols, (float*)out, ld_out, (float*)out_t, ld_out_t);
   else SM_REQUIRE(false, "sm_cast_weight: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_cast_weights_multi(int dtype, const sm_cast_desc* descs_dev, int n, int total_tiles, void* stream) {
+  SM_REQUIRE(descs_dev != nullptr && n > 0 && total_tiles > 0, "sm_cast_weights_multi: empty table");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SM_BF16) hipLaunchKernelGGL(cast_weights_multi_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n);
+  else if (dtype == SM_F32) hipLaunchKernelGGL(cast_weights_multi_kernel<float>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n);
+  else SM_REQUIRE(false, "sm_cast_weights_multi: bad dtype %d", dtype);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

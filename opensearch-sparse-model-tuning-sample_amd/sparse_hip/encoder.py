@@ -305,15 +305,20 @@ class HipBertMLM(torch.nn.Module):
                 st[key] = torch.zeros(shape, dtype=dt, device=dev)
             return st[key]
 
-        vpad = (V + 127) // 128 * 128
-        ops.cast_weight(self.view("bert.embeddings.word_embeddings.weight"), buf("E", (vpad, H)), None)
-        for l in range(cfg.num_hidden_layers):
-            p = f"bert.encoder.layer.{l}."
-            ops.cast_weight(self.qkv_weight(l), buf(f"qkv{l}", (3 * H, H)), buf(f"qkvT{l}", (H, 3 * H)))
-            ops.cast_weight(self.view(p + "attention.output.dense.weight"), buf(f"o{l}", (H, H)), buf(f"oT{l}", (H, H)))
-            ops.cast_weight(self.view(p + "intermediate.dense.weight"), buf(f"w1{l}", (I, H)), buf(f"w1T{l}", (H, I)))
-            ops.cast_weight(self.view(p + "output.dense.weight"), buf(f"w2{l}", (H, I)), buf(f"w2T{l}", (I, H)))
-        ops.cast_weight(self.view("cls.predictions.transform.dense.weight"), buf("t", (H, H)), buf("tT", (H, H)))
+        key = (self.flat_param.data_ptr(), len(st))
+        if self._cast_table is None or self._cast_key != key:
+            vpad = (V + 127) // 128 * 128
+            ent = [(self.view("bert.embeddings.word_embeddings.weight"), buf("E", (vpad, H)), None)]
+            for l in range(cfg.num_hidden_layers):
+                p = f"bert.encoder.layer.{l}."
+                ent.append((self.qkv_weight(l), buf(f"qkv{l}", (3 * H, H)), buf(f"qkvT{l}", (H, 3 * H))))
+                ent.append((self.view(p + "attention.output.dense.weight"), buf(f"o{l}", (H, H)), buf(f"oT{l}", (H, H))))
+                ent.append((self.view(p + "intermediate.dense.weight"), buf(f"w1{l}", (I, H)), buf(f"w1T{l}", (H, I))))
+                ent.append((self.view(p + "output.dense.weight"), buf(f"w2{l}", (H, I)), buf(f"w2T{l}", (I, H))))
+            ent.append((self.view("cls.predictions.transform.dense.weight"), buf("t", (H, H)), buf("tT", (H, H))))
+            self._cast_table = ops.CastTable(ent)  # raw pointers: rebuilt if the flat buffer or the staging set changes
+            self._cast_key = (self.flat_param.data_ptr(), len(st))
+        self._cast_table.run()
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
@@ -536,5 +541,7 @@ class _EncodeFn(torch.autograd.Function):
 
 
 HipBertMLM._layer_hook = None
+HipBertMLM._cast_table = None
+HipBertMLM._cast_key = None
 HipBertMLM._wgrad = None
 HipBertMLM._argmax_log = None

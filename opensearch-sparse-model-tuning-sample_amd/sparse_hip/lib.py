@@ -33,6 +33,11 @@ class SmEpilogue(C.Structure):
     ]
 
 
+class SmCastDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("out_t", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
+                ("ld_out", C.c_int), ("ld_out_t", C.c_int), ("tile_begin", C.c_int), ("_pad", C.c_int)]
+
+
 class SmRagged(C.Structure):
     _fields_ = [("doc_off", C.c_void_p), ("blk_doc", C.c_void_p), ("pos_ids", C.c_void_p), ("rows", C.c_int)]
 
@@ -70,6 +75,7 @@ SIGNATURES = {
     "sm_minmax_accumulate": [_p, _i, _i, _f, _p, _i, _p],
     "sm_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
     "sm_cast_weight": [_i, _p, _i, _i, _p, _i, _p, _i, _p],
+    "sm_cast_weights_multi": [_i, _p, _i, _i, _p],
     "sm_axpby": [_f, _p, _f, _p, _p, _l, _p],
     "sm_scale_by": [_p, _p, _f, _l, _p],
 }

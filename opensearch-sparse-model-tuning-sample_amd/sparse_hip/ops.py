@@ -283,6 +283,33 @@ def adamw(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, lr: float, beta1: f
            float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), L.stream_ptr())
 
 
+class CastTable:
+    """Device table for sm_cast_weights_multi: all (fp32 master -> compute-dtype copy [+ transposed copy]) pairs of a
+    model, refreshed by ONE launch.  Built once; the tensors must keep their storage (the table holds raw pointers)."""
+
+    def __init__(self, entries):
+        # entries: [(w fp32 [rows, cols] contiguous, out or None, out_t or None)]
+        import numpy as np
+        self.keep = entries
+        ref = next(t for e in entries for t in e[1:] if t is not None)
+        self.dtype_code = L.dtype_code(ref.dtype)
+        descs = (L.SmCastDesc * len(entries))()
+        tiles = 0
+        for i, (w, out, out_t) in enumerate(entries):
+            rows, cols = w.shape
+            if not w.is_contiguous():
+                raise L.SparseHipError("CastTable: master weights must be contiguous")
+            descs[i] = L.SmCastDesc(L.ptr(w), L.ptr(out), L.ptr(out_t), rows, cols, out.stride(0) if out is not None else 0,
+                                    out_t.stride(0) if out_t is not None else 0, tiles, 0)
+            tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+        self.n, self.tiles = len(entries), tiles
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
+        self.dev = torch.from_numpy(raw).to(ref.device)
+
+    def run(self):
+        L.call("sm_cast_weights_multi", self.dtype_code, L.ptr(self.dev), self.n, self.tiles, L.stream_ptr())
+
+
 def cast_weight(w: Tensor, out: Optional[Tensor], out_t: Optional[Tensor]):
     rows, cols = w.shape
     ref = out if out is not None else out_t
