@@ -232,7 +232,7 @@ def test_attention_dropout_consistent_between_fwd_and_bwd(ops, dtype):
 # ------------------------------------------------------------------ fused sparse head
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,H,V", [(6, 16, 64, 520), (5, 64, 128, 300), (3, 128, 128, 1000), (2, 256, 128, 260), (2, 512, 128, 260),
-                                     (3, 128, 384, 700), (5, 64, 384, 300), (5, 32, 384, 300)])
+                                     (2, 256, 384, 300), (3, 512, 384, 260), (3, 128, 384, 700), (5, 64, 384, 300), (5, 32, 384, 300)])
 @pytest.mark.parametrize("use_l0", [False, True])
 def test_sparse_head_fwd_bwd(ops, dtype, B, S, H, V, use_l0):
     t = q(rnd(B * S, H, seed=1), dtype)
@@ -424,14 +424,14 @@ def _ragged(lens):
 def test_sparse_head_ragged_layout(ops, dtype, H, use_l0):
     """un-padded documents (each a multiple of 16 rows, spanning row tiles arbitrarily): the fused head
     and its backward must equal the per-document dense computation"""
-    lens, off, rows, row_doc, pos, valid = _ragged([37, 128, 16, 90, 5, 64, 100, 128, 77, 3, 250])
+    lens, off, rows, row_doc, pos, valid = _ragged([37, 128, 16, 90, 5, 64, 100, 128, 77, 3, 250, 512, 300])
     B, V = len(lens), 700
-    rag = ops.Ragged(dev(off.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, 256)
+    rag = ops.Ragged(dev(off.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, 512)
     t = q(rnd(rows, H, seed=1), dtype)
     E = q(rnd(V, H, seed=2, scale=0.3 if H < 384 else 0.15), dtype)
     bias = rnd(V, seed=3, scale=0.5)
     mask = torch.from_numpy(valid.astype(np.uint8))
-    rep, am = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask), B, 256, V, use_l0, rag)
+    rep, am = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask), B, 512, V, use_l0, rag)
     tr, Er, br = t.clone().requires_grad_(True), E.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     refs, tops = [], []
     for b in range(B):
@@ -450,7 +450,7 @@ def test_sparse_head_ragged_layout(ops, dtype, H, use_l0):
     up = rnd(B, V, seed=4)
     (ref * up).sum().backward()
     dE, dbias = torch.zeros(V, H, device="cuda"), torch.zeros(V, device="cuda")
-    dt = ops.sparse_head_bwd(dev(up), rep, am, dev(t, dtype), dev(E, dtype), dE, dbias, B, 256, V, use_l0, rag)
+    dt = ops.sparse_head_bwd(dev(up), rep, am, dev(t, dtype), dev(E, dtype), dE, dbias, B, 512, V, use_l0, rag)
     want_dt = tr.grad.clone()
     want_dt[~torch.from_numpy(valid)] = 0
     close(dt, want_dt, tol * 2, "dt")
