@@ -1105,6 +1105,12 @@ __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+__device__ __forceinline__ f32x4 lds_r128f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_w128f(uint32_t addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -1286,6 +1292,167 @@ __global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// C = A . B^T for bf16 at N = 384 and K >= 1024 (FFN2 forward, FFN1 / QKV input gradients): [192 rows x 384 columns]
+// per 8-wave workgroup, one workgroup per CU, ONE round (<= 256 row tiles: the bench's ~44k token rows give 229).
+// Against the 128 x 128 kernel above: 36 KB of LDS-DMA per 4.7 MFLOP K-step instead of 16 KB per 1.05 MFLOP -- the
+// CU's load path (~40 B/clk) is what bounds these GEMMs.  Only for long K: with a single round the load burst at
+// the start and the store burst at the end of all workgroups line up, and at K = 384 (12 K-steps) they cost more
+// than the better tile saves (380 vs 412 TFLOP/s measured); at K = 1536 it is ~925 vs 724.
+// Same 64-byte-row swizzled LDS image and counted-vmcnt ring (4 stages) as nt_mainloop_glds, but fragments are
+// read with inline-asm ds_read_b128 (no compiler-inserted vmcnt(0)) and the operands are swapped (D = B-frag x
+// A-frag) so that a lane owns 4 consecutive columns of a row.  Epilogue: the ring is idle by then; each wave
+// transposes its 96 x 96 block through a private patch, 16 rows at a time, and runs the same fused bias / GELU /
+// dropout / residual / GELU' code on 16-byte row-contiguous vectors.
+// ---------------------------------------------------------------------------------------
+constexpr int NB_R = 192, NB_C = 384, NB_NST = 4, NB_STAGE = (NB_R + NB_C) * 64, NB_PS = 100;  // NB_PS: fp32 row stride of the patch
+constexpr int NB_LDS = NB_NST * NB_STAGE;
+static_assert(8 * 16 * NB_PS * 4 <= NB_LDS, "epilogue patches must fit the idle ring");
+
+__global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+                                                         bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int NBLK = N / NB_C, MT = (M + NB_R - 1) / NB_R, items = MT * NBLK;
+  // XCD-blocked order: the column blocks of a row tile (same A rows) run on one XCD
+  int item;
+  {
+    const int per = (items + 7) >> 3, L = blockIdx.x, j = L >> 3;
+    item = j < per ? (L & 7) * per + j : items;
+  }
+  if (item >= items) return;
+  const int mt = item / NBLK, nb = item - mt * NBLK;
+  const int m0 = mt * NB_R, n0 = nb * NB_C;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3, g = lane >> 4, li = lane & 15;
+  const int nk = K / 32;
+  const uint32_t sbase = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+  // ---- loader: 12 A pieces + 24 B pieces of 1 KiB (16 rows x 64 B) per stage, 5 slots per wave (4 duplicates) ----
+  const bf16* src[5];
+  uint32_t dst[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int piece = min(w + 8 * u, 35);
+    const int prow = (piece < 12 ? piece : piece - 12) * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ ((0 - (prow >> 2)) & 3);
+    src[u] = piece < 12 ? A + (size_t)min(m0 + prow, M - 1) * lda + lchunk * 8 : B + (size_t)(n0 + prow) * ldb + lchunk * 8;
+    dst[u] = piece * 1024;
+  }
+  auto issue = [&](int k) {
+    const int kc = min(k, nk - 1);
+    char* d = smem + (k % NB_NST) * NB_STAGE;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[u] + kc * 32), (lds_void_t*)(d + dst[u]), 16, 0, 0);
+  };
+  uint32_t aaddr[6], baddr[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int ra = wm * 96 + i * 16 + li, rb = wn * 96 + i * 16 + li;
+    aaddr[i] = sbase + ra * 64 + ((g ^ ((0 - (ra >> 2)) & 3)) << 4);
+    baddr[i] = sbase + NB_R * 64 + rb * 64 + ((g ^ ((0 - (rb >> 2)) & 3)) << 4);
+  }
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  issue(1);
+  issue(2);
+  for (int k = 0; k < nk; ++k) {
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // stage k landed: only stages k+1, k+2 (5 loads each) may be in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the slot of stage k+3 held stage k-1, drained by every wave before the barrier.  Waves 0-3 issue their
+    // loads before their MFMAs, waves 4-7 after: the barrier puts all eight in lockstep, and eight waves issuing
+    // LDS-DMA at once and then fighting for the matrix pipe at once serialises the two phases
+    if (w < 4) issue(k + 3);
+    const uint32_t so = (uint32_t)((k % NB_NST) * NB_STAGE);
+    bf16x8 fa[6], fb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa[i] = lds_b128(aaddr[i] + so);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fb[j] = lds_b128(baddr[j] + so);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
+                   "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (w >= 4) issue(k + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the (redundant) tail loads must not land in a patch
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue ----
+  bf16* preact = reinterpret_cast<bf16*>(e.preact);
+  const bf16* residual = reinterpret_cast<const bf16*>(e.residual);
+  const bf16* ggo = reinterpret_cast<const bf16*>(e.gelu_grad_of);
+  // (inline-asm LDS access here too: behind a compiler-visible LDS access the compiler would wait for vmcnt(0),
+  // i.e. for the previous chunk's global stores to be acknowledged)
+  const uint32_t patch = sbase + w * (16 * NB_PS * 4);
+  const int prow = lane >> 2, pc = (lane & 3) * 8;  // patch row / first column (within each 32-column third) of this lane
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) lds_w128f(patch + (li * NB_PS + j * 16 + 4 * g) * 4, acc[i][j]);
+    const int row = m0 + wm * 96 + i * 16 + prow;
+    f32x4 lo[3], hi[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      lo[u] = lds_r128f(patch + (prow * NB_PS + u * 32 + pc) * 4);
+      hi[u] = lds_r128f(patch + (prow * NB_PS + u * 32 + pc + 4) * 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]) : : "memory");
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int cw = u * 32 + pc;  // column within the wave's 96
+      if (row < M) {
+        const int col = n0 + wn * 96 + cw;
+        const size_t off = (size_t)row * ldc + col;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = lo[u][q]; v[4 + q] = hi[u][q]; }
+        if (e.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(e.bias + col), b1 = *reinterpret_cast<const f32x4*>(e.bias + col + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+        }
+        if (preact) store8<bf16>(preact + off, v, true, 8);
+        if (e.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+        }
+        if (e.drop.thresh16) {
+          const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = drop_keep1(e.drop, eb + q) ? v[q] * e.drop.scale : 0.f;
+        }
+        if (residual) {
+          float rv[8];
+          load8<bf16>(residual + off, rv, true, 8);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] += rv[q];
+        }
+        if (ggo) {
+          float xv[8];
+          load8<bf16>(ggo + off, xv, true, 8);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_f(xv[q]);
+        }
+        store8<bf16>(C + off, v, true, 8);
+      }
+    }
+  }
+}
+
 template <typename T>
 int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const sm_epilogue* epi, hipStream_t st) {
@@ -1301,6 +1468,17 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
+  static const int nt192 = getenv("SM_NT192") ? atoi(getenv("SM_NT192")) : 1;
+  if constexpr (sizeof(T) == 2) {
+    static const int nt192_mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
+    if (nt192 && N == NB_C && K >= nt192_mink && sm_cdiv(M, NB_R) <= 256 && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+      const int items = sm_cdiv(M, NB_R) * (N / NB_C);
+      (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
+      hipLaunchKernelGGL(gemm_nt192_kernel, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+                         M, N, K, e);
+      return 0;
+    }
+  }
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   static const int glds_on = getenv("SM_GLDS") ? atoi(getenv("SM_GLDS")) : 1;
   if (glds_on)
