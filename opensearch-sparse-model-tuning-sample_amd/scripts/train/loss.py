@@ -21,32 +21,31 @@ class SparseTrainingLoss:
         return self.weight * self.__call__(q_rep, d_rep, inputs)
 
 
-class KLDivLoss(SparseTrainingLoss):
+class _TeacherScoredLoss(SparseTrainingLoss):
+    """losses against teacher scores in ``inputs["scores"]``: one fused kernel pass per call (kind = kernel name)"""
+    kind = None
+
     def __init__(self, use_in_batch_negatives=False, weight=1, temperature=1.0):
-        self.use_in_batch_negatives = use_in_batch_negatives
-        self.temperature = temperature
         super().__init__(weight)
+        self.use_in_batch_negatives, self.temperature = use_in_batch_negatives, temperature
 
     def __call__(self, q_rep, d_rep, inputs):
-        return F.ranking_loss("kldiv", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature,
+        return F.ranking_loss(self.kind, q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature,
                               q_cap=self.sparse_query_cap)
 
 
-class MarginMSELoss(SparseTrainingLoss):
-    def __init__(self, use_in_batch_negatives=False, weight=1, temperature=1.0):
-        self.use_in_batch_negatives = use_in_batch_negatives
-        self.temperature = temperature
+class KLDivLoss(_TeacherScoredLoss):  # reference loss.py:25-43
+    kind = "kldiv"
+
+
+class MarginMSELoss(_TeacherScoredLoss):  # reference loss.py:57-77
+    kind = "marginmse"
+
+
+class InfoNCELoss(SparseTrainingLoss):  # reference loss.py:86-107; a temperature argument is accepted and ignored there too
+    def __init__(self, weight=1, use_in_batch_negatives=False, **kwargs):
         super().__init__(weight)
-
-    def __call__(self, q_rep, d_rep, inputs):
-        return F.ranking_loss("marginmse", q_rep, d_rep, inputs["scores"], self.use_in_batch_negatives, self.temperature,
-                              q_cap=self.sparse_query_cap)
-
-
-class InfoNCELoss(SparseTrainingLoss):
-    def __init__(self, weight=1, use_in_batch_negatives=False, **kwargs):  # temperature ignored, as in the reference
         self.use_in_batch_negatives = use_in_batch_negatives
-        super().__init__(weight)
 
     def __call__(self, q_rep, d_rep, inputs):
         return F.ranking_loss("infonce", q_rep, d_rep, None, self.use_in_batch_negatives, q_cap=self.sparse_query_cap)

@@ -35,14 +35,6 @@ def get_model(model_args, compute_dtype=None, device=None):
     if model_args.inf_free and model_args.idf_path:
         with open(model_args.idf_path) as f:
             idf = json.load(f)
-    return SparseModel(
-        model_args.model_name_or_path,
-        idf=idf,
-        tokenizer_id=model_args.tokenizer_name,
-        idf_requires_grad=model_args.idf_requires_grad,
-        prune_ratio=model_args.prune_ratio,
-        preprocess_func=model_args.preprocess_func,
-        use_l0=model_args.use_l0,
-        compute_dtype=compute_dtype,
-        device=device,
-    )
+    kw = {name: getattr(model_args, name) for name in ("idf_requires_grad", "prune_ratio", "preprocess_func", "use_l0")}
+    return SparseModel(model_args.model_name_or_path, idf=idf, tokenizer_id=model_args.tokenizer_name,
+                       compute_dtype=compute_dtype, device=device, **kw)
