@@ -82,6 +82,14 @@ typedef struct sm_epilogue {
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                int M, int N, int K, const sm_epilogue* epi, void* stream);
 
+/* Input-gradient GEMM fused with the LayerNorm backward that consumes it (hf:293/351 backward):
+ *   dy = A[M,K] . B[N,K]^T + residual;  dx = LN'(dy | x, gamma, mean, rstd);  dx_drop = dropout_bwd(dx) (optional);
+ *   dgamma / dbeta atomically accumulated.  All [M,N] operands contiguous (ld = N).  Returns 0 when the fused
+ * kernel ran, 1 when the shape is not eligible (run sm_gemm_nt + sm_layernorm_bwd instead), < 0 on error. */
+int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                      const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, void* stream);
+
 /* Weight gradient: C[N,Kc] += A[M,N]^T . B[M,Kc]  (fp32, atomically accumulated), and
  * optionally colsum[N] += sum_m A[m,:] (the bias gradient).  Backward of every nn.Linear. */
 int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,

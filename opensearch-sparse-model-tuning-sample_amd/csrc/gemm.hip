@@ -1118,6 +1118,12 @@ __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
 }
 __device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
+__device__ __forceinline__ bf16x4 pack4(f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (bf16)v[k];
+  return o;
+}
 union TgFrag { struct { s16x4 lo, hi; } s; bf16x8 v; };
 // Producer / consumer structure: 8 waves -- waves 4..7 only issue the LDS-DMA loads (an LDS-DMA instruction
 // holds its wave's issue slot for 60-180 cycles, which waves that also issue MFMAs lose per stage),
@@ -1309,8 +1315,25 @@ constexpr int NB_R = 192, NB_C = 384, NB_NST = 4, NB_STAGE = (NB_R + NB_C) * 64,
 constexpr int NB_LDS = NB_NST * NB_STAGE;
 static_assert(8 * 16 * NB_PS * 4 <= NB_LDS, "epilogue patches must fit the idle ring");
 
+// LNB = true: the epilogue is the LayerNorm BACKWARD of dy = A.B^T + residual (the tile holds whole rows, N = 384 =
+// hidden size): C receives dx = LN'(dy), ln.dx_drop its dropout-masked copy, ln.dgamma / ln.dbeta the parameter
+// gradients -- the [T, H] tensor dy never goes to HBM and the separate LN-backward launch (2 reads + 2 writes of
+// [T, H]) disappears.  Row sums cross the 4 column-waves of a row through LDS: pass 1 accumulates them (and the
+// gamma / beta column sums), one barrier, pass 2 replays the transposition and writes dx.
+struct LnBwdArgs {
+  const bf16* x;        // LayerNorm input (pre-normalisation), [M, N]
+  const float* gamma;
+  const float* mean;
+  const float* rstd;
+  bf16* dx_drop;        // may be null
+  float* dgamma;
+  float* dbeta;
+  DropCfg drop;
+};
+
+template <bool LNB>
 __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
-                                                         bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
+                                                         bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, LnBwdArgs ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
   const int NBLK = N / NB_C, MT = (M + NB_R - 1) / NB_R, items = MT * NBLK;
@@ -1399,6 +1422,122 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   // i.e. for the previous chunk's global stores to be acknowledged)
   const uint32_t patch = sbase + w * (16 * NB_PS * 4);
   const int prow = lane >> 2, pc = (lane & 3) * 8;  // patch row / first column (within each 32-column third) of this lane
+  if constexpr (LNB) {
+    // (1) accumulators -> bf16 image dy'[192][384] in the idle ring (exactly NB_LDS bytes); 16-byte chunks are
+    //     XOR-swizzled with (row & 7) so that the 16 rows a store instruction covers spread over the banks
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int trow = wm * 96 + i * 16 + li;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int chunk = wn * 12 + j * 2 + (g >> 1);
+        union { bf16x4 v; unsigned long long u; } pk;
+        pk.v = pack4(acc[i][j]);
+        asm volatile("ds_write_b64 %0, %1" ::"v"(sbase + trow * 768 + ((chunk ^ (trow & 7)) << 4) + (g & 1) * 8), "v"(pk.u) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (2) LayerNorm backward, a row per 16 lanes (24 columns per lane), 4 rows of the wave's 24 at a time
+    const int sl = lane & 15, sub = lane >> 4;
+    float dg[3][8], db[3][8], gm[3][8];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      *reinterpret_cast<f32x4*>(gm[u]) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8);
+      *reinterpret_cast<f32x4*>(gm[u] + 4) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8 + 4);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { dg[u][q] = 0.f; db[u][q] = 0.f; }
+    }
+    const float invn = 1.f / (float)N;
+    // unrolled by two: two iterations' global loads in flight (a rolled loop pays the full load latency six times,
+    // a fully unrolled one spills)
+#pragma unroll 2
+    for (int it = 0; it < 6; ++it) {
+      const int trow = w * 24 + it * 4 + sub, row = m0 + trow;
+      const bool live = row < M;
+      bf16x8 raw[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) raw[u] = lds_b128(sbase + trow * 768 + (((sl + 16 * u) ^ (trow & 7)) << 4));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
+      const float mu = live ? ln.mean[row] : 0.f, rs = live ? ln.rstd[row] : 0.f;
+      float dy[3][8], xn[3][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const size_t off = (size_t)row * ldc + (sl + 16 * u) * 8;
+        float rv[8], xv[8];
+        if (live) {
+          if (residual) {
+            load8<bf16>(residual + off, rv, true, 8);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = 0.f;
+          }
+          load8<bf16>(ln.x + off, xv, true, 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          dy[u][q] = live ? (float)(bf16)((float)raw[u][q] + rv[q]) : 0.f;
+          xn[u][q] = live ? (xv[q] - mu) * rs : 0.f;
+          const float dyg = dy[u][q] * gm[u][q];
+          s1 += dyg;
+          s2 += dyg * xn[u][q];
+          dg[u][q] += dy[u][q] * xn[u][q];
+          db[u][q] += dy[u][q];
+        }
+      }
+#pragma unroll
+      for (int sft = 1; sft < 16; sft <<= 1) { s1 += __shfl_xor(s1, sft, 64); s2 += __shfl_xor(s2, sft, 64); }
+      const float c1 = s1 * invn, c2 = s2 * invn;
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int col = (sl + 16 * u) * 8;
+          const size_t off = (size_t)row * ldc + col;
+          float gx[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) gx[q] = rs * (dy[u][q] * gm[u][q] - c1 - xn[u][q] * c2);
+          store8<bf16>(C + off, gx, true, 8);
+          if (ln.dx_drop) {
+            if (ln.drop.thresh16) {
+              const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) gx[q] = drop_keep1(ln.drop, eb + q) ? gx[q] * ln.drop.scale : 0.f;
+            }
+            store8<bf16>(ln.dx_drop + off, gx, true, 8);
+          }
+        }
+      }
+    }
+    // (3) gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, then ONE global
+    //     atomic per column and workgroup (768 hot addresses shared by every workgroup: per-wave atomics cost 4 ms)
+    const uint32_t colsum = sbase + NB_LDS;  // [2][384] fp32 behind the dy image
+    for (int c = tid; c < 2 * NB_C; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float a = dg[u][q], b = db[u][q];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (sub == 0) {
+          const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
+          asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(a) : "memory");
+          asm volatile("ds_add_f32 %0, %1" ::"v"(ca + NB_C * 4), "v"(b) : "memory");
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = tid; c < 2 * NB_C; c += 512) {
+      float v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
+      atomicAdd(c < NB_C ? ln.dgamma + c : ln.dbeta + (c - NB_C), v);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -1473,9 +1612,9 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     static const int nt192_mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
     if (nt192 && N == NB_C && K >= nt192_mink && sm_cdiv(M, NB_R) <= 256 && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
-      (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
-      hipLaunchKernelGGL(gemm_nt192_kernel, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
-                         M, N, K, e);
+      (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
+      hipLaunchKernelGGL(gemm_nt192_kernel<false>, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+                         M, N, K, e, LnBwdArgs{});
       return 0;
     }
   }
@@ -1542,6 +1681,40 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
   if (dtype == SM_BF16) launch_gemm_nt<bf16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
   else if (dtype == SM_F32) launch_gemm_nt<float>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
   else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+// dx = LayerNorm'(A.B^T + residual) in one launch (see gemm_nt192_kernel<true>).  Returns SM_OK when the fused kernel
+// ran, 1 when the shape is not eligible (the caller then runs sm_gemm_nt + sm_layernorm_bwd), < 0 on error.
+extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                                 const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, void* stream) {
+  static const int fuse = getenv("SM_LN_FUSE") ? atoi(getenv("SM_LN_FUSE")) : 1;
+  static const int mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
+  if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 256) return 1;
+  const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)residual | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_drop |
+                       (uintptr_t)gamma;
+  if ((al % 16) != 0 || (lda % 8) != 0 || (ldb % 8) != 0) return 1;
+  SM_REQUIRE(x && gamma && mean && rstd && dx && dgamma && dbeta, "sm_gemm_nt_ln_bwd: null argument");
+  EpiArgs e{};
+  e.residual = residual;
+  e.vec_ok = 1;
+  LnBwdArgs ln;
+  ln.x = (const bf16*)x;
+  ln.gamma = gamma;
+  ln.mean = mean;
+  ln.rstd = rstd;
+  ln.dx_drop = (bf16*)dx_drop;
+  ln.dgamma = dgamma;
+  ln.dbeta = dbeta;
+  ln.drop = make_drop(drop);
+  hipStream_t st = (hipStream_t)stream;
+  const int items = sm_cdiv(M, NB_R);
+  constexpr int LNB_LDS = NB_LDS + 2 * NB_C * 4;  // + the [2][384] column-sum patch
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_LDS));
+  hipLaunchKernelGGL(gemm_nt192_kernel<true>, dim3((items + 7) / 8 * 8), dim3(512), LNB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb,
+                     (bf16*)dx, N, M, N, K, e, ln);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

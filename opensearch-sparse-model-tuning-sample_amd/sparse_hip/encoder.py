@@ -501,29 +501,50 @@ class _EncodeFn(torch.autograd.Function):
         dx = ops.gemm_nt(dft, st["tT"])
         if model._layer_hook is not None:
             model._layer_hook("head", wg.mark())
+        pending = None  # (dz2, dz2d) of the layer about to run, when the previous GEMM already produced them (fused)
         for l in reversed(range(cfg.num_hidden_layers)):
             p = f"bert.encoder.layer.{l}."
             x, qkv, ctxt, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2 = ctx.saved["layers"][l]
             d_at = model._drop(pa, training, seed, l + 1, _Site.ATTN)
             d_h1 = model._drop(ph, training, seed, l + 1, _Site.HID1)
             d_h2 = model._drop(ph, training, seed, l + 1, _Site.HID2)
-            dz2, dz2d = ops.layernorm_bwd(dx, z2, v(p + "output.LayerNorm.weight"), m2, r2,
-                                          g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"),
-                                          d_h2, want_drop=d_h2 is not None)
+            if pending is not None:
+                dz2, dz2d = pending
+                pending = None
+            else:
+                dz2, dz2d = ops.layernorm_bwd(dx, z2, v(p + "output.LayerNorm.weight"), m2, r2,
+                                              g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"),
+                                              d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
             wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
             df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
             wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
-            dx1 = ops.gemm_nt(df1, st[f"w1T{l}"], residual=dz2)
-            dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
-                                          g(p + "attention.output.LayerNorm.weight"),
-                                          g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
+            # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
+            # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
+            fused = ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                       g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
+                                       d_h1, want_drop=d_h1 is not None)
+            if fused is not None:
+                dz1, dz1d = fused
+            else:
+                dx1 = ops.gemm_nt(df1, st[f"w1T{l}"], residual=dz2)
+                dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                              g(p + "attention.output.LayerNorm.weight"),
+                                              g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
             a1 = dz1d if d_h1 is not None else dz1
             wg.run(a1, ctxt, g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias"))
             dctx = ops.gemm_nt(a1, st[f"oT{l}"])
             dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at, rag)
             wg.run(dqkv, x, model.qkv_weight(l, grad=True), model.qkv_bias(l, grad=True))
-            dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
+            if l > 0:  # the QKV input gradient feeds the output LayerNorm of layer l-1: same fusion
+                pp = f"bert.encoder.layer.{l - 1}."
+                z2p, m2p, r2p = ctx.saved["layers"][l - 1][10:13]
+                d_h2p = model._drop(ph, training, seed, l, _Site.HID2)
+                pending = ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z2p, v(pp + "output.LayerNorm.weight"), m2p, r2p,
+                                             g(pp + "output.LayerNorm.weight"), g(pp + "output.LayerNorm.bias"),
+                                             d_h2p, want_drop=d_h2p is not None)
+            if pending is None:
+                dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
             if model._layer_hook is not None:
                 model._layer_hook(l, wg.mark())
         z0, m0, r0 = ctx.saved["emb"]

@@ -48,6 +48,7 @@ _rag = C.POINTER(SmRagged)
 # name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
 SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
+    "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
@@ -144,3 +145,12 @@ def call(name: str, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise SparseHipError(f"{name} failed (rc={rc}): {lib.sm_last_error().decode()}")
+
+
+def call_optional(name: str, *args) -> bool:
+    """entry points that may decline a shape (return 1): True = done, False = use the unfused ops; errors raise"""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc < 0:
+        raise SparseHipError(f"{name} failed (rc={rc}): {lib.sm_last_error().decode()}")
+    return rc == 0

@@ -53,6 +53,22 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
     return out
 
 
+def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
+                   dgamma: Tensor, dbeta: Tensor, drop: Optional[L.SmDropout] = None, want_drop: bool = False):
+    """(dx, dx_drop) = LayerNorm'(A @ B^T + residual) in one launch, or None when the fused kernel does not take the shape
+    (then: gemm_nt(..., residual=) followed by layernorm_bwd)."""
+    M, K = A.shape
+    N = B.shape[0]
+    if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)):
+        return None
+    dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if want_drop else None
+    ok = L.call_optional("sm_gemm_nt_ln_bwd", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
+                         L.ptr(residual), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), _drop_ref(drop), L.ptr(dx),
+                         L.ptr(dx_drop), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+    return (dx, dx_drop) if ok else None
+
+
 def gemm_tn_acc(A: Tensor, B: Tensor, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
     """out[N,Kc] += A[M,N]^T @ B[M,Kc] (fp32 accumulate); colsum[N] += A.sum(0)."""
     M, N = A.shape

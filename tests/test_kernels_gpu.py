@@ -112,6 +112,44 @@ def test_gemm_nt_dropout_mask_is_the_one_the_backward_kernels_regenerate(ops, dt
         assert abs((mask != 0).float().mean().item() - 0.9) < 0.01
 
 
+def test_gemm_nt_fused_with_layernorm_backward_matches_the_two_separate_kernels(ops):
+    """input-gradient GEMM + residual + LayerNorm backward in one launch (N = hidden = 384, K >= 1024) against
+    gemm_nt followed by layernorm_bwd, and against torch autograd in fp32"""
+    from sparse_hip import lib
+    dtype = torch.bfloat16
+    for M, K in ((6200, 1024), (6151, 1536)):
+        N = 384
+        A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.05), dtype)
+        res, x = q(rnd(M, N, seed=3), dtype), q(rnd(M, N, seed=4, scale=2.0), dtype)
+        gamma = 1.0 + 0.1 * rnd(N, seed=5)
+        beta = 0.1 * rnd(N, seed=6)
+        _, mean, rstd = ops.layernorm_fwd(dev(x, dtype), dev(gamma), dev(beta), 1e-12)
+        drop = lib.dropout(0.1, 11, 5)
+        dg0, db0 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        dy = ops.gemm_nt(dev(A, dtype), dev(B, dtype), residual=dev(res, dtype))
+        dx0, dxd0 = ops.layernorm_bwd(dy, dev(x, dtype), dev(gamma), mean, rstd, dg0, db0, drop, want_drop=True)
+        dg1, db1 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        out = ops.gemm_nt_ln_bwd(dev(A, dtype), dev(B, dtype), dev(res, dtype), dev(x, dtype), dev(gamma), mean, rstd, dg1, db1,
+                                 drop, want_drop=True)
+        assert out is not None, "the fused kernel must take this shape"
+        dx1, dxd1 = out
+        fro = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+        assert fro(dx1, dx0) <= 1e-2 and fro(dxd1, dxd0) <= 1e-2, (fro(dx1, dx0), fro(dxd1, dxd0))
+        assert torch.equal(dxd1 != 0, (dx1 != 0) & (dxd0 != 0) | ((dxd1 != 0) & (dx0 == 0)))  # same dropout mask
+        assert fro(dg1, dg0) <= 1e-2 and fro(db1, db0) <= 1e-2
+        # fp32 autograd reference of LN' applied to the exact dy
+        dyr = (A @ B.t() + res)
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr, (N,), gamma, beta, 1e-12).backward(dyr)
+        assert fro(dx1.cpu(), xr.grad) <= 2e-2
+    # shapes the fused kernel does not take are declined, not mis-computed
+    A, B = dev(q(rnd(500, 1024, seed=1), dtype), dtype), dev(q(rnd(384, 1024, seed=2), dtype), dtype)
+    xs = dev(q(rnd(500, 384, seed=3), dtype), dtype)
+    _, mean, rstd = ops.layernorm_fwd(xs, dev(torch.ones(384)), dev(torch.zeros(384)), 1e-12)
+    z = torch.zeros(384, device="cuda")
+    assert ops.gemm_nt_ln_bwd(A, B, xs, xs, dev(torch.ones(384)), mean, rstd, z, z.clone()) is None
+
+
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,Kc", [(300, 72, 136), (1024, 128, 128), (96, 192, 64), (2000, 64, 520 - 520 % 8),
