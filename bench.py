@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--negs", type=int, default=15)
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the post-run per-GEMM timing steps")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     ap.add_argument("--no-dropout", action="store_true")
@@ -107,6 +108,48 @@ class KernelTimer:
 
     def mean_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+
+
+class GemmRoofline:
+    """After the timed region: a few extra steps with HIP events around every encoder GEMM launch (events on the stream
+    the kernel runs on; the weight-gradient GEMMs run on the side stream and share the GPU with the backward chain,
+    exactly as in the measured step).  Reported per op: launches / step, executed FLOPs, achieved TFLOP/s in the step."""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.orig = ops, {}, {}
+
+    def _wrap(self, name, flops):
+        orig = getattr(self.ops, name)
+        self.orig[name] = orig
+
+        def wrapped(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **kw)
+            e1.record()
+            self.rec.setdefault(name, []).append((e0, e1, flops(*a, **kw)))
+            return out
+        setattr(self.ops, name, wrapped)
+
+    def __enter__(self):
+        self._wrap("gemm_nt", lambda A, B, *a, n=None, **k: 2.0 * A.shape[0] * A.shape[1] * (B.shape[0] if n is None else n))
+        self._wrap("gemm_nt_ln_bwd", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
+        self._wrap("gemm_tn_acc", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.ops, n, f)
+
+    def summary(self, steps, peak):
+        out = []
+        for name, rec in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+            fl = sum(f for _, _, f in rec)
+            if ms > 0:
+                out.append({"op": name, "launches_per_step": len(rec) / steps, "gflop_per_step": fl / steps / 1e9,
+                            "ms_per_step": ms / steps, "achieved_tflops": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / peak})
+        return out
 
 
 def usable_cores() -> int:
@@ -212,6 +255,14 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         head_ms = kt.mean_ms()
+    gemm_lines = None
+    if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
+        with GemmRoofline(ops) as gr:
+            for i in range(3):
+                trainer.training_step(batches[i % len(batches)])
+            torch.cuda.synchronize()
+        gemm_lines = gr.summary(3, MFMA_PEAK[args.dtype])
+    barrier()
     tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -255,6 +306,8 @@ def main():
                      "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
                      "kernel_ms": head_ms, "rows_per_launch": T},
     }
+    if gemm_lines is not None:
+        result["roofline_encoder_gemms"] = gemm_lines
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
