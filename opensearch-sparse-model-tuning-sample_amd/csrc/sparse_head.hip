@@ -246,31 +246,52 @@ __global__ __launch_bounds__(256) void scores_pairs_bwd_kernel(const float* __re
 }
 
 // ---- sparse-query score matrices (inference-free queries: <= cap non-zeros per row) -------
-// row compaction: q[nq,V] dense -> (cols, vals)[nq,cap], nnz[nq]; one block per row, ballot-prefix
-__global__ __launch_bounds__(256) void row_compact_kernel(const float* __restrict__ q, int V, int cap, int* __restrict__ cols,
-                                                          float* __restrict__ vals, int* __restrict__ nnz, int* __restrict__ overflow) {
-  __shared__ int wcount[4];
-  __shared__ int base;
+// row compaction: q[nq,V] dense -> (cols, vals)[nq,cap], nnz[nq] in increasing column order; one block per row.
+// Each of the block's 16 waves owns a contiguous sixteenth of the row: pass 1 counts its non-zeros (ballot popcounts, four loads in
+// flight), one barrier turns the sixteen counts into offsets, pass 2 writes -- no barrier inside the column loops
+// (the one-barrier-pair-per-256-columns version took 72 us for 32 rows).
+__global__ __launch_bounds__(1024) void row_compact_kernel(const float* __restrict__ q, int V, int cap, int* __restrict__ cols,
+                                                           float* __restrict__ vals, int* __restrict__ nnz, int* __restrict__ overflow) {
+  __shared__ int wcount[16];
   const int row = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base = 0;
+  const float* r = q + (size_t)row * V;
+  const int per = ((V + 15) / 16 + 63) / 64 * 64;  // columns per wave, a multiple of 64
+  const int c0 = w * per, c1 = min(V, c0 + per);
+  int cnt = 0;
+  for (int v0 = c0; v0 < c1; v0 += 256) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + u * 64 + lane;
+      x[u] = v < c1 ? r[v] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(x[u] != 0.f));
+  }
+  if (lane == 0) wcount[w] = cnt;
   __syncthreads();
-  for (int v0 = 0; v0 < V; v0 += 256) {
-    const int v = v0 + threadIdx.x;
-    const float x = v < V ? q[(size_t)row * V + v] : 0.f;
-    const unsigned long long m = __ballot(x != 0.f);
-    if (lane == 0) wcount[w] = __popcll(m);
-    __syncthreads();
-    int off = base;
-    for (int k = 0; k < w; ++k) off += wcount[k];
-    off += __popcll(m & ((1ull << lane) - 1ull));
-    if (x != 0.f && off < cap) { cols[(size_t)row * cap + off] = v; vals[(size_t)row * cap + off] = x; }
-    __syncthreads();
-    if (threadIdx.x == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    __syncthreads();
+  int off = 0;
+  for (int k = 0; k < w; ++k) off += wcount[k];
+  for (int v0 = c0; v0 < c1; v0 += 256) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + u * 64 + lane;
+      x[u] = v < c1 ? r[v] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long m = __ballot(x[u] != 0.f);
+      const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+      if (x[u] != 0.f && o < cap) { cols[(size_t)row * cap + o] = v0 + u * 64 + lane; vals[(size_t)row * cap + o] = x[u]; }
+      off += __popcll(m);
+    }
   }
   if (threadIdx.x == 0) {
-    nnz[row] = base < cap ? base : cap;
-    if (base > cap) atomicAdd(overflow, 1);
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wcount[k];
+    nnz[row] = total < cap ? total : cap;
+    if (total > cap) atomicAdd(overflow, 1);
   }
 }
 // scores[i,j] = sum_t vals[i,t] d[j, cols[i,t]]; block per document row j, waves over queries
@@ -604,7 +625,7 @@ extern "C" int sm_minmax_accumulate(const float* scores, int nq, int ncols, floa
 
 extern "C" int sm_row_compact(const float* q, int nq, int V, int cap, int* cols, float* vals, int* nnz, int* overflow, void* stream) {
   SM_REQUIRE(nq > 0 && V > 0 && cap > 0, "sm_row_compact: empty problem");
-  hipLaunchKernelGGL(row_compact_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, q, V, cap, cols, vals, nnz, overflow);
+  hipLaunchKernelGGL(row_compact_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, q, V, cap, cols, vals, nnz, overflow);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
