@@ -1978,13 +1978,20 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
       fb[j].s.lo = lds_tr16(eaddr[j][0] + so);
       fb[j].s.hi = lds_tr16(eaddr[j][1] + so);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
+    // first half of the MFMAs as soon as fa and fb[0..2] are here; the reads of fb[3..5] land underneath them
+    asm volatile("s_waitcnt lgkmcnt(6)"
                  : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0].v), "+v"(fb[1].v),
-                   "+v"(fb[2].v), "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v)
+                   "+v"(fb[2].v)
                  :
                  : "memory");
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v) : : "memory");
+#pragma unroll
+    for (int j = 3; j < 6; ++j)
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -2165,13 +2172,19 @@ __global__ __launch_bounds__(512) void head_de128_kernel(const float* __restrict
       fb[j].s.lo = lds_tr16(eaddr[j][0] + so);
       fb[j].s.hi = lds_tr16(eaddr[j][1] + so);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0].v), "+v"(fb[1].v), "+v"(fb[2].v), "+v"(fb[3].v),
-                   "+v"(fb[4].v), "+v"(fb[5].v)
+    // first half of the MFMAs as soon as fa and fb[0..2] are here; the reads of fb[3..5] land underneath them
+    asm volatile("s_waitcnt lgkmcnt(6)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0].v), "+v"(fb[1].v), "+v"(fb[2].v)
                  :
                  : "memory");
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v) : : "memory");
+#pragma unroll
+    for (int j = 3; j < 6; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);

@@ -1,6 +1,9 @@
 """Stand-alone timing of the fused head's backward (dt and dE kernels) at the bench's ragged shapes."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "opensearch-sparse-model-tuning-sample_amd"))
+from sparse_hip import lib as _L
+if os.environ.get("SM_LIB"):  # A/B two builds in one run
+    _L._LIB_PATH = os.environ["SM_LIB"]
 from sparse_hip import ops
 rng = np.random.default_rng(0)
 B, H, V = 512, 384, 30522
