@@ -1610,7 +1610,10 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   static const int nt192 = getenv("SM_NT192") ? atoi(getenv("SM_NT192")) : 1;
   if constexpr (sizeof(T) == 2) {
     static const int nt192_mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
-    if (nt192 && N == NB_C && K >= nt192_mink && sm_cdiv(M, NB_R) <= 256 && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+    static const int nt192_multi = getenv("SM_NT192_MULTI") ? atoi(getenv("SM_NT192_MULTI")) : 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
+    const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
+    const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
+    if (nt192 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
       (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
       hipLaunchKernelGGL(gemm_nt192_kernel<false>, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,

@@ -61,7 +61,9 @@ def close(got, want, tol, what=""):
                                    (8200, 384, 384), (8197, 256, 128), (4100, 256, 1536), (6200, 768, 64), (6151, 1152, 384),
                                    (33017, 384, 128),
                                    # N = 384, K >= 1024, one round of 192-row tiles: bf16 takes gemm_nt192_kernel
-                                   (6200, 384, 1024), (6151, 384, 1152)])
+                                   (6200, 384, 1024), (6151, 384, 1152),
+                                   # two column blocks, >= 512 tiles: the same kernel over several rounds (bert-base shapes)
+                                   (49200, 768, 1024)])
 def test_gemm_nt_plain_and_epilogues(ops, dtype, M, N, K):
     A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.5), dtype)
     bias = rnd(N, seed=3)
