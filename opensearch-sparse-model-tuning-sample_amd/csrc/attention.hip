@@ -30,16 +30,24 @@ template <> struct AT<float> {
   }
 };
 
-// fragment (contraction over the head dim) of row `row` of a row-major [rows][DH] LDS image
-template <typename T>
-__device__ __forceinline__ typename AT<T>::Frag row_frag(const char* base, int rs, int row, int ks, int g);
-template <>
-__device__ __forceinline__ bf16x8 row_frag<bf16>(const char* base, int rs, int row, int ks, int g) {
-  return *reinterpret_cast<const bf16x8*>(base + row * rs + (ks * 32 + 8 * g) * 2);
+// Byte offset of (row, byte column) in a row-major LDS image.  SWZ (bf16 images whose rows are exactly 128 B: head dim
+// 64, or two heads of 32 side by side): no padding, the 16-byte chunk index is XORed with (row & 7) -- conflict-free for
+// the ds_read_b128 fragment reads (16 rows at chunks c / c+1) AND for the transposing reads (8 rows x 32 B per half
+// wave); the padded layout used before left 34-39 % of the attention kernels' LDS cycles in bank conflicts
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Otherwise rows are padded by 16 B.
+template <bool SWZ>
+__device__ __forceinline__ int img_off(int row, int rs, int bytecol) {
+  return SWZ ? row * 128 + ((((bytecol >> 4) ^ (row & 7)) << 4) | (bytecol & 15)) : row * rs + bytecol;
 }
-template <>
-__device__ __forceinline__ float row_frag<float>(const char* base, int rs, int row, int ks, int g) {
-  return *reinterpret_cast<const float*>(base + row * rs + (ks * 4 + g) * 4);
+
+// fragment (contraction over the head dim) of row `row` of a row-major [rows][DH] LDS image
+template <typename T, bool SWZ>
+__device__ __forceinline__ typename AT<T>::Frag row_frag(const char* base, int rs, int cof, int row, int ks, int g) {
+  if constexpr (sizeof(T) == 2) {
+    return *reinterpret_cast<const bf16x8*>(base + img_off<SWZ>(row, rs, cof + (ks * 32 + 8 * g) * 2));
+  } else {
+    return *reinterpret_cast<const float*>(base + img_off<false>(row, rs, cof + (ks * 4 + g) * 4));
+  }
 }
 // same, straight from global memory (row-major, `ld` elements)
 template <typename T>
@@ -54,12 +62,12 @@ __device__ __forceinline__ float grow_frag<float>(const float* base, size_t ld, 
 }
 
 // acc (16 x 16) = sum over the head dim of A-rows (LDS row-major) x B frags
-template <typename T, int DH>
-__device__ __forceinline__ f32x4 dh_product(const char* abase, int rs, int arow, int g,
+template <typename T, int DH, bool SWZ>
+__device__ __forceinline__ f32x4 dh_product(const char* abase, int rs, int cof, int arow, int g,
                                             const typename AT<T>::Frag (&fb)[DH / AT<T>::KSTEP]) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < DH / AT<T>::KSTEP; ++ks) acc = AT<T>::mma(row_frag<T>(abase, rs, arow, ks, g), fb[ks], acc);
+  for (int ks = 0; ks < DH / AT<T>::KSTEP; ++ks) acc = AT<T>::mma(row_frag<T, SWZ>(abase, rs, cof, arow, ks, g), fb[ks], acc);
   return acc;
 }
 
@@ -85,19 +93,20 @@ template <> struct PT<float> {
 
 // acc (16 x 16) = sum over the sequence dim: A = rows of a transposed [DH][S] LDS image,
 // B = accumulator-layout tiles p[0..nt) (rows = sequence index, col = lane & 15).
-template <typename T, int NT> struct SeqProd;
-template <int NT> struct SeqProd<bf16, NT> {
+template <typename T, int NT, bool SWZ> struct SeqProd;
+template <int NT, bool SWZ> struct SeqProd<bf16, NT, SWZ> {
   // A operand = X^T (rows = head-dim index trow0 .. trow0+15, k = sequence index) read straight from the
   // ROW-MAJOR image X[seq][dh] with the transposing LDS read: for the 16-lane group g the block rows are
   // the 4 sequence rows R0 .. R0+3 and the block columns the 16 head-dim columns trow0 .. trow0+15; lane
   // (q = li >> 2, p = li & 3) supplies the address of row R0 + q, columns 4p .. 4p+3 and receives column
   // li of the 4 rows.  Two reads (sequence tiles 2t and 2t+1) fill the 8 k-slots in the same permuted
   // order in which the accumulator tiles p[2t], p[2t+1] provide the B operand.
-  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const bf16x4 (&p)[NT], int nt) {
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int cof, int trow0, int g, int li, const bf16x4 (&p)[NT], int nt) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int q = li >> 2, pp = li & 3;
-    const char* lane_base = rowbase + (4 * g + q) * rs + (trow0 + 4 * pp) * 2;
+    // (rows t*16 + 4g + q: the swizzle term (row & 7) does not depend on the tile t)
+    const char* lane_base = rowbase + img_off<SWZ>(4 * g + q, rs, cof + (trow0 + 4 * pp) * 2);
 #pragma unroll
     for (int t2 = 0; t2 < NT / 2; ++t2) {
       if (2 * t2 < nt) {
@@ -115,11 +124,12 @@ template <int NT> struct SeqProd<bf16, NT> {
     return acc;
   }
 };
-template <int NT> struct SeqProd<float, NT> {
+template <int NT, bool SWZ> struct SeqProd<float, NT, SWZ> {
   // fp32 parity mode keeps no transposed LDS images (they would not fit for head dim 64): the A operand
   // element (row = trow of the transposed view, k = sequence index) is read from the row-major image
-  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int trow0, int g, int li, const f32x4 (&p)[NT], int nt) {
+  __device__ static __forceinline__ f32x4 run(const char* rowbase, int rs, int cof, int trow0, int g, int li, const f32x4 (&p)[NT], int nt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    rowbase += cof;
     const int trow = trow0 + li;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -137,12 +147,12 @@ template <int NT> struct SeqProd<float, NT> {
 
 // One pair of sequence tiles (2*t2, 2*t2+1) of the same product, accumulated into `acc`: lets the backward
 // walk the sequence two tiles at a time with only those two probability tiles live in registers.
-template <typename T> struct SeqPair;
-template <> struct SeqPair<bf16> {
-  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int trow0, int g, int li, bf16x4 p0, bf16x4 p1, int t2) {
+template <typename T, bool SWZ> struct SeqPair;
+template <bool SWZ> struct SeqPair<bf16, SWZ> {
+  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int cof, int trow0, int g, int li, bf16x4 p0, bf16x4 p1, int t2) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     const int q = li >> 2, pp = li & 3;
-    const char* lane_base = rowbase + (4 * g + q) * rs + (trow0 + 4 * pp) * 2 + (2 * t2) * 16 * rs;
+    const char* lane_base = rowbase + img_off<SWZ>(4 * g + q, rs, cof + (trow0 + 4 * pp) * 2) + (2 * t2) * 16 * rs;
     union { struct { s16x4 a, b; } s; bf16x8 v; } fa;
     fa.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base));
     fa.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(lane_base + 16 * rs));
@@ -152,8 +162,9 @@ template <> struct SeqPair<bf16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, acc, 0, 0, 0);
   }
 };
-template <> struct SeqPair<float> {
-  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int trow0, int g, int li, f32x4 p0, f32x4 p1, int t2) {
+template <bool SWZ> struct SeqPair<float, SWZ> {
+  __device__ static __forceinline__ f32x4 acc(f32x4 acc, const char* rowbase, int rs, int cof, int trow0, int g, int li, f32x4 p0, f32x4 p1, int t2) {
+    rowbase += cof;
     const int trow = trow0 + li;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -170,7 +181,7 @@ template <> struct SeqPair<float> {
 
 // cooperative staging of a [S][DH] slice (row stride `ld` elements in global) into LDS:
 // row-major image (stride rs bytes) and / or transposed image [DH][S] (stride rst bytes)
-template <typename T, int DH>
+template <typename T, int DH, bool SWZ = false>
 __device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int nvalid, int ntotal, char* rowimg, int rs, char* timg, int rst) {
   // rows [0, nvalid) come from global memory, rows [nvalid, ntotal) are zero-filled (a ragged
   // document shorter than the LDS image must not expose its neighbour's rows or stale NaNs)
@@ -179,7 +190,7 @@ __device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int 
   for (int idx = threadIdx.x; idx < ntotal * CPR; idx += blockDim.x) {
     const int r = idx / CPR, c = idx % CPR;
     const uint4 v = r < nvalid ? *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * EPC) : make_uint4(0, 0, 0, 0);
-    if (rowimg) *reinterpret_cast<uint4*>(rowimg + r * rs + c * 16) = v;
+    if (rowimg) *reinterpret_cast<uint4*>(rowimg + img_off<SWZ>(r, rs, c * 16)) = v;
     if (timg) {
       const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
@@ -198,8 +209,9 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
 }
 
 template <typename T, int DH>
-struct Lay {  // LDS strides (bytes); +16 keeps 16-byte alignment and rotates banks per row
-  static constexpr int RS = DH * (int)sizeof(T) + 16;
+struct Lay {  // LDS row stride (bytes): 128-byte bf16 rows are XOR-swizzled (img_off), everything else is padded by 16 B
+  static constexpr bool SWZ = sizeof(T) == 2 && DH * (int)sizeof(T) == 128;
+  static constexpr int RS = SWZ ? 128 : DH * (int)sizeof(T) + 16;
   __host__ __device__ static int rst(int S) { return S * (int)sizeof(T) + 16; }
 };
 
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
   uint8_t* sM = reinterpret_cast<uint8_t*>(sV0 + S * L::RS);
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
-  stage<T, HP * DH>(base0 + H, ld, Lr, nkt * 16, sK0, L::RS, nullptr, 0);
-  stage<T, HP * DH>(base0 + 2 * H, ld, Lr, nkt * 16, sV0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(base0 + H, ld, Lr, nkt * 16, sK0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(base0 + 2 * H, ld, Lr, nkt * 16, sV0, L::RS, nullptr, 0);
   for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
@@ -237,8 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   for (int u = w; u < nqb * HP; u += 4) {  // units = (query block, head)
     const int qb = u / HP, hh = u % HP, h = h0 + hh;
     const T* base = base0 + hh * DH;
-    const char* sK = sK0 + hh * DH * (int)sizeof(T);
-    const char* sVt = sV0 + hh * DH * (int)sizeof(T);
+    const int cof = hh * DH * (int)sizeof(T);  // this head's byte column inside the images
     typename AT<T>::Frag fq[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fq[ks] = grow_frag<T>(base, ld, qb * 16 + li, ks, g);
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        p[kt] = dh_product<T, DH>(sK, L::RS, kt * 16 + li, g, fq);
+        p[kt] = dh_product<T, DH, L::SWZ>(sK0, L::RS, cof, kt * 16 + li, g, fq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s = sM[kt * 16 + 4 * g + r] ? p[kt][r] * scale : -INFINITY;
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     for (int kt = 0; kt < NKT; ++kt) pp[kt] = PT<T>::pack(p[kt]);
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT>::run(sVt, L::RS, dt * 16, g, li, pp, nkt);
+      const f32x4 o = SeqProd<T, NKT, L::SWZ>::run(sV0, L::RS, cof, dt * 16, g, li, pp, nkt);
       store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
     }
   }
@@ -323,8 +334,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
   const T* dob0 = dctx + (size_t)row0 * H + h0 * DH;
   const T* ob0 = ctx + (size_t)row0 * H + h0 * DH;
-  stage<T, HP * DH>(base0 + H, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
-  stage<T, HP * DH>(base0 + 2 * H, ld, Lr, nt * 16, sY0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(base0 + H, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(base0 + 2 * H, ld, Lr, nt * 16, sY0, L::RS, nullptr, 0);
   for (int idx = threadIdx.x; idx < HP * nt * 16; idx += blockDim.x) {
     const int hh = idx / (nt * 16), i = idx % (nt * 16);
     float d = 0.f;
@@ -354,8 +365,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   for (int u = w; u < nblk * HP; u += 4) {  // units = (query block, head)
     const int qb = u / HP, hh = u % HP, h = h0 + hh;
     const int cof = hh * DH * (int)sizeof(T);
-    const char* sX = sX0 + cof;
-    const char* sY = sY0 + cof;
     const T* base = base0 + hh * DH;
     const T* dob = dob0 + hh * DH;
     T* dq_out = dq_out0 + hh * DH;
@@ -376,8 +385,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int kt = 2 * t2 + hh;
-        const f32x4 s = dh_product<T, DH>(sX, L::RS, kt * 16 + li, g, fq);
-        const f32x4 dp = dh_product<T, DH>(sY, L::RS, kt * 16 + li, g, fdo);
+        const f32x4 s = dh_product<T, DH, L::SWZ>(sX0, L::RS, cof, kt * 16 + li, g, fq);
+        const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, kt * 16 + li, g, fdo);
         const uint32_t m4 = *reinterpret_cast<const uint32_t*>(sM + kt * 16 + 4 * g);
         f32x4 dsv;
 #pragma unroll
@@ -391,22 +400,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         ds[hh] = PT<T>::pack(dsv);
       }
 #pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = SeqPair<T>::acc(dq[dt], sX, L::RS, dt * 16, g, li, ds[0], ds[1], t2);
+      for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = SeqPair<T, L::SWZ>::acc(dq[dt], sX0, L::RS, cof, dt * 16, g, li, ds[0], ds[1], t2);
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, dq[dt]);
   }
   __syncthreads();  // every wave is done with the K,V images
-  stage<T, HP * DH>(base0, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
-  stage<T, HP * DH>(dob0, H, Lr, nt * 16, sY0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(base0, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
+  stage<T, HP * DH, L::SWZ>(dob0, H, Lr, nt * 16, sY0, L::RS, nullptr, 0);
   __syncthreads();
 
   // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
   for (int u = w; u < nblk * HP; u += 4) {  // units = (key block, head)
     const int kb = u / HP, hh = u % HP, h = h0 + hh;
     const int cof = hh * DH * (int)sizeof(T);
-    const char* sX = sX0 + cof;
-    const char* sY = sY0 + cof;
     const T* base = base0 + hh * DH;
     T* dq_out = dq_out0 + hh * DH;
     const float* sLse = sLse0 + hh * S;
@@ -431,8 +438,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int qt = 2 * t2 + hh;
-        const f32x4 s = dh_product<T, DH>(sX, L::RS, qt * 16 + li, g, fk);
-        const f32x4 dp = dh_product<T, DH>(sY, L::RS, qt * 16 + li, g, fv);
+        const f32x4 s = dh_product<T, DH, L::SWZ>(sX0, L::RS, cof, qt * 16 + li, g, fk);
+        const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, qt * 16 + li, g, fv);
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
         f32x4 pdv, dsv;
@@ -450,8 +457,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       }
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        dv[dt] = SeqPair<T>::acc(dv[dt], sY, L::RS, dt * 16, g, li, pd[0], pd[1], t2);
-        dk[dt] = SeqPair<T>::acc(dk[dt], sX, L::RS, dt * 16, g, li, ds[0], ds[1], t2);
+        dv[dt] = SeqPair<T, L::SWZ>::acc(dv[dt], sY0, L::RS, cof, dt * 16, g, li, pd[0], pd[1], t2);
+        dk[dt] = SeqPair<T, L::SWZ>::acc(dk[dt], sX0, L::RS, cof, dt * 16, g, li, ds[0], ds[1], t2);
       }
     }
 #pragma unroll
