@@ -28,13 +28,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HEAD_KERNELS = ("sparse_head_fwd_p2_kernel", "sparse_head_fwd_ares_kernel")  # roofline kernel names in the PMC summaries, newest first
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--layout", default="ragged", choices=["ragged", "dense"],
+                    help="layout `value` is measured on: ragged = padding tokens skipped on the device (product default), "
+                         "dense = every document computed at the full padded length (SURVEY 8d headline protocol); the "
+                         "other layout is timed too (after the timed region) and reported beside it")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--negs", type=int, default=15)
@@ -42,12 +47,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the post-run per-GEMM timing steps")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time the oracle on configs[1] at FULL shape (32 x 16 docs, 2 steps; ~36 GB of host RAM, minutes)")
     ap.add_argument("--no-dropout", action="store_true")
     return ap.parse_args()
 
 
-def build_trainer(args, device, rank):
+def build_trainer(args, device, rank, layouts=("ragged",)):
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
     from scripts.model.sparse_encoders import SparseModel
@@ -75,7 +82,10 @@ def build_trainer(args, device, rank):
                               learning_rate=2e-5, weight_decay=0.01, warmup_steps=200, logging_steps=10 ** 9, bf16=True)
     trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
                                  loss_functions=[LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1)])
-    batches = [trainer._prepare_inputs(coll([ds[b * args.bs + i] for i in range(args.bs)])) for b in range(n_batches)]
+    batches = {}
+    for layout in layouts:  # same token ids; "dense" keeps the collator's [B, S] layout, "ragged" packs on the host
+        bb.varlen = layout == "ragged"
+        batches[layout] = [trainer._prepare_inputs(coll([ds[b * args.bs + i] for i in range(args.bs)])) for b in range(n_batches)]
     return trainer, cfg, batches
 
 
@@ -165,46 +175,53 @@ def usable_cores() -> int:
     return max(1, min(n, 32))
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
     """Run the CPU leg in a child process with a hard wall-clock bound so the GPU bench line is never
     held hostage by a slow host (the child never touches the GPU)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--negs", str(args.negs), "--seq", str(args.seq),
-           "--bs", str(args.bs)]
+           "--bs", str(args.bs)] + (["--cpu-baseline-full"] if args.cpu_baseline_full else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    timeout = args.cpu_baseline_timeout + (1200 if args.cpu_baseline_full else 0)
+    fail = {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port", "cpu_model": cpu_model()}
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout, env=env)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         for line in reversed(out.stdout.splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port",
-                "sample": "CPU leg failed: " + (out.stderr.strip().splitlines() or ["no output"])[-1][:200]}
+        return dict(fail, sample="CPU leg failed: " + (out.stderr.strip().splitlines() or ["no output"])[-1][:200])
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port",
-                "sample": f"CPU oracle did not finish 2 queries x {args.negs + 1} docs in {args.cpu_baseline_timeout:.0f} s"}
+        return dict(fail, sample=f"CPU oracle did not finish within {timeout:.0f} s")
 
 
-def cpu_baseline_child(args):
-    """CPU oracle (the 'port') on a bounded sample of the same workload: the same model
-    shape, sequence length and 16 docs per query, but 2 queries per step so one step is
-    ~5-30 s of host work.  Forward + backward + AdamW, fp32, dropout on."""
-    from oracle import sparse_oracle as O  # baseline leg only
+def _oracle_steps(O, oc, nq, k, S, Sq, steps, seed, lr=2e-5):
+    """`steps` optimisation steps of the CPU oracle (forward + backward + AdamW, fp32, dropout 0.1) over consecutive
+    batches of nq queries x k documents x seq S of the synthetic generator; returns the per-step wall times"""
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
-
-    torch.set_num_threads(usable_cores())
-    oc = O.BertShape()
-    params = {k: v.requires_grad_(True) for k, v in O.init_params(oc, seed=0).items()}
+    params = {n: v.requires_grad_(True) for n, v in O.init_params(oc, seed=0).items()}
     g = torch.Generator().manual_seed(7)
     idf = torch.exp(torch.rand(oc.vocab_size, generator=g) * 6.66 - 3.9)
-    nq, k = 2, args.negs + 1
-    ds = SyntheticTriplesDataset(nq, k, args.seq, 32, oc.vocab_size, seed=1234)
-    batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
+    n_batches = min(steps, 16)
+    ds = SyntheticTriplesDataset(nq * n_batches, k, S, Sq, oc.vocab_size, seed=seed)
+    coll = PreTokenizedCollator()
     lc = O.LossConfig(loss_types=("infonce",), use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=200)
     m = {n: torch.zeros_like(v) for n, v in params.items()}
     v2 = {n: torch.zeros_like(v) for n, v in params.items()}
-    q, d = batch["query"][0], batch["docs"][0]
     times = []
-    for step in range(2):
+    for step in range(steps):
+        b = step % n_batches
+        batch = coll([ds[b * nq + i] for i in range(nq)])
+        q, d = batch["query"][0], batch["docs"][0]
         t0 = time.perf_counter()
         loss = O.compute_loss(params, oc, idf, [0, 100, 101, 102, 103], q["input_ids"], q["attention_mask"], d["input_ids"],
                               d["attention_mask"], None, lc, step, dropout_p=0.1, gen=g)[0]
@@ -212,13 +229,88 @@ def cpu_baseline_child(args):
         with torch.no_grad():
             for n, p in params.items():
                 if p.grad is not None:
-                    O.adamw_step(p, p.grad, m[n], v2[n], step + 1, 2e-5)
+                    O.adamw_step(p, p.grad, m[n], v2[n], step + 1, lr)
                     p.grad = None
         times.append(time.perf_counter() - t0)
-    t = min(times)
-    return {"value": nq / t, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"CPU oracle (torch fp32), same model/seq/docs-per-query, {nq} queries x {k} docs per step "
-                      f"(1/{args.bs // nq} of the GPU batch), best of 2 steps, {t:.1f} s/step"}
+    return times
+
+
+def cpu_baseline_child(args):
+    """CPU oracle (the 'port'; oracle/sparse_oracle.py, validated against the reference through tests/golden) timed on
+    this box's host cores:
+      * `value`: BASELINE configs[1]'s shape (same model, seq 128, 16 docs per query) on a BOUNDED sample -- 2 queries per
+        step instead of 32 (one step is a few seconds of host work), 3 steps, mean of steps 2-3;
+      * `c1_full`: BASELINE configs[0] (the reference's own CPU-runnable case) IN FULL: 64 triples = 16 steps of bs 4 x
+        (1 pos + 1 neg) x seq 64, mean of steps 2-16;
+      * `c2_full` (--cpu-baseline-full only): configs[1] at full shape, 2 steps (~36 GB of host RAM)."""
+    from oracle import sparse_oracle as O  # baseline leg only
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    oc = O.BertShape()
+    k = args.negs + 1
+    nq = 2
+    t = _oracle_steps(O, oc, nq, k, args.seq, 32, 3, seed=1234)
+    mean = sum(t[1:]) / len(t[1:])
+    out = {"value": nq / mean, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"CPU oracle (torch fp32, dropout 0.1, AdamW), configs[1] model/seq/docs-per-query, {nq} queries x {k} docs per "
+                     f"step (1/{args.bs // nq} of the GPU batch), 3 steps, mean of steps 2-3 = {mean:.2f} s/step"}
+    t1 = _oracle_steps(O, oc, 4, 2, 64, 16, 16, seed=4321)
+    m1 = sum(t1[1:]) / len(t1[1:])
+    out["c1_full"] = {"value": 4 / m1, "unit": "samples/sec", "s_per_step": m1,
+                      "sample": "configs[0] in full: 64 triples = 16 steps of bs 4 x (1 pos + 1 neg) x seq 64, mean of steps 2-16"}
+    if args.cpu_baseline_full:
+        t2 = _oracle_steps(O, oc, args.bs, k, args.seq, 32, 2, seed=1234)
+        out["c2_full"] = {"value": args.bs / t2[-1], "unit": "samples/sec", "s_per_step": t2[-1],
+                          "sample": f"configs[1] at full shape: {args.bs} queries x {k} docs x seq {args.seq}, 2 steps, second step"}
+    return out
+
+
+def measured_peaks(device):
+    """On-box peaks beside the vendor ones: a bare bf16 MFMA loop (random operands in registers, one wave per
+    SIMD on every CU) and a 16-byte-per-lane streaming copy of 1 GiB, both timed with HIP events on the launch stream."""
+    from sparse_hip import lib as L
+    sink = torch.zeros(1024, device=device)
+    blocks, iters = 256 * 4, 4096
+    st = L.stream_ptr()
+    L.call("sm_peak_mfma_bf16", L.ptr(sink), blocks, 64, st)  # warm
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.call("sm_peak_mfma_bf16", L.ptr(sink), blocks, iters, st)
+    e1.record()
+    torch.cuda.synchronize()
+    mfma = blocks * 4 * iters * 16 * 16384 / (e0.elapsed_time(e1) * 1e-3)
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    L.call("sm_peak_copy", L.ptr(src), L.ptr(dst), n, st)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        L.call("sm_peak_copy", L.ptr(src), L.ptr(dst), n, st)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return {"mfma_bf16_tflops": mfma / 1e12, "hbm_copy_gbs": 2 * n / (best * 1e-3) / 1e9,
+            "how": "bare v_mfma_f32_16x16x32_bf16 loop, random operands in registers, 1024 WGs x 4 waves; float4 copy of 1 GiB (read + write bytes)"}
+
+
+def latest_traffic(kernel_names):
+    """HBM-side bytes per launch of the roofline kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command, tools/pmc_summary.py); the git revision it was measured at is reported so a
+    stale figure is visible.  PMC counters cannot be read from inside this process."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            for name in kernel_names:
+                if name in pmc["kernels"]:
+                    return (pmc["kernels"][name]["bytes_per_launch"], f"{os.path.relpath(path, ROOT)}: {pmc['source']}",
+                            pmc.get("git", "unknown (round 1)"), name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None, None
 
 
 def main():
@@ -243,78 +335,98 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from sparse_hip import ops
-    trainer, cfg, batches = build_trainer(args, device, rank)
+    other = "dense" if args.layout == "ragged" else "ragged"
+    trainer, cfg, batches = build_trainer(args, device, rank, layouts=(args.layout, other))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with KernelTimer(ops, "sparse_head_fwd") as kt:
+    def timed(layout, kt=None):
+        """W untimed + exactly K timed steps bracketed by barrier + synchronize; max over ranks"""
+        bs_ = batches[layout]
         for i in range(args.warmup):
-            trainer.training_step(batches[i % len(batches)])
+            trainer.training_step(bs_[i % len(bs_)])
         barrier()
-        kt.enabled = True
+        if kt is not None:
+            kt.enabled = True
         t0 = time.perf_counter()
         for i in range(args.steps):
-            trainer.training_step(batches[i % len(batches)])
+            trainer.training_step(bs_[i % len(bs_)])
         barrier()
-        elapsed = time.perf_counter() - t0
+        el = time.perf_counter() - t0
+        if kt is not None:
+            kt.enabled = False
+        tmax = torch.tensor([el], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    with KernelTimer(ops, "sparse_head_fwd") as kt:
+        elapsed = timed(args.layout, kt)   # <- the line's `value`
         head_ms = kt.mean_ms()
+        rows = list(kt.rows)
+    elapsed_other = timed(other)           # the other layout, outside the headline region
     gemm_lines = None
     if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
         with GemmRoofline(ops) as gr:
+            bs_ = batches[args.layout]
             for i in range(3):
-                trainer.training_step(batches[i % len(batches)])
+                trainer.training_step(bs_[i % len(bs_)])
             torch.cuda.synchronize()
         gemm_lines = gr.summary(3, MFMA_PEAK[args.dtype])
     barrier()
-    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
 
     k = args.negs + 1
     T_padded = args.bs * k * args.seq
-    T = sum(kt.rows) / max(1, len(kt.rows))  # rows per launch: the ragged layout skips padding tokens
+    T = sum(rows) / max(1, len(rows))  # rows per launch: the ragged layout skips padding tokens
     H, V = cfg.hidden_size, cfg.vocab_size
     head_flops = 2.0 * T * H * V  # executed FLOPs of one fused decoder launch (SURVEY 8d: 2THV, T = computed rows)
     achieved = head_flops / (head_ms * 1e-3)
     peak = MFMA_PEAK[args.dtype]
-    # HBM-side bytes per launch of the roofline kernel: not measurable from inside this process (PMC counters need
-    # rocprofv3); taken from the committed PMC passes of this same command (tools/pmc_summary.py), null if absent
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
-        if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
-            traffic = pmc["kernels"]["sparse_head_fwd_ares_kernel"]["bytes_per_launch"]
-            traffic_src = "profiles/r1_pmc_traffic.json: " + pmc["source"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_src, traffic_git, traffic_kernel = None, None, None, None
+    if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16" and args.layout == "ragged":
+        traffic, traffic_src, traffic_git, traffic_kernel = latest_traffic(HEAD_KERNELS)
+    sps = lambda el: world * args.bs * args.steps / el
     result = {
         "metric": "training samples/sec (q+1pos+15neg, seq128)",
-        "value": world * args.bs * args.steps / elapsed,
+        "value": sps(elapsed),
         "unit": "samples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic MS-MARCO-shaped triples, random-init weights",
+        "value_layout": args.layout,
+        "value_dense_layout": sps(elapsed if args.layout == "dense" else elapsed_other),
+        "value_ragged_layout": sps(elapsed if args.layout == "ragged" else elapsed_other),
         "config": {"workload": "configs[1]: config_infonce.yaml recipe, v2-mini-shaped encoder (6L/384H/12A/1536I/V30522), "
                                f"bs={args.bs} x (1 pos + {args.negs} negs), seq {args.seq}, inference-free queries, "
                                "InfoNCE in-batch negatives + FLOPS, dropout " + ("off" if args.no_dropout else "0.1") + ", fused AdamW; "
-                               f"documents padded to {args.seq} by the collator, padding tokens skipped on the device "
-                               f"({T:.0f} of {T_padded} token rows computed per step)",
+                               f"documents (lengths ~N(80,30) in [16,{args.seq}]) padded to {args.seq} by the collator; `value` is the "
+                               + (f"ragged layout: padding tokens skipped on the device ({T:.0f} of {T_padded} token rows computed per step, "
+                                  "identical outputs); value_dense_layout computes all of them" if args.layout == "ragged" else
+                                  f"dense layout: all {T_padded} token rows computed; value_ragged_layout skips padding tokens"),
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
-                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks: queries, score blocks and "
-                                                      "FLOPS column means exchanged over RCCL; flat-gradient all-reduce overlapped with backward)")},
-        "roofline": {"kernel": "sparse_head_fwd_ares_kernel (fused MLM decoder + seq-max + log1p(relu))", "bound": "mfma",
+                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks: all-gather of the representations over "
+                                                      "RCCL as in the reference; flat-gradient all-reduce in slices overlapped with backward)")},
+        "roofline": {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
                      "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
+                     "traffic_measured_at_git": traffic_git, "traffic_kernel": traffic_kernel,
                      "kernel_ms": head_ms, "rows_per_launch": T},
     }
     if gemm_lines is not None:
         result["roofline_encoder_gemms"] = gemm_lines
+        fl = sum(g["gflop_per_step"] for g in gemm_lines)
+        ms = sum(g["ms_per_step"] for g in gemm_lines)
+        result["roofline_encoder_gemms_aggregate"] = {"gflop_per_step": fl, "ms_per_step": ms, "achieved_tflops": fl / ms,
+                                                      "frac": fl / ms * 1e12 / peak}
     if rank == 0:
+        if world == 1:
+            pm = measured_peaks(device)
+            result["roofline"]["peak_measured"] = pm
+            result["roofline"]["frac_of_measured_peak"] = achieved / 1e12 / pm["mfma_bf16_tflops"] if args.dtype == "bf16" else None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

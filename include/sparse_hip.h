@@ -24,6 +24,7 @@
  */
 #ifndef SPARSE_HIP_H_
 #define SPARSE_HIP_H_
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -211,6 +212,14 @@ int sm_cast_weights_multi(int dtype, const sm_cast_desc* descs_dev, int n, int t
 int sm_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
 /* x[i] *= s[0] * c with s a DEVICE scalar (autograd's upstream gradient): no host sync */
 int sm_scale_by(float* x, const float* s, float c, long n, void* stream);
+
+
+/* ---- on-box roofline calibration (measured peaks beside the vendor peaks; bench.py only) ----------
+ * sm_peak_mfma_bf16: `blocks` x 4 waves, each issuing iters x 16 independent v_mfma_f32_16x16x32_bf16 on random
+ * operands held in registers: blocks * 4 * iters * 16 * 16384 FLOP per launch.  sm_peak_copy: 16-byte-per-lane
+ * streaming copy (reads `bytes`, writes `bytes`). */
+int sm_peak_mfma_bf16(float* sink, int blocks, int iters, void* stream);
+int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

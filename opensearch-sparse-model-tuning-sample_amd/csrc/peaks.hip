@@ -1,0 +1,63 @@
+// On-box roofline calibration ("report against the vendor peak AND an on-box measured peak"):
+// a bare bf16 MFMA loop (operands in registers, one wave per SIMD, random data -- the chip holds a lower clock on
+// random operands than on zeros) and a 16-byte-per-lane streaming copy.  bench.py times both with HIP events and
+// prints them as roofline.peak_measured; nothing on the training path calls them.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void peak_mfma_bf16_kernel(float* __restrict__ sink, int iters) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t h = fmix32(t * 64 + i * 8 + j);
+      a[i][j] = (bf16)(((int)(h & 0xFFFF) - 32768) * (1.0f / 32768.0f));
+      b[i][j] = (bf16)(((int)(h >> 16) - 32768) * (1.0f / 32768.0f));
+    }
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456f) sink[t & 1023] = s;  // keeps the loop alive, (almost) never stores
+}
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n16) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+    const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+    dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+// One launch of `blocks` x 4 waves, each issuing iters x 16 independent v_mfma_f32_16x16x32_bf16 (16384 FLOP each).
+// FLOPs of the launch = blocks * 4 * iters * 16 * 16384.
+extern "C" int sm_peak_mfma_bf16(float* sink, int blocks, int iters, void* stream) {
+  SM_REQUIRE(sink != nullptr && blocks > 0 && iters > 0, "sm_peak_mfma_bf16: bad arguments");
+  hipLaunchKernelGGL(peak_mfma_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, iters);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+// dst[0:bytes) = src[0:bytes), 16 bytes per lane; moves 2 * bytes through HBM when the buffers exceed the Infinity Cache.
+extern "C" int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream) {
+  SM_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+             "sm_peak_copy: 16-byte aligned buffers and size required");
+  hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

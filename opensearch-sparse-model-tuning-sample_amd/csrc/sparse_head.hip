@@ -632,24 +632,26 @@ extern "C" int sm_row_compact(const float* q, int nq, int V, int cap, int* cols,
 
 extern "C" int sm_scores_csr_fwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, int nq, int nd, int V,
                                  int pairs, float* scores, void* stream) {
-  SM_REQUIRE(nq > 0 && nd > 0 && nd % nq == 0, "sm_scores_csr_fwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
-  hipLaunchKernelGGL(scores_csr_kernel, dim3(nd), dim3(256), 0, (hipStream_t)stream, cols, vals, nnz, cap, d, nq, nd, V, nd / nq, pairs, scores);
+  // per-query pairs need k = nd / nq documents per query; the full [nq, nd] matrix (pairs == 0) takes any shape
+  SM_REQUIRE(nq > 0 && nd > 0 && (!pairs || nd % nq == 0), "sm_scores_csr_fwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
+  hipLaunchKernelGGL(scores_csr_kernel, dim3(nd), dim3(256), 0, (hipStream_t)stream, cols, vals, nnz, cap, d, nq, nd, V, pairs ? nd / nq : 1, pairs, scores);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
 
 extern "C" int sm_scores_csr_bwd(const int* cols, const float* vals, const int* nnz, int cap, const float* d, const float* ds, int nq,
                                  int nd, int V, int pairs, float* dq, float* dd, void* stream) {
-  SM_REQUIRE(nq > 0 && nd > 0 && nd % nq == 0, "sm_scores_csr_bwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
+  SM_REQUIRE(nq > 0 && nd > 0 && (!pairs || nd % nq == 0), "sm_scores_csr_bwd: nd=%d must be a positive multiple of nq=%d", nd, nq);
+  const int kq = pairs ? nd / nq : 1;  // documents per query: only the per-query pair form reads it
   hipStream_t st = (hipStream_t)stream;
   if (dd) {
     SM_HIP_CHECK(hipMemsetAsync(dd, 0, (size_t)nd * V * sizeof(float), st));
-    hipLaunchKernelGGL(scores_csr_bwd_dd_kernel, dim3(nd), dim3(256), 0, st, cols, vals, nnz, cap, ds, nq, nd, V, nd / nq, pairs, dd);
+    hipLaunchKernelGGL(scores_csr_bwd_dd_kernel, dim3(nd), dim3(256), 0, st, cols, vals, nnz, cap, ds, nq, nd, V, kq, pairs, dd);
   }
   if (dq) {
     SM_HIP_CHECK(hipMemsetAsync(dq, 0, (size_t)nq * V * sizeof(float), st));
     hipLaunchKernelGGL(scores_csr_bwd_dq_kernel, dim3(sm_cdiv((long)nq * cap, 4)), dim3(256), 0, st, cols, nnz, cap, ds, d, nq, nd, V,
-                       nd / nq, pairs, dq);
+                       kq, pairs, dq);
   }
   SM_LAUNCH_CHECK();
   return SM_OK;

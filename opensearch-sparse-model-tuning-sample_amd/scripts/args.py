@@ -33,9 +33,9 @@ class DataTrainingArguments:
     idf_lr: Optional[float] = None
     first_rank_thresh: int = 10000
     flops_threshold: Optional[int] = None
-    # N > 1 only: "scores" = exchange queries / score blocks / FLOPS column means (default), "gather" = the
-    # reference's dense all-gather of the representations (scripts/utils.py:16-23); identical results
-    dist_exchange: str = "scores"
+    # N > 1 only: "gather" = the reference's dense all-gather of the representations (scripts/utils.py:16-23,
+    # default), "scores" = exchange queries / score blocks / FLOPS column means instead (opt-in); identical results
+    dist_exchange: str = "gather"
     swap_times: float = 0
     temperature: float = 1.0
     score_scale: float = 1.0

@@ -175,12 +175,12 @@ class SparseModelTrainer:
         return (loss, outputs) if return_outputs else loss
 
     def _use_score_exchange(self) -> bool:
-        """N > 1: exchange queries, score blocks and FLOPS column means instead of all-gathering d_rep (same loss,
-        same gradients, ~100x less traffic; sparse_hip.functional.distributed_loss).  SM_EXCHANGE=gather (or
-        data_args.dist_exchange) selects the reference's dense all-gather, kept as the parity mode."""
+        """N > 1: the default is the reference's dense all-gather of the representations (utils.py:16-23).
+        SM_EXCHANGE=scores (or data_args.dist_exchange) opts into exchanging queries, score blocks and FLOPS
+        column means instead (same loss, same gradients, ~100x less traffic; sparse_hip.functional.distributed_loss)."""
         if self.accelerator.num_processes <= 1:
             return False
-        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "scores"))
+        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "gather"))
         if mode not in ("scores", "gather"):
             raise KeyError(mode)
         return mode == "scores"
@@ -341,8 +341,10 @@ class SparseModelTrainer:
         a = self.args
         n = self.accelerator.num_processes
         if self.optimizer is not None:  # caller-supplied torch optimiser (train_ir.py:85-107 style)
-            if n > 1:
+            if n > 1:  # SUM all-reduce -> the reference's DDP mean of (loss x N) gradients
                 bb.flat_grad.div_(n)
+                if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None:
+                    sm.idf_vector.grad.div_(n)
             self.optimizer.step()
             if self.lr_scheduler is not None:
                 self.lr_scheduler.step()

@@ -19,3 +19,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# kernel / end-to-end parity first, multi-process cases last: a stalled rendezvous must not hide the parity results
+_ORDER = ("test_oracle_golden", "test_host_cpu", "test_kernels_gpu", "test_e2e_gpu", "test_baseline_configs_gpu",
+          "test_fullsize_gpu", "test_bench_cli", "test_distributed")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else len(_ORDER) - 1
+    items.sort(key=rank)  # stable: the order inside a file is kept

@@ -1,0 +1,63 @@
+"""bench.py's contract: ONE JSON line with the fields the driver and the judge read (task statement + SURVEY 8d), at
+N = 1 and -- two ranks sharing the test GPU over gloo -- at N = 2 through torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "value_layout", "value_dense_layout", "value_ragged_layout"}
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_cli_defaults_follow_the_measurement_protocol():
+    """>= 50 timed steps after >= 10 warm-up by default, layout switch present"""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert a.gpus == 1 and a.steps >= 50 and a.warmup >= 10 and a.layout in ("ragged", "dense")
+
+
+@pytest.mark.gpu
+def test_bench_one_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert REQUIRED <= set(j), REQUIRED - set(j)
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["unit"] == "samples/sec" and j["dtype"] == "bf16" and j["vs_baseline"] is None
+    assert abs(j["value"] - 32 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    pm = rf["peak_measured"]
+    assert 500 < pm["mfma_bf16_tflops"] < 2600 and 2000 < pm["hbm_copy_gbs"] < 8200, pm
+    assert j["value_ragged_layout"] > j["value_dense_layout"] > 0
+    agg = j["roofline_encoder_gemms_aggregate"]
+    assert 0 < agg["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """the N > 1 launch contract (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, barrier + max over ranks, one line
+    from rank 0); RCCL needs one GPU per rank, so on the single test GPU the transport is gloo (SM_BENCH_BACKEND)"""
+    env = dict(os.environ, SM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
+    assert "cpu_baseline" not in j and j["value"] > 0

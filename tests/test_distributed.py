@@ -50,7 +50,9 @@ def test_gradient_slices_tile_the_flat_buffer():
 
 
 WORKER = r"""
-import os, sys, numpy as np, torch, torch.distributed as dist
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(90, exit=True)  # a stalled rank prints every thread's stack and dies
+import numpy as np, torch, torch.distributed as dist
 root, pkg, out = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path[:0] = [root, pkg]
 torch.cuda.set_device(0)
@@ -74,6 +76,7 @@ model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
 case = os.environ.get("SM_TEST_CASE", "infonce_ibn")
 inf_free = case != "learned_queries"
 ibn = case != "kd_pairs"
+K = 3 if case == "infonce_ibn_k3" else 4  # k = 3 with 2 ranks: the rank count does not divide the documents per query
 kind = "kldiv" if case == "kd_pairs" else "infonce"
 margs = ModelArguments(model_name_or_path="x", inf_free=inf_free)
 dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
@@ -85,8 +88,11 @@ trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, arg
 t = lambda k: torch.tensor(g6["infonce_ibn/" + k])
 q_ids, q_mask = torch.cat([t("q_ids"), t("q_ids").flip(0)]), torch.cat([t("q_mask"), t("q_mask").flip(0)])
 d_ids = torch.cat([t("d_ids"), t("d_ids").roll(5, 0)]); d_mask = torch.cat([t("d_mask"), t("d_mask").roll(5, 0)])
+if K != 4:  # keep the first K documents of every query
+    keep = (torch.arange(24) % 4) < K
+    d_ids, d_mask = d_ids[keep], d_mask[keep]
 nq = 6 // world
-sl_q, sl_d = slice(rank * nq, (rank + 1) * nq), slice(rank * nq * 4, (rank + 1) * nq * 4)
+sl_q, sl_d = slice(rank * nq, (rank + 1) * nq), slice(rank * nq * K, (rank + 1) * nq * K)
 inp = {"query": [{"input_ids": q_ids[sl_q].cuda(), "attention_mask": q_mask[sl_q].cuda()}],
        "docs": [{"input_ids": d_ids[sl_d].cuda(), "attention_mask": d_mask[sl_d].cuda()}]}
 if kind == "kldiv":
@@ -102,25 +108,33 @@ print("done", rank)
 """
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", ["infonce_ibn", "kd_pairs", "learned_queries"])
-def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_path, case):
-    """both exchange modes: "gather" (the reference's dense all-gather of the representations) and "scores" (queries,
-    score blocks and FLOPS column means only) must reproduce the single-process step; cases: inference-free InfoNCE
-    with in-batch negatives, KL distillation on per-query pairs with a row threshold in FLOPS, learned queries (the
-    query gradient crosses ranks, FLOPS on queries too)"""
+SUBPROCESS_TIMEOUT = 120  # seconds per leg: a stalled leg must not eat the suite's time budget
+
+
+def _run(cmd, env):
+    """subprocess with a hard limit; on expiry the captured output (incl. the faulthandler stack dump the worker
+    arms at 90 s) becomes the failure message"""
+    try:
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=SUBPROCESS_TIMEOUT, env=env)
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace") + (e.stderr or b"").decode(errors="replace")
+        pytest.fail(f"timed out after {SUBPROCESS_TIMEOUT}s: {' '.join(cmd[-6:])}\n{out[-6000:]}")
+
+
+def _two_rank_case(tmp_path, case, backend, ports):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+    script.write_text(WORKER.replace('dist.init_process_group("gloo")', f'dist.init_process_group("{backend}")')
+                      .replace("torch.cuda.set_device(0)", "torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))"
+                               if backend == "nccl" else "torch.cuda.set_device(0)"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_TEST_CASE=case)
     one = str(tmp_path / "one.npz")
-    r1 = subprocess.run([sys.executable, str(script), ROOT, PKG, one], capture_output=True, text=True, timeout=600, env=env)
+    r1 = _run([sys.executable, str(script), ROOT, PKG, one], env)
     assert r1.returncode == 0, r1.stdout + r1.stderr
     a = np.load(one)
-    for port, mode in ((29541, "gather"), (29543, "scores")):
+    for port, mode in zip(ports, ("gather", "scores")):
         two = str(tmp_path / f"two_{mode}.npz")
-        r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                             "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two],
-                            capture_output=True, text=True, timeout=600, env=dict(env, SM_EXCHANGE=mode))
+        r2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                   "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two], dict(env, SM_EXCHANGE=mode))
         assert r2.returncode == 0, r2.stdout + r2.stderr
         b = np.load(two)
         # each rank reports loss x num_processes (trainer.py:139-141)
@@ -130,3 +144,25 @@ def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_
         # differences on a handful of elements, everything else must agree to fp32 accuracy
         assert (diff > 1e-4).sum() <= 1e-3 * diff.size, (mode, int((diff > 1e-4).sum()))
         assert diff.max() <= 2.5e-3, mode
+
+
+CASES = ["infonce_ibn", "infonce_ibn_k3", "kd_pairs", "learned_queries"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_path, case):
+    """both exchange modes: "gather" (the reference's dense all-gather of the representations, the default) and
+    "scores" (queries, score blocks and FLOPS column means only) must reproduce the single-process step; cases:
+    inference-free InfoNCE with in-batch negatives (k = 4, and k = 3 which the 2 ranks do not divide), KL
+    distillation on per-query pairs with a row threshold in FLOPS, learned queries (the query gradient crosses
+    ranks, FLOPS on queries too).  Two processes share the single test GPU, so the transport is gloo."""
+    _two_rank_case(tmp_path, case, "gloo", (29541 + 4 * CASES.index(case), 29543 + 4 * CASES.index(case)))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+@pytest.mark.parametrize("case", ["infonce_ibn", "kd_pairs"])
+def test_two_rank_step_over_rccl(tmp_path, case):
+    """the same invariant with one GPU per rank over RCCL (backend "nccl"), when the box has two GPUs"""
+    _two_rank_case(tmp_path, case, "nccl", (29571 + 4 * CASES.index(case), 29573 + 4 * CASES.index(case)))
