@@ -134,7 +134,11 @@ int sm_attention_bwd(int dtype, const void* qkv, const uint8_t* keymask, const v
  * Never materialises the [B,S,V] logits. */
 int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
                        float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0,
-                       const sm_ragged* rag, uint64_t* scratch /* [B,V], ragged layout only */, void* stream);
+                       const sm_ragged* rag, uint64_t* scratch /* sm_sparse_head_fwd_scratch_bytes(), may be NULL when 0 */,
+                       void* stream);
+/* bytes of caller-owned scratch the call above needs for this (dtype, shape, layout): 0 for bf16 at H in
+ * {128, 256, 384, 512, 768} (vocabulary-stationary kernel: rep / argmax are written once, finished) */
+long sm_sparse_head_fwd_scratch_bytes(int dtype, int B, int S, int H, int V, int ragged);
 /* scripts/model/sparse_encoders.py:115-119 ratio prune, in place on rep */
 int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream);
 /* backward of the fused head: given grad_rep[B,V] produces dt[B*S,H] (dtype),

@@ -517,275 +517,6 @@ __global__ void head_unpack_kernel(const unsigned long long* __restrict__ packed
 }
 
 // ---------------------------------------------------------------------------------------
-// Persistent form of the fused head for H = 384 in bf16 (the v2-mini headline shape): one
-// workgroup (4 waves, one per SIMD, so each wave owns the full 512-register file) per 128-token
-// row tile.  Each wave keeps its 64 x 384 slice of t as MFMA A-fragments IN REGISTERS for its
-// whole life (192 VGPRs) and the whole LDS becomes a 16-stage global_load_lds ring through which
-// the tied embedding table E streams continuously across the 239 vocab tiles (128 vocab rows x
-// 32 k per stage, up to 14 stages = 112 KiB in flight per CU: enough to cover L2-miss latency at
-// the ~60 GB/s per CU the MFMAs can consume).  B fragments are double-buffered in registers so
-// the LDS reads of slice k+1 fly under the MFMAs of slice k; the epilogue is the (max, argmax)
-// reduction of the generic kernel.
-// ---------------------------------------------------------------------------------------
-constexpr int AR_K = 384, AR_NST = 16, AR_SLICES = AR_K / 32;
-constexpr int AR_LDS = AR_NST * GL_STAGE + 8 * 4 * 128 * 4;  // ring + reduction scratch (ragged: 8 blocks x 4 lane groups)
-
-// s_waitcnt vmcnt(2 * n) for a run-time n in [0, AR_NST - 3] (the count must be an immediate)
-__device__ __forceinline__ void wait_younger(int n) {
-  if (n >= AR_NST - 3) { asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); return; }  // steady state
-  switch (n) {
-#define SM_W(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N) : "memory"); break;
-    SM_W(0) SM_W(1) SM_W(2) SM_W(3) SM_W(4) SM_W(5) SM_W(6) SM_W(7) SM_W(8) SM_W(9) SM_W(10) SM_W(11) SM_W(12)
-#undef SM_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-}
-
-template <int DBG, bool RAG>
-__global__ __launch_bounds__(NTHREADS) void sparse_head_fwd_ares_kernel(const bf16* __restrict__ Tn, const bf16* __restrict__ E,
-                                                                        const float* __restrict__ bias, const uint8_t* __restrict__ mask,
-                                                                        float* __restrict__ rep, uint16_t* __restrict__ argmax,
-                                                                        int Bdocs, int S, int V, int use_l0,
-                                                                        const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
-                                                                        int rag_rows, unsigned long long* __restrict__ packed) {
-  extern __shared__ __attribute__((aligned(16))) char dsmem[];
-  char* const ring = dsmem;
-  float* const redv = reinterpret_cast<float*>(ring + AR_NST * GL_STAGE);
-  const int Ttot = RAG ? rag_rows : Bdocs * S;
-  const int m0 = blockIdx.x * 128;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
-  // blockIdx.y selects a contiguous range of vocab tiles: more, shorter workgroups so that a tile count
-  // that is not a multiple of the CU count does not leave most of the chip idle in the last round
-  const int nvt_all = (V + 127) / 128;
-  const int per = (nvt_all + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int vt0 = blockIdx.y * per, vt1 = min(nvt_all, vt0 + per);
-  if (vt0 >= vt1) return;
-  const int nvt = vt1 - vt0, nslice = nvt * AR_SLICES;
-
-  // per-lane source offsets of this wave's two 1-KiB pieces of a stage (elements, within a vocab
-  // tile): row = piece*16 + lane/4, swizzled 16-byte chunk; the stream position (vocab tile, k
-  // slice) of the next stage to issue is tracked incrementally in scalars
-  int eoff[2], erow[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    erow[p] = (w * 2 + p) * 16 + (lane >> 2);
-    eoff[p] = erow[p] * AR_K + (((lane & 3) ^ ((0 - (erow[p] >> 2)) & 3)) << 3);
-  }
-  int ivt = vt0, iks = 0, istage = 0;
-  auto issue_next = [&]() {
-    const bf16* src = E + (size_t)ivt * 128 * AR_K + iks * 32;
-    char* st = ring + istage * GL_STAGE + w * 2048;
-    if (ivt == nvt_all - 1) {  // last vocab tile: rows past V are clamped (their columns are never stored)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int r = min(ivt * 128 + erow[p], V - 1) - ivt * 128;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + eoff[p] + (r - erow[p]) * AR_K), (lds_void_t*)(st + p * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + eoff[p]), (lds_void_t*)(st + p * 1024), 16, 0, 0);
-    }
-    if (++iks == AR_SLICES) { iks = 0; ++ivt; }
-    istage = (istage + 1) & (AR_NST - 1);
-  };
-#pragma unroll
-  for (int s = 0; s < AR_NST - 1; ++s) issue_next();
-  // resident A fragments: rows wm*64 + i*16 + li, k = 32*ks + 8*g .. +7
-  bf16x8 fa[AR_SLICES][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = min(m0 + wm * 64 + i * 16 + li, Ttot - 1);
-#pragma unroll
-    for (int ks = 0; ks < AR_SLICES; ++ks)
-      fa[ks][i] = *reinterpret_cast<const bf16x8*>(Tn + (size_t)row * AR_K + ks * 32 + g * 8);
-  }
-  uint32_t mrow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = m0 + wm * 64 + i * 16 + g * 4;
-    mrow[i] = row < Ttot ? *reinterpret_cast<const uint32_t*>(mask + row) : 0u;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  bf16x8 fb[2][4];
-  auto load_b = [&](int gs, bf16x8 (&b)[4]) {
-    const char* st = ring + (gs & (AR_NST - 1)) * GL_STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = GlFrag<bf16>::load(st, wn * 64 + i * 16 + li, 0, g);
-  };
-  load_b(0, fb[0]);  // slice 0 is complete (the vmcnt(0) above)
-
-  // Epilogue pipelining: the in-lane (max, argmax) reduction of a tile (64 accumulators -> 4
-  // candidates per lane) runs right after its last MFMA; the LDS exchange and the finalisation
-  // (bias, log1p, stores) of tile vt-1 ride inside tile vt's K-loop, behind its slice barriers.
-  // (max, argmax) travel as ONE float: the row index (7 bits in the dense layout: row in tile; 8 bits in
-  // the ragged layout: position in the document) replaces the low mantissa bits of the candidate, so
-  // a plain v_max_f32 chain carries the arg-max along (the value keeps >= 16 mantissa bits, far
-  // inside the bf16 error of the inputs).
-  constexpr uint32_t IDX_MASK = RAG ? 0xFFu : 0x7Fu;
-  constexpr int NC = RAG ? 4 : 1;  // candidates per lane and column block: per 16-row block / per 64 rows
-  f32x4 acc[4][4];
-  float cand[4][NC];
-  float mneg[4][4];  // 0 for attended rows, -3e38 for padded rows of this lane
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mneg[i][r] = ((mrow[i] >> (8 * r)) & 0xFFu) ? 0.f : -3.0e38f;  // finite: -inf | index bits would be a NaN
-  // index of this lane's row r of block i: row in tile (dense) or position in its document (ragged)
-  int ibase[4];
-  const int nblk_tot = Ttot / 16;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rt = wm * 64 + i * 16 + g * 4;
-    if (RAG) {
-      const int blk = min(m0 / 16 + wm * 4 + i, nblk_tot - 1);
-      ibase[i] = m0 + rt - doc_off[blk_doc[blk]];
-    } else {
-      ibase[i] = rt;
-    }
-  }
-
-  // ragged: documents of this thread's 4 blocks (half = threadIdx.x >> 7 picks wave row 0 / 1), fixed
-  // for the life of the workgroup, and the bias of the next tile's column (prefetched a tile ahead)
-  int bdoc[4];
-  float bias_next = 0.f;
-  if constexpr (RAG) {
-    const int half = threadIdx.x >> 7;
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-      const int blk = m0 / 16 + half * 4 + k2;
-      bdoc[k2] = blk < nblk_tot ? blk_doc[blk] : -1;
-    }
-    const int c0 = vt0 * 128 + (threadIdx.x & 127);
-    bias_next = c0 < V ? bias[c0] : 0.f;
-  }
-  auto finalize = [&](int vt) {
-    if constexpr (RAG) {
-      // all 256 threads: thread = (column, wave row); per 16-row block max over the 4 lane groups, merge
-      // consecutive blocks of one document, fold into the 64-bit (relu(max + bias) bits, 0xFFFF - position)
-      // scratch with atomicMax (documents spanning wave rows / row tiles combine there)
-      const int tcol = threadIdx.x & 127, half = threadIdx.x >> 7;
-      const int col = vt * 128 + tcol;
-      const float bcol = bias_next;
-      const int cn = (vt + 1) * 128 + tcol;
-      bias_next = (vt + 1 < vt1 && cn < V) ? bias[cn] : 0.f;
-      float c[4];
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) {
-        const float* rb = redv + (half * 4 + k2) * 512 + tcol;
-        c[k2] = fmaxf(fmaxf(rb[0], rb[128]), fmaxf(rb[256], rb[384]));
-      }
-      int cur = -1;
-      unsigned long long best = 0ull;
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) {
-        const int d = bdoc[k2];
-        if (d != cur) {
-          if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
-          cur = d;
-          best = 0ull;
-        }
-        if (d >= 0 && c[k2] > -1.0e37f) {
-          const uint32_t bits = __float_as_uint(c[k2]);
-          const float y = fmaxf(__uint_as_float(bits & ~IDX_MASK) + bcol, 0.f);
-          const unsigned long long w64 = ((unsigned long long)__float_as_uint(y) << 32) | (0xFFFFu - (bits & IDX_MASK));
-          if (y > 0.f && w64 > best) best = w64;
-        }
-      }
-      if (cur >= 0 && best && col < V) atomicMax(&packed[(size_t)cur * V + col], best);
-      return;
-    }
-    if (threadIdx.x < 128) {
-      const int col = vt * 128 + threadIdx.x;
-      {
-        float c[8];
-#pragma unroll
-        for (int grp = 0; grp < 8; ++grp) c[grp] = redv[grp * 128 + threadIdx.x];
-        const float lo = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])), hi = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
-        const int ndoc = 128 / S;  // S is 64 or 128 here: a document is one or both 64-row wave blocks
-        for (int dd = 0; dd < ndoc; ++dd) {
-          const int b = m0 / S + dd;
-          const float best = ndoc == 2 ? (dd ? hi : lo) : fmaxf(lo, hi);
-          if (b < Bdocs && col < V) {
-            const uint32_t bits = __float_as_uint(best);
-            float y = best < -1.0e37f ? 0.f : fmaxf(__uint_as_float(bits & ~IDX_MASK) + bias[col], 0.f);
-            y = log1pf(y);
-            if (use_l0) y = log1pf(y);
-            rep[(size_t)b * V + col] = y;
-            argmax[(size_t)b * V + col] = (uint16_t)((int)(bits & IDX_MASK) - dd * S);
-          }
-        }
-      }
-    }
-  };
-  auto publish = [&]() {  // candidates of the previous tile -> LDS
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (RAG) {  // [block = wm*4 + i][lane group g][128 cols]
-#pragma unroll
-        for (int i = 0; i < 4; ++i) redv[((wm * 4 + i) * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j][i];
-      } else {              // [wm*4 + g][128 cols]
-        redv[(wm * 4 + g) * 128 + wn * 64 + j * 16 + li] = cand[j][0];
-      }
-    }
-  };
-
-  for (int vt = 0; vt < nvt; ++vt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < AR_SLICES; ++ks) {
-      const int gs = vt * AR_SLICES + ks;
-      // slice gs+1 must have landed; slices gs+2 .. gs+NST-2 stay in flight (2 loads per slice and
-      // wave, completion in issue order; the epilogue's stores only make this wait conservative)
-      if (!(DBG & 2) && gs + 1 < nslice) wait_younger(min(AR_NST - 3, nslice - 2 - gs));
-      if (ks == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // publish() of slice 0 is in LDS
-      __builtin_amdgcn_s_barrier();  // slice gs+1 landed for every wave; stage (gs-1) % NST is free
-      asm volatile("" ::: "memory");
-      if (!(DBG & 2) && gs + AR_NST - 1 < nslice) issue_next();
-      if (gs + 1 < nslice) load_b(gs + 1, fb[(ks + 1) & 1]);
-      if (!(DBG & 1) && vt > 0 && ks == 0) publish();
-      if (!(DBG & 1) && vt > 0 && ks == 1) finalize(vt0 + vt - 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
-    }
-    // in-lane reduction, index packed into the low mantissa bits: over the lane's 16 rows (dense) or
-    // per 16-row block (ragged: blocks of one tile may belong to different documents)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float best = -3.0e38f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (RAG) best = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[i][j][r] + mneg[i][r];
-          best = fmaxf(best, __uint_as_float((__float_as_uint(v) & ~IDX_MASK) | (uint32_t)(ibase[i] + r)));
-        }
-        if (RAG) cand[j][i] = best;
-      }
-      if (!RAG) cand[j][0] = best;
-    }
-  }
-  if (!(DBG & 1)) {  // epilogue of the last tile
-    publish();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    finalize(vt0 + nvt - 1);
-  } else if (cand[0][0] + cand[1][0] + cand[2][0] + cand[3][0] == 12345.678f) {
-    rep[threadIdx.x] = cand[0][0];
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // TN (weight gradient): C[N,Kc] += sum_m A[m,N]^T B[m,Kc], split over m across grid.z and
 // atomically accumulated in fp32.  Both operands are staged row-major [m][cols] exactly as
 // they sit in HBM (coalesced) and the MFMA fragments (8 consecutive m per lane) come out of
@@ -1740,7 +1471,15 @@ extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, 
 
 // vocab-range split of the persistent head kernel: 1 when the row tiles already fill whole rounds of the
 // 256 CUs, otherwise 8 ranges (~30 vocab tiles each) so the last round is short
-static int ares_vsplit(int mtiles) { return (mtiles % 256 == 0) ? 1 : 8; }
+// bf16 at the supported hidden sizes: the vocabulary-stationary kernel of head_fwd.hip (no scratch, rep / argmax written once)
+int sm_head_fwd_vs_try(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask, float* rep, uint16_t* argmax,
+                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
+bool sm_head_fwd_vs_takes(int dtype, int H, int S);
+
+extern "C" long sm_sparse_head_fwd_scratch_bytes(int dtype, int B, int S, int H, int V, int ragged) {
+  if (!ragged || sm_head_fwd_vs_takes(dtype, H, S)) return 0;
+  return (long)B * V * (long)sizeof(uint64_t);
+}
 
 extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask,
                                   float* rep, uint16_t* argmax, int B, int S, int H, int V, int use_l0, const sm_ragged* rag,
@@ -1750,22 +1489,20 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
   SM_REQUIRE(dtype == SM_BF16 || dtype == SM_F32, "sm_sparse_head_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
-  static const int ares_on = getenv("SM_ARES") ? atoi(getenv("SM_ARES")) : 1;
+  {
+    const int r = sm_head_fwd_vs_try(dtype, t, E, bias, mask, rep, argmax, B, S, H, V, use_l0, rag, st);
+    if (r <= 0) return r;
+  }
+  const int xcd_on = 1;
   if (rag) {
-    // ragged layout: per-(document, column) candidates meet in a 64-bit atomicMax scratch
+    // generic kernel (fp32 parity mode, other hidden sizes), ragged layout: per-(document, column) candidates meet in a 64-bit
+    // atomicMax scratch that a second pass unpacks
     SM_REQUIRE(scratch != nullptr && rag->rows > 0 && rag->rows % 16 == 0, "sm_sparse_head_fwd: ragged layout needs scratch and rows % 16 == 0");
     SM_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)B * V * sizeof(uint64_t), st));
     const int mtiles = sm_cdiv(rag->rows, 128);
     dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
     unsigned long long* pk = reinterpret_cast<unsigned long long*>(scratch);
-    if (ares_on && dtype == SM_BF16 && H == AR_K && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
-      static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
-      auto kern = dbg == 1 ? sparse_head_fwd_ares_kernel<1, true> : sparse_head_fwd_ares_kernel<0, true>;
-      SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));
-      hipLaunchKernelGGL(kern, dim3(mtiles, ares_vsplit(mtiles)), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, V,
-                         use_l0, rag->doc_off, rag->blk_doc, rag->rows, pk);
-    } else if (dtype == SM_BF16)
+    if (dtype == SM_BF16)
       hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax,
                          B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
     else
@@ -1780,29 +1517,6 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0),
              "sm_sparse_head_fwd: S=%d must be 16/32/64/128 or a multiple of 128 (pad the batch)", S);
   const long T = (long)B * S;
-  if (ares_on && dtype == SM_BF16 && H == AR_K && (S == 64 || S == 128) && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0) {
-    static const int dbg = getenv("SM_ARES_DBG") ? atoi(getenv("SM_ARES_DBG")) : 0;
-#define SM_ARES_LAUNCH(D)                                                                                                   \
-    {                                                                                                                       \
-      auto kern = sparse_head_fwd_ares_kernel<D, false>;                                                                    \
-      SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AR_LDS));             \
-      hipLaunchKernelGGL(kern, dim3(sm_cdiv(T, 128), ares_vsplit(sm_cdiv(T, 128))), dim3(NTHREADS), AR_LDS, st, (const bf16*)t, (const bf16*)E, bias,     \
-                         mask, rep, argmax, B, S, V, use_l0, (const int32_t*)nullptr, (const int32_t*)nullptr, 0,          \
-                         (unsigned long long*)nullptr);                                                                     \
-    }
-    switch (dbg) {
-      case 1: SM_ARES_LAUNCH(1) break;
-      case 2: SM_ARES_LAUNCH(2) break;
-      case 3: SM_ARES_LAUNCH(3) break;
-      case 4: SM_ARES_LAUNCH(4) break;
-      case 5: SM_ARES_LAUNCH(5) break;
-      case 6: SM_ARES_LAUNCH(6) break;
-      default: SM_ARES_LAUNCH(0) break;
-    }
-#undef SM_ARES_LAUNCH
-    SM_LAUNCH_CHECK();
-    return SM_OK;
-  }
   const int mtiles = S > 128 ? B : sm_cdiv(T, 128);
   dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _rag, _p],
     "sm_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _rag, _p],
     "sm_sparse_head_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p],
+    "sm_sparse_head_fwd_scratch_bytes": [_i, _i, _i, _i, _i, _i],
     "sm_prune_rows": [_p, _i, _i, _f, _p],
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
@@ -107,7 +108,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_long if name.endswith("_bytes") else C.c_int
     _lib = lib
     return lib
 
