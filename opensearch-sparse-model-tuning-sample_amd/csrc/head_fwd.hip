@@ -43,17 +43,19 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr float VS_NEG = -3.0e38f;  // finite: (-inf | index bits) would be a NaN
-constexpr int VS_D = 8;            // A fragments in flight per compute wave
+#ifndef VS_EXP_D
+#define VS_EXP_D 8
+#endif
+constexpr int VS_D = VS_EXP_D;            // A fragments in flight per compute wave
 
 template <int H> struct VsCfg {
   static constexpr int KS = H / 16;          // MFMA k-steps per 32-row step = LDS-DMA pieces (1 KiB) per stage
   static constexpr int ROWB = 2 * H;         // bytes per LDS row
   static constexpr int STAGE = 32 * ROWB;
   static constexpr bool DED = H <= 384;      // dedicated loader waves (512 threads) or self-loading compute waves (256)
-  static constexpr int MAILBOX = DED ? 2 * 4 * 2 * (256 + 4) : 0;  // [parity][compute wave][block]: 64 running maxima + a flag
-  static constexpr int NST = ((160 * 1024 - MAILBOX) / STAGE) > 6 ? 6 : ((160 * 1024 - MAILBOX) / STAGE);
+  static constexpr int NST = (160 * 1024 / STAGE) > 6 ? 6 : (160 * 1024 / STAGE);
   static constexpr int PPW = KS / 4;         // pieces per loading wave and stage
-  static constexpr int LDS = NST * STAGE + MAILBOX;
+  static constexpr int LDS = NST * STAGE;
   static_assert(H % 128 == 0 && NST >= 3, "hidden size must be a multiple of 128 and leave room for a 3-stage ring");
 };
 
@@ -70,6 +72,11 @@ template <int PPW> __device__ __forceinline__ void vs_wait_stages(int younger) {
 template <int OFF> __device__ __forceinline__ bf16x8 vs_lds_read(uint32_t addr) {
   bf16x8 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 vs_lds_read128f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
 __device__ __forceinline__ uint32_t vs_lds_read32(uint32_t addr) {
@@ -89,9 +96,21 @@ template <int I, int N, typename F> __device__ __forceinline__ void vs_static_fo
 }
 
 struct VsMeta {
-  int doc, pos;        // lane & 1 = block: document of the block, position of its first row in that document
-  uint32_t mw[2][2];   // [block][half-block]: mask bytes of this lane's 4 + 4 rows
+  int doc, pos;  // lane & 1 = block: document of the block, position of its first row in that document
+  uint32_t vlo, vhi;  // mask dwords of rows 0-3 / 8-11 of the block, as loaded (consumed a step later: no wait at the load);
+                      // their low byte = first row of each 8-row half: zero -> that half is padding entirely
 };
+
+#if defined(VS_EXP_STAMP) || defined(VS_EXP_CSTAMP)
+__device__ unsigned long long vs_stamps[8 * 2048];
+#ifdef VS_EXP_STAMP
+#define VS_STAMP(S, K) if (blockIdx.x == 17 && w == 4 && (S) < 2048) { if (lane == 0) vs_stamps[(S) * 8 + (K)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define VS_STAMP(S, K)
+#endif
+#else
+#define VS_STAMP(S, K)
+#endif
 
 template <int H, bool RAG>
 __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_kernel(
@@ -100,6 +119,7 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
     const int32_t* __restrict__ pos_ids, int rows, uint32_t idx_mask) {
   using C = VsCfg<H>;
   constexpr int KS = C::KS, NST = C::NST, PPW = C::PPW, D = VS_D;
+  constexpr int BAR_KS = KS - D < 4 ? KS - D : 4;  // barrier(s) sits behind MFMA BAR_KS of step s, in front of the first read of stage s + 1
   constexpr bool DED = C::DED;
   extern __shared__ __attribute__((aligned(256))) char vs_smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,22 +130,30 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
   const int col_l = lane & 31, h = lane >> 5;
   const int col = n0 + cw * 32 + col_l;
   const float bias_c = col < V ? bias[col] : 0.f;
-  // mailbox (DED only): [parity][compute wave][block] -> 64 packed running maxima + the document they belong to (or -1)
-  const uint32_t mb_val = lds0 + NST * C::STAGE, mb_flag = mb_val + 2 * 4 * 2 * 256;
-  auto mb_val_addr = [&](int parity, int b) { return mb_val + (uint32_t)(((parity * 4 + cw) * 2 + b) * 256 + lane * 4); };
-  auto mb_flag_addr = [&](int parity, int b) { return mb_flag + (uint32_t)(((parity * 4 + cw) * 2 + b) * 4); };
-
-  // finish one (document, column): cross-half maximum already taken, `bits` = packed (value, position)
+  // finish one (document, column) from the packed (value, complemented position) maximum; log(1 + y) through v_log_f32:
+  // its absolute error (~1e-7) is far inside the bf16 error of the inputs.  `run` is kept identical in both lane halves
+  // (the halves exchange their block candidates), so no lane exchange is needed here
+  auto finish_value = [&](uint32_t bits, float& y, uint32_t& pos) {
+    y = fmaxf(__uint_as_float(bits & ~idx_mask) + bias_c, 0.f);
+    // v_log_f32 (log2) directly: the argument is >= 1, none of logf's range handling is needed
+    y = __builtin_amdgcn_logf(1.0f + y) * 0.69314718f;
+    const float y2 = __builtin_amdgcn_logf(1.0f + y) * 0.69314718f;
+    y = use_l0 ? y2 : y;
+    pos = idx_mask - (bits & idx_mask);  // the position travels complemented: lower positions win ties
+  };
   auto store_doc = [&](int doc, uint32_t bits) {
-    float y = fmaxf(__uint_as_float(bits & ~idx_mask) + bias_c, 0.f);
-    y = log1pf(y);
-    if (use_l0) y = log1pf(y);
+    float y;
+    uint32_t pos;
+    finish_value(bits, y, pos);
     if (col < V) {
       const size_t o = (size_t)doc * V + col;
       if (h == 0) rep[o] = y;
-      else argmax[o] = (uint16_t)(bits & idx_mask);
+      else argmax[o] = (uint16_t)pos;
     }
   };
+  // lanes that store rep (lower half) / argmax (upper half) for a finished document, as exec masks
+  const unsigned long long colmask = __builtin_amdgcn_ballot_w64(col < V);
+  const unsigned long long rep_lanes = colmask & 0xFFFFFFFFull, arg_lanes = colmask & 0xFFFFFFFF00000000ull;
 
   // ------------------------------------------------------------------ loader role
   const int lw = DED ? w - 4 : w;  // loading wave index 0..3
@@ -156,6 +184,40 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
       }
     }
   };
+  // Padded rows (zero mask byte) of a landed stage are overwritten IN LDS with a copy of the first row of their 8-row
+  // half-block: a duplicate of a valid row cannot change a maximum, and because lower positions win ties (below) it cannot
+  // become the arg-max either -- so the compute waves need no per-row masking at all.  Masks are per-document prefixes
+  // (right-padded batches, scripts/dataset/collator.py:158-175): a half-block whose first row is padded is padded entirely
+  // and is left out by the compute waves (VsMeta::val).  This loading wave fixes rows 8 lw .. 8 lw + 7 of the stage --
+  // exactly the rows its own LDS-DMA pieces carried, so its own vmcnt wait is all the ordering the copy needs.
+  // mask bytes of this wave's 8 rows of stage s (all ones past the end: nothing to fix there)
+  auto load_mask8 = [&](int s) -> uint2 {
+    const int row0 = s * 32 + lw * 8;
+    if (row0 + 8 > rows) return uint2{0x01010101u, 0x01010101u};
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(mask + row0);
+    return uint2{(uint32_t)__builtin_amdgcn_readfirstlane(mw[0]), (uint32_t)__builtin_amdgcn_readfirstlane(mw[1])};
+  };
+  auto fix_stage = [&](int s, uint2 mk) {
+    const uint32_t m0 = mk.x, m1 = mk.y;
+    const uint32_t nz0 = (((m0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m0) & 0x80808080u, nz1 = (((m1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m1) & 0x80808080u;
+    if (!(nz0 & 0x80u) || (nz0 == 0x80808080u && nz1 == 0x80808080u)) return;  // half-block left out entirely / nothing padded here
+    const uint32_t stage = lds0 + (uint32_t)((s % NST) * C::STAGE);
+    const uint32_t src_row = (uint32_t)(lw * 8), sx = src_row & 15u;
+    for (int c = lane; c < 2 * KS; c += 64) {  // logical 16-byte chunk c of the row
+      f32x4 v = vs_lds_read128f(stage + src_row * C::ROWB + ((((uint32_t)c & ~15u) | (((uint32_t)c & 15u) ^ sx)) << 4));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+#pragma unroll
+      for (int j = 1; j < 8; ++j) {
+        const uint32_t nz = j < 4 ? nz0 : nz1;
+        if (!((nz >> (8 * (j & 3) + 7)) & 1u)) {
+          const uint32_t rx = sx + (uint32_t)j;  // (row & 15) of the destination
+          const uint32_t pc = ((uint32_t)c & ~15u) | (((uint32_t)c & 15u) ^ rx);
+          asm volatile("ds_write_b128 %0, %1" ::"v"(stage + (src_row + j) * C::ROWB + (pc << 4)), "v"(v) : "memory");
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   // before barrier(s): stage min(s + 1, nsteps - 1) has landed; stages up to s + NST - 2 have been issued
   auto wait_landed = [&](int s) {
     const int younger = min(s + NST - 2, nsteps - 1) - min(s + 1, nsteps - 1);
@@ -163,33 +225,25 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
     else vs_wait_stages<PPW>(younger);
   };
   if (DED && w >= 4) {
-    // the compute waves post the running maximum of every finished document in the mailbox (epilogue of step s - 1, written
-    // during step s into parity s & 1); this wave finishes it (bias, relu, log1p, stores) after barrier(s + 1).  All LDS
-    // accesses here are inline asm: a read the compiler can see would wait for every LDS-DMA in flight
-    auto drain = [&](int parity) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        uint32_t f = vs_lds_read32(mb_flag_addr(parity, b));
-        uint32_t mine = vs_lds_read32(mb_val_addr(parity, b));
-        uint32_t other = vs_lds_read32(mb_val_addr(parity, b) ^ 128u);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f), "+v"(mine), "+v"(other) : : "memory");
-        const int doc = __builtin_amdgcn_readfirstlane((int)f);
-        if (doc >= 0) store_doc(doc, __float_as_uint(fmaxf(__uint_as_float(mine), __uint_as_float(other))));
-      }
-    };
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
       if (s < nsteps) issue(s);
+    uint2 mk = load_mask8(1);  // mask words travel one iteration ahead of their use (scalar loads: off the vmcnt queue)
     for (int s = 0; s < nsteps; ++s) {
+      VS_STAMP(s, 0)
       wait_landed(s);
+      VS_STAMP(s, 1)
+      if (s == 0) fix_stage(0, load_mask8(0));  // (stage 0 has landed too: completion is in issue order)
+      if (s + 1 < nsteps) fix_stage(s + 1, mk);
+      VS_STAMP(s, 2)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      VS_STAMP(s, 3)
       if (s + NST - 1 < nsteps) issue(s + NST - 1);
-      if (s >= 2) drain((s - 1) & 1);  // written during step s - 1, complete since barrier(s)
+      VS_STAMP(s, 4)
+      mk = load_mask8(s + 2);
+      VS_STAMP(s, 5)
     }
-    __builtin_amdgcn_s_barrier();  // the compute waves' last in-loop epilogue (step nsteps - 1, parity (nsteps - 1) & 1)
-    asm volatile("" ::: "memory");
-    if (nsteps >= 2) drain((nsteps - 1) & 1);
     return;
   }
   if (!DED) {
@@ -217,66 +271,86 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
       m.doc = blk / bps;
       m.pos = (blk - m.doc * bps) * 16;
     }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int r0 = min(2 * s + b, nblk - 1) * 16 + 4 * h;
-      m.mw[b][0] = *reinterpret_cast<const uint32_t*>(mask + r0);
-      m.mw[b][1] = *reinterpret_cast<const uint32_t*>(mask + r0 + 8);
-    }
-  };
-  // any of the 32 rows of the step masked out?  (byte-nonzero test of this lane's 16 mask bytes, then a ballot)
-  auto any_masked = [&](const VsMeta& m) {
-    uint32_t all = 0x80808080u;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) all &= (((m.mw[b][q] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m.mw[b][q]);
-    return __builtin_amdgcn_ballot_w64((all & 0x80808080u) != 0x80808080u) != 0ull;
+    const uint4 mb = *reinterpret_cast<const uint4*>(mask + blk * 16);
+    m.vlo = mb.x;
+    m.vhi = mb.z;
   };
 
   int cur = -1;        // document whose maximum `run` carries (wave-uniform)
   float run = VS_NEG;  // packed (value, position) running maximum of this lane's column over this lane's rows
-  // reduce one 16-row block (registers 8 b .. 8 b + 7 of `acc`) into the running maximum.  MASKED: rows with a zero mask byte
-  // are excluded.  POST: branch-free form, a finished document's maximum goes to the mailbox (parity `par`) for the loader
-  // wave to finish; otherwise this wave finishes it itself (a branch)
-  auto fold_block = [&](const f32x16& acc, int b, int doc, int pos, uint32_t mw0, uint32_t mw1, auto masked_c, auto post_c, int par) {
-    constexpr bool MASKED = decltype(masked_c)::value, POST = decltype(post_c)::value;
+  // reduce one 16-row block (registers 8 b .. 8 b + 7 of `acc`) into the running maximum; a finished document is completed
+  // right here (a branch: used for the last step, and for every step when there are no loader waves).  Ties go to the LOWER
+  // position (as torch.max does): register index and position travel complemented.
+  auto fold_block = [&](const f32x16& acc, int b, int doc, int pos, bool lo_ok, bool hi_ok) {
     const bool newdoc = doc != cur;
-    if constexpr (POST) {
-      asm volatile("ds_write_b32 %0, %1" ::"v"(mb_val_addr(par, b)), "v"(run) : "memory");
-      asm volatile("ds_write_b32 %0, %1" ::"v"(mb_flag_addr(par, b)), "v"(newdoc ? cur : -1) : "memory");
-    } else {
-      if (newdoc && cur >= 0) store_doc(cur, __float_as_uint(fmaxf(run, __shfl_xor(run, 32, 64))));
-    }
+    if (newdoc && cur >= 0) store_doc(cur, __float_as_uint(run));
     run = newdoc ? VS_NEG : run;
     cur = doc;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = acc[8 * b + i];
-    if constexpr (MASKED) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (((mw0 >> (8 * i)) & 0xFFu) == 0u) v[i] = VS_NEG;
-        if (((mw1 >> (8 * i)) & 0xFFu) == 0u) v[4 + i] = VS_NEG;
-      }
-    }
     uint32_t p[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = (__float_as_uint(v[i]) & 0xFFFFFFF8u) | (uint32_t)i;
-    float m = fmaxf(fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1])), __uint_as_float(p[2]));
-    m = fmaxf(fmaxf(m, __uint_as_float(p[3])), __uint_as_float(p[4]));
-    m = fmaxf(fmaxf(m, __uint_as_float(p[5])), __uint_as_float(p[6]));
-    m = fmaxf(m, __uint_as_float(p[7]));
+    for (int i = 0; i < 8; ++i) p[i] = (__float_as_uint(acc[8 * b + i]) & 0xFFFFFFF8u) | (uint32_t)(7 - i);
+    const float m_lo = fmaxf(fmaxf(fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1])), __uint_as_float(p[2])), __uint_as_float(p[3]));
+    const float m_hi = fmaxf(fmaxf(fmaxf(__uint_as_float(p[4]), __uint_as_float(p[5])), __uint_as_float(p[6])), __uint_as_float(p[7]));
+    const float m = hi_ok ? fmaxf(m_lo, m_hi) : m_lo;  // rows 8-15 all padded: left out
     const uint32_t mb = __float_as_uint(m);
-    const uint32_t i3 = mb & 7u;
-    const uint32_t rib = ((i3 & 4u) << 1) + (i3 & 3u) + 4u * h;  // row in block: 8 (i / 4) + 4 h + i % 4
-    run = fmaxf(run, __uint_as_float((mb & ~idx_mask) | ((uint32_t)pos + rib)));
+    // register i = 7 - (mb & 7) holds row 8 (i / 4) + 4 h + i % 4 of the block: complemented position =
+    // idx_mask - (pos + row) = (idx_mask - pos - 11 - 4 h) + 8 (c / 4) + c % 4 with c = mb & 7
+    const uint32_t c3 = mb & 7u;
+    const uint32_t cpos = (idx_mask - (uint32_t)pos - 11u - 4u * h) + ((c3 & 4u) << 1) + (c3 & 3u);
+    const uint32_t cand = lo_ok ? ((mb & ~idx_mask) | cpos) : __float_as_uint(VS_NEG);  // rows 0-7 all padded: the block is padding
+    const auto sw = __builtin_amdgcn_permlane32_swap(cand, cand, false, false);                // this half's and the other half's candidate
+    run = fmaxf(run, fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
   };
-  auto epilogue = [&](const f32x16& acc, int nb, const VsMeta& m, auto masked_c, auto post_c, int par) {
+  auto epilogue = [&](const f32x16& acc, int nb, const VsMeta& m) {
     const int d0 = __builtin_amdgcn_readlane(m.doc, 0), d1 = __builtin_amdgcn_readlane(m.doc, 1);
     const int p0 = __builtin_amdgcn_readlane(m.pos, 0), p1 = __builtin_amdgcn_readlane(m.pos, 1);
-    fold_block(acc, 0, d0, p0, m.mw[0][0], m.mw[0][1], masked_c, post_c, par);
-    if (nb > 1) fold_block(acc, 1, d1, p1, m.mw[1][0], m.mw[1][1], masked_c, post_c, par);
+    const uint32_t l0 = __builtin_amdgcn_readlane(m.vlo, 0), l1 = __builtin_amdgcn_readlane(m.vlo, 1);
+    const uint32_t h0 = __builtin_amdgcn_readlane(m.vhi, 0), h1 = __builtin_amdgcn_readlane(m.vhi, 1);
+    fold_block(acc, 0, d0, p0, (l0 & 0xFFu) != 0u, (h0 & 0xFFu) != 0u);
+    if (nb > 1) fold_block(acc, 1, d1, p1, (l1 & 0xFFu) != 0u, (h1 & 0xFFu) != 0u);
+  };
+  // The same reduction cut into NPIECE branch-free pieces (8 per block) that the step body pins between its MFMAs, a few
+  // vector instructions per MFMA (an MFMA keeps the vector issue port for 8 of its 32 cycles).  The finished value of the
+  // CURRENT document is computed at every block and stored under an exec mask that is empty unless the block starts a new
+  // document: no branch, and an instruction with EXEC = 0 costs an issue slot only.  State between the pieces:
+  constexpr int NPIECE = 16;
+  struct { int doc, pos; bool newdoc, lo_ok, hi_ok; uint32_t p[8], mb, t, opos; float m_lo, m_hi, y; } e;
+  auto piece = [&](auto cc, const f32x16& acc, const VsMeta& m) {
+    constexpr int c = decltype(cc)::value, b = c / 8, k = c % 8;
+    if constexpr (k == 0) {
+      e.doc = __builtin_amdgcn_readlane(m.doc, b);
+      e.pos = __builtin_amdgcn_readlane(m.pos, b);
+      e.lo_ok = (__builtin_amdgcn_readlane(m.vlo, b) & 0xFFu) != 0u;
+      e.hi_ok = (__builtin_amdgcn_readlane(m.vhi, b) & 0xFFu) != 0u;
+      e.newdoc = e.doc != cur;
+    } else if constexpr (k == 1) {
+      finish_value(__float_as_uint(run), e.y, e.opos);
+    } else if constexpr (k == 2) {
+      const bool fire = e.newdoc && cur >= 0;
+      const size_t o = (size_t)(cur < 0 ? 0 : cur) * V + col;
+      asm volatile("s_mov_b64 exec, %2\n\tglobal_store_dword %0, %1, off\n\ts_mov_b64 exec, -1" ::"v"(rep + o), "v"(e.y), "s"(fire ? rep_lanes : 0ull) : "memory");
+      asm volatile("s_mov_b64 exec, %2\n\tglobal_store_short %0, %1, off\n\ts_mov_b64 exec, -1" ::"v"(argmax + o), "v"(e.opos), "s"(fire ? arg_lanes : 0ull) : "memory");
+      run = e.newdoc ? VS_NEG : run;
+      cur = e.doc;
+    } else if constexpr (k == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e.p[i] = (__float_as_uint(acc[8 * b + i]) & 0xFFFFFFF8u) | (uint32_t)(7 - i);
+    } else if constexpr (k == 4) {
+#pragma unroll
+      for (int i = 4; i < 8; ++i) e.p[i] = (__float_as_uint(acc[8 * b + i]) & 0xFFFFFFF8u) | (uint32_t)(7 - i);
+    } else if constexpr (k == 5) {
+      e.m_lo = fmaxf(fmaxf(fmaxf(__uint_as_float(e.p[0]), __uint_as_float(e.p[1])), __uint_as_float(e.p[2])), __uint_as_float(e.p[3]));
+      e.m_hi = fmaxf(fmaxf(fmaxf(__uint_as_float(e.p[4]), __uint_as_float(e.p[5])), __uint_as_float(e.p[6])), __uint_as_float(e.p[7]));
+    } else if constexpr (k == 6) {
+      e.mb = __float_as_uint(e.hi_ok ? fmaxf(e.m_lo, e.m_hi) : e.m_lo);
+      const uint32_t c3 = e.mb & 7u;
+      e.t = ((c3 & 4u) << 1) + (c3 & 3u);
+    } else {
+      const uint32_t cpos = (idx_mask - (uint32_t)e.pos - 11u - 4u * h) + e.t;
+      const uint32_t cand = e.lo_ok ? ((e.mb & ~idx_mask) | cpos) : __float_as_uint(VS_NEG);
+      const auto sw = __builtin_amdgcn_permlane32_swap(cand, cand, false, false);
+      run = fmaxf(run, fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+    }
   };
 
   // per-lane LDS read address: row (lane & 31), chunk 2 ks + h -> physical (2 ks & ~15) | ((2 ks & 15) ^ y), y = h ^ (row & 15);
@@ -290,7 +364,11 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
   // loads would otherwise land inside it and drain the fragment queue every step
   VsMeta meta_prev, meta_now;
   fetch_meta(0, meta_prev);
-  if (!DED) wait_landed(0);
+  if (!DED) {
+    wait_landed(0);
+    fix_stage(0, load_mask8(0));
+    if (1 < nsteps) fix_stage(1, load_mask8(1));
+  }
   __builtin_amdgcn_s_barrier();  // barrier(0): stages 0 and 1 are in LDS
   asm volatile("" ::: "memory");
   if (!DED && NST - 1 < nsteps) issue(NST - 1);
@@ -302,44 +380,79 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
   // one 32-row step: KS MFMAs into `acc` (zeroed here).  FIRST = step 0 (barrier(0) already passed, nothing to reduce);
   // otherwise barrier(s) sits behind the 5th MFMA and the reduction of the PREVIOUS step's accumulators (both of its
   // blocks exist: it is not the last step) rides under this step's MFMAs -- the body is one basic block
-  auto step = [&](int s, f32x16& acc, const f32x16& prev, auto first_c, auto masked_c) {
+  auto step = [&](int s, f32x16& acc, const f32x16& prev, auto first_c) {
     constexpr bool FIRST = decltype(first_c)::value;
+    constexpr int E0 = BAR_KS + 1;                          // first MFMA gap that carries reduction pieces
+    constexpr int CPK = (NPIECE + (KS - E0) - 1) / (KS - E0);   // pieces per gap (1 at KS = 24)
     const uint32_t sb = (uint32_t)((s % NST) * C::STAGE), sb_next = (uint32_t)(((s + 1) % NST) * C::STAGE);
-    if constexpr (!FIRST) fetch_meta(s, meta_now);  // consumed one step from now
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#ifdef VS_EXP_CSTAMP
+    unsigned long long tq[4];
+#endif
     vs_static_for<0, KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
+#ifdef VS_EXP_CSTAMP
+      if constexpr (ks % 8 == 0) asm volatile("s_memtime %0" : "=s"(tq[ks / 8]));
+#endif
+#ifndef VS_EXP_NOREAD
       vs_wait_frag<D - 1>(a[ks % D]);
+#endif
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], fb[ks], acc, 0, 0, 0);
-      if constexpr (ks == 4 && !FIRST) {
+      if constexpr (ks == BAR_KS && !FIRST) {
         // barrier(s): every read of stage s - 1 has returned (its MFMAs were issued in the previous step); afterwards stage
         // s + 1 is in LDS and the loaders refill the slot of stage s - 1
-        if (!DED) wait_landed(s);
+        if (!DED) {
+          wait_landed(s);
+          if (s + 1 < nsteps) fix_stage(s + 1, load_mask8(s + 1));
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (!DED && s + NST - 1 < nsteps) issue(s + NST - 1);
       }
+#ifdef VS_EXP_NOREAD
+      if constexpr (false) {
+#else
       if constexpr (ks + D < KS) {
         VS_READ(ks + D, sb);
       } else {
+#endif
         // the first D fragments of the next stage (in LDS since barrier(s)); past the last stage this re-reads stale LDS, which
         // keeps the lgkmcnt arithmetic of vs_wait_frag (D - 1 younger reads) valid and is never used
+#ifndef VS_EXP_NOREAD
         VS_READ(ks + D - KS, sb_next);
+#endif
       }
-      if constexpr (ks == 6 && !FIRST) epilogue(prev, 2, meta_prev, masked_c, std::integral_constant<bool, DED>{}, s & 1);
+      if constexpr (!FIRST) {
+#ifndef VS_EXP_NOEPI
+        if constexpr (ks == 0) fetch_meta(s, meta_now);  // consumed one step from now
+        if constexpr (DED) {
+          if constexpr (ks >= E0) {
+            vs_static_for<(ks - E0) * CPK, ((ks - E0 + 1) * CPK < NPIECE ? (ks - E0 + 1) * CPK : NPIECE)>([&](auto cc) { piece(cc, prev, meta_prev); });
+          }
+        } else {
+          if constexpr (ks == E0) epilogue(prev, 2, meta_prev);
+        }
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);  // nothing moves between MFMA gaps: the pieces stay where they were put
     });
+#ifdef VS_EXP_CSTAMP
+    asm volatile("s_memtime %0" : "=s"(tq[3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tq[0]), "+s"(tq[1]), "+s"(tq[2]), "+s"(tq[3]) : : "memory");
+    if (blockIdx.x == 17 && w == 0 && s < 2048 && lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vs_stamps[s * 8 + q] = tq[q];
+    }
+#endif
     if constexpr (!FIRST) meta_prev = meta_now;
   };
   constexpr std::true_type T_{};
   constexpr std::false_type F_{};
   f32x16 acc0, acc1;
-  step(0, acc0, acc0, T_, F_);
+  step(0, acc0, acc0, T_);
   // steps 1 .. nsteps - 1, two per iteration so that the accumulators ping-pong without copies
-  auto one = [&](int s, f32x16& acc, const f32x16& prev) {
-    if (any_masked(meta_prev)) step(s, acc, prev, F_, T_);
-    else step(s, acc, prev, F_, F_);
-  };
+  auto one = [&](int s, f32x16& acc, const f32x16& prev) { step(s, acc, prev, F_); };
   int s = 1;
   for (; s + 1 < nsteps; s += 2) {
     one(s, acc1, acc0);
@@ -348,17 +461,13 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
   // the last step's blocks (the second one may not exist) and the last document are finished here, with branches
   auto finish = [&](const f32x16& acc) {
     // the last step's look-ahead reads are still in flight: their destination registers must stay reserved until they land
-    static_assert(D == 8, "the operand list below names all D fragments");
+    static_assert(D >= 8, "the operand list below names the first 8 fragments");
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
                  :
                  : "memory");
-    if (DED) {
-      __builtin_amdgcn_s_barrier();  // hands the mailbox of the last in-loop reduction to the loader waves
-      asm volatile("" ::: "memory");
-    }
-    epilogue(acc, nblk - 2 * (nsteps - 1), meta_prev, T_, F_, 0);
-    if (cur >= 0) store_doc(cur, __float_as_uint(fmaxf(run, __shfl_xor(run, 32, 64))));
+    epilogue(acc, nblk - 2 * (nsteps - 1), meta_prev);
+    if (cur >= 0) store_doc(cur, __float_as_uint(run));
   };
   if (s < nsteps) {
     one(s, acc1, acc0);
@@ -415,4 +524,7 @@ int sm_head_fwd_vs_try(int dtype, const void* t, const void* E, const float* bia
     default: return vs_launch<768>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, st);
   }
 }
+#if defined(VS_EXP_STAMP) || defined(VS_EXP_CSTAMP)
+extern "C" int sm_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vs_stamps), sizeof(vs_stamps)); }
+#endif
 bool sm_head_fwd_vs_takes(int dtype, int H, int S) { return vs_eligible(dtype, H, S, nullptr, nullptr); }
