@@ -1473,11 +1473,15 @@ extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, 
 // 256 CUs, otherwise 8 ranges (~30 vocab tiles each) so the last round is short
 // bf16 at the supported hidden sizes: the vocabulary-stationary kernel of head_fwd.hip (no scratch, rep / argmax written once)
 int sm_head_fwd_vs_try(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask, float* rep, uint16_t* argmax,
-                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
+                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, uint64_t* scratch, hipStream_t st);
 bool sm_head_fwd_vs_takes(int dtype, int H, int S);
+int sm_head_fwd_wide_try(int dtype, const void* t, const void* E, const float* bias, const uint8_t* mask, float* rep, uint16_t* argmax,
+                         int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
+bool sm_head_fwd_wide_takes(int dtype, int H, int S);
 
 extern "C" long sm_sparse_head_fwd_scratch_bytes(int dtype, int B, int S, int H, int V, int ragged) {
-  if (!ragged || sm_head_fwd_vs_takes(dtype, H, S)) return 0;
+  if (sm_head_fwd_vs_takes(dtype, H, S)) return 4L * ((long)B * S / 16 + 64);  // one packed word per 16-row block
+  if (!ragged || sm_head_fwd_wide_takes(dtype, H, S)) return 0;
   return (long)B * V * (long)sizeof(uint64_t);
 }
 
@@ -1490,7 +1494,9 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(dtype == SM_BF16 || dtype == SM_F32, "sm_sparse_head_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   {
-    const int r = sm_head_fwd_vs_try(dtype, t, E, bias, mask, rep, argmax, B, S, H, V, use_l0, rag, st);
+    int r = sm_head_fwd_vs_try(dtype, t, E, bias, mask, rep, argmax, B, S, H, V, use_l0, rag, scratch, st);
+    if (r <= 0) return r;
+    r = sm_head_fwd_wide_try(dtype, t, E, bias, mask, rep, argmax, B, S, H, V, use_l0, rag, st);
     if (r <= 0) return r;
   }
   const int xcd_on = 1;

@@ -166,7 +166,7 @@ def sparse_head_fwd(t: Tensor, E: Tensor, bias: Tensor, mask: Tensor, B: int, S:
     rep = _new((B, V), torch.float32, t)
     argmax = _new((B, V), torch.int16, t)  # u16 payload
     nbytes = L.load().sm_sparse_head_fwd_scratch_bytes(L.dtype_code(t.dtype), B, S, H, V, int(rag is not None))
-    scratch = _new((nbytes // 8,), torch.int64, t) if nbytes else None
+    scratch = _new(((nbytes + 7) // 8,), torch.int64, t) if nbytes else None
     L.call("sm_sparse_head_fwd", L.dtype_code(t.dtype), L.ptr(t), L.ptr(E), L.ptr(bias), L.ptr(mask), L.ptr(rep),
            L.ptr(argmax), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(scratch), L.stream_ptr())
     return rep, argmax

@@ -4,6 +4,9 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opensearch-sparse-model-tuning-sample_amd")]
+from sparse_hip import lib as _L
+if os.environ.get('SM_LIB'):
+    _L._LIB_PATH = os.environ['SM_LIB']
 from sparse_hip import ops
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 dense = len(sys.argv) > 2
@@ -47,3 +50,27 @@ for b in (0, 1, 17, 255, 511):
     live = want > 0
     bad = int(((picked < lg.max(0).values - 0.05) & live).sum())
     print(f"doc {b} len {int(lens[b])}: max |rep err| {err:.2e}, argmax misses {bad}, pos out of range {int((amx[live] >= int(lens[b])).sum())}")
+if os.environ.get("SM_STAMPS"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * (8 * 2048))()
+    _L.load().sm_debug_stamps(buf)
+    a = np.array(buf, dtype=np.int64).reshape(2048, 8)[:, :6]
+    a = a[20:1200]
+    d = np.diff(a, axis=1)
+    loop = a[1:, 0] - a[:-1, 0]
+    names = ["wait_landed", "fix", "barrier wait", "issue", "mask prefetch"]
+    print("loader wave, cycles (s_memtime ticks) per step: mean / p50 / p90")
+    for i, n in enumerate(names):
+        print(f"  {n:14s} {d[:, i].mean():8.0f} {np.percentile(d[:, i], 50):8.0f} {np.percentile(d[:, i], 90):8.0f}")
+    print(f"  whole iteration {loop.mean():8.0f} {np.percentile(loop, 50):8.0f} {np.percentile(loop, 90):8.0f}")
+if os.environ.get("SM_CSTAMPS"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * (8 * 2048))()
+    _L.load().sm_debug_stamps(buf)
+    a = np.array(buf, dtype=np.int64).reshape(2048, 8)[:, :4]
+    a = a[20:1200]
+    d = np.diff(a, axis=1)
+    loop = a[1:, 0] - a[:-1, 0]
+    for i, n in enumerate(["MFMA 0-7", "MFMA 8-15", "MFMA 16-23"]):
+        print(f"  {n:14s} {d[:, i].mean():8.0f} {np.percentile(d[:, i], 50):8.0f} {np.percentile(d[:, i], 90):8.0f}")
+    print(f"  whole step     {loop.mean():8.0f} {np.percentile(loop, 50):8.0f} {np.percentile(loop, 90):8.0f}")
