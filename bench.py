@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="also time the oracle on configs[1] at FULL shape (32 x 16 docs, 2 steps; ~36 GB of host RAM, minutes)")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--only-value-layout", action="store_true", help="profiling runs: do not time the other layout")
     return ap.parse_args()
 
 
@@ -336,7 +337,7 @@ def main():
 
     from sparse_hip import ops
     other = "dense" if args.layout == "ragged" else "ragged"
-    trainer, cfg, batches = build_trainer(args, device, rank, layouts=(args.layout, other))
+    trainer, cfg, batches = build_trainer(args, device, rank, layouts=(args.layout,) if args.only_value_layout else (args.layout, other))
 
     def barrier():
         if world > 1:
@@ -367,7 +368,7 @@ def main():
         elapsed = timed(args.layout, kt)   # <- the line's `value`
         head_ms = kt.mean_ms()
         rows = list(kt.rows)
-    elapsed_other = timed(other)           # the other layout, outside the headline region
+    elapsed_other = float("nan") if args.only_value_layout else timed(other)  # the other layout, outside the headline region
     gemm_lines = None
     if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
         with GemmRoofline(ops) as gr:

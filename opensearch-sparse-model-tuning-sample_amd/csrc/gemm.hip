@@ -1333,15 +1333,15 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.drop = make_drop(epi ? &epi->drop : nullptr);
   e.residual = epi ? epi->residual : nullptr;
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
-  static const int xcd_on = getenv("SM_XCD") ? atoi(getenv("SM_XCD")) : 1;
+  constexpr int xcd_on = 1;
   e.xcd = xcd_on;
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
-  static const int nt192 = getenv("SM_NT192") ? atoi(getenv("SM_NT192")) : 1;
+  constexpr int nt192 = 1;
   if constexpr (sizeof(T) == 2) {
-    static const int nt192_mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
-    static const int nt192_multi = getenv("SM_NT192_MULTI") ? atoi(getenv("SM_NT192_MULTI")) : 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
+    constexpr int nt192_mink = 1024;
+    constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
     if (nt192 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
@@ -1353,7 +1353,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     }
   }
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
-  static const int glds_on = getenv("SM_GLDS") ? atoi(getenv("SM_GLDS")) : 1;
+  constexpr int glds_on = 1;
   if (glds_on)
     hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
   else
@@ -1366,9 +1366,9 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
                    float* colsum, hipStream_t st) {
   const int tiles = sm_cdiv(N, 128) * sm_cdiv(Kc, 128);
   constexpr int BKM = Tn<T>::BKM;
-  static const int tn_glds = getenv("SM_TN_GLDS") ? atoi(getenv("SM_TN_GLDS")) : 4;  // LDS-DMA ring depth (0 = register-staged kernel)
-  static const int tn_blocks = getenv("SM_TN_BLOCKS") ? atoi(getenv("SM_TN_BLOCKS")) : (tn_glds ? 256 : 1024);
-  static const int tn_xcd = getenv("SM_TN_XCD") ? atoi(getenv("SM_TN_XCD")) : 1;
+  constexpr int tn_glds = 4;  // LDS-DMA ring depth (0 = register-staged kernel)
+  constexpr int tn_blocks = (tn_glds ? 256 : 1024);
+  constexpr int tn_xcd = 1;
   // token splits: about tn_blocks workgroups in total, at least 4 stages each, a multiple of 8 when there
   // are enough of them so that tn_block_map can give every split its own XCD
   auto plan = [&](int target, int bkm, int& nsplit, int& rps) {
@@ -1424,8 +1424,8 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
 extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, void* stream) {
-  static const int fuse = getenv("SM_LN_FUSE") ? atoi(getenv("SM_LN_FUSE")) : 1;
-  static const int mink = getenv("SM_NT192_MINK") ? atoi(getenv("SM_NT192_MINK")) : 1024;
+  constexpr int fuse = 1;
+  constexpr int mink = 1024;
   if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 256) return 1;
   const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)residual | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_drop |
                        (uintptr_t)gamma;
@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(512) void head_de128_kernel(const float* __restrict
 }
 
 int sm_head_de_eligible(int dtype, const void* t, const float* dE, int B, int S, int H, int V, const sm_ragged* rag) {
-  static const int de128 = getenv("SM_DE128") ? atoi(getenv("SM_DE128")) : 1;
+  constexpr int de128 = 1;
   const long T = rag ? rag->rows : (long)B * S;
   return de128 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && B <= 65535 && T % 16 == 0 && T / 16 <= DE_MAXBLK &&
          ((uintptr_t)t % 16) == 0 && ((uintptr_t)dE % 16) == 0 && (rag || S % 16 == 0);
@@ -1957,7 +1957,7 @@ int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const 
   const int32_t* doc_off = rag ? rag->doc_off : nullptr;
   const int32_t* blk_doc = rag ? rag->blk_doc : nullptr;
   const int rrows = rag ? rag->rows : 0;
-  static const int dt192 = getenv("SM_DT192") ? atoi(getenv("SM_DT192")) : 1;
+  constexpr int dt192 = 1;
   if (dt192 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
     hipLaunchKernelGGL(head_dt192_kernel, dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,

@@ -455,7 +455,7 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   // per-CU MFMA kernels they cannot share a CU anyway and simply follow each other on the caller's stream.
   static thread_local hipStream_t side = nullptr;
   static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  static const int overlap_env = getenv("SM_HEAD_OVERLAP") ? atoi(getenv("SM_HEAD_OVERLAP")) : 1;
+  constexpr int overlap_env = 1;
   const bool overlap = overlap_env && !sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag);
   hipStream_t st_de = st;
   if (overlap) {

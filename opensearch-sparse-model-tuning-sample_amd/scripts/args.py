@@ -89,7 +89,24 @@ class TrainingArguments:
     dataloader_drop_last: bool = False
     dataloader_num_workers: int = 0
     log_level: str = "info"
+    # set by the launcher (train_ir.py) from the torchrun environment; what the dataset loaders shard by
+    world_size: int = 1
+    local_process_index: int = 0
     extra: dict = field(default_factory=dict)
+
+    # transformers.TrainingArguments keys that change the optimisation and that this step driver does not implement: setting one
+    # to a non-default value must not pass silently (the reference recipes leave all of them at their defaults)
+    _UNSUPPORTED = {"gradient_accumulation_steps": 1, "num_train_epochs": 3.0, "warmup_ratio": 0.0, "label_smoothing_factor": 0.0,
+                    "optim": "adamw_torch", "gradient_checkpointing": False}
+
+    def __post_init__(self):
+        if self.lr_scheduler_type != "linear":
+            raise ValueError(f"lr_scheduler_type={self.lr_scheduler_type!r}: only the linear warm-up / decay schedule of the "
+                             "reference recipes (train_ir.py:103-107) is implemented")
+        for key, default in self._UNSUPPORTED.items():
+            if key in self.extra and self.extra[key] not in (default, None) and not (key == "optim" and str(self.extra[key]).startswith("adamw")):
+                raise ValueError(f"TrainingArguments.{key}={self.extra[key]!r} is not supported by this step driver "
+                                 f"(only the default {default!r}): it would train with different semantics than asked for")
 
     @property
     def compute_dtype(self):
@@ -111,6 +128,8 @@ def _split(raw: dict):
         used |= set(kw)
         groups.append(kw)
     groups[2]["extra"] = {k: v for k, v in raw.items() if k not in used}
+    groups[2].pop("world_size", None)
+    groups[2].pop("local_process_index", None)
     return ModelArguments(**groups[0]), DataTrainingArguments(**groups[1]), TrainingArguments(**groups[2])
 
 

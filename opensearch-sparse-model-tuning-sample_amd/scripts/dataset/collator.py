@@ -48,6 +48,26 @@ class KnowledgeDistillDataCollator(_TextCollator):
         return out
 
 
+class KnowledgeDistillIdsDataCollator(_TextCollator):
+    """kd-ids items [query, q_id, docs, d_ids, scores] (reference collator.py:60-132).  The ids only matter to teachers that are
+    looked up in the remote embedding service (numeric teacher ids: AWS DynamoDB, outside the training kernels), so here they
+    are dropped and the texts are tokenised like kd."""
+
+    def __init__(self, tokenizer, max_length=512, teacher_tokenizer_ids=(), embedding_service=None, **kwargs):
+        if any(str(t).isdigit() for t in teacher_tokenizer_ids):
+            raise KeyError("numeric teacher ids select remote (DynamoDB) teachers, which this build does not provide")
+        super().__init__(tokenizer, max_length, teacher_tokenizer_ids)
+
+    def __call__(self, batch):
+        q, _q_id, docs, _d_ids, scores = zip(*batch)
+        assert len(docs) == len(scores)
+        out = self._encode_all(q, list(itertools.chain.from_iterable(docs)))
+        if scores[0][0] is not None:
+            out["scores"] = torch.tensor(scores)
+        return out
+
+
 from .synthetic import PreTokenizedCollator  # noqa: E402
 
-COLLATOR_CLS_MAP = {"kd": KnowledgeDistillDataCollator, "posnegs": PosNegsDataCollator, "synthetic": PreTokenizedCollator}
+COLLATOR_CLS_MAP = {"kd": KnowledgeDistillDataCollator, "posnegs": PosNegsDataCollator, "kd-ids": KnowledgeDistillIdsDataCollator,
+                    "synthetic": PreTokenizedCollator}

@@ -227,6 +227,9 @@ class SparseModelTrainer:
         if self.accelerator.is_main_process:
             self.accelerator.unwrap_model(self.model).save(
                 output_dir, state_dict=state_dict, safe_serialization=getattr(self.args, "save_safetensors", True))
+            if self._adam is not None:  # what a resume needs besides the weights: AdamW moments and the step counter
+                torch.save({"global_step": self.state.global_step, **{k: v.detach().cpu() for k, v in self._adam.items()}},
+                           os.path.join(output_dir, "trainer_state.pt"))
 
     def set_bi_encoder_teacher(self, embedding_service=None):
         from .bi_encoder_wrapper import BiEncoderWrapper
@@ -245,6 +248,13 @@ class SparseModelTrainer:
         from torch.utils.data import DataLoader, RandomSampler
         from torch.utils.data.distributed import DistributedSampler
 
+        common = dict(collate_fn=self.data_collator, num_workers=self.args.dataloader_num_workers, pin_memory=True)
+        from ..dataset.dataset import CombinedDataset, CombinedRandomSampler
+        if isinstance(self.train_dataset, CombinedDataset):
+            # every batch from one member dataset, members already sharded by rank (reference trainer.py:204-217)
+            logger.info("Combined dataset. Set combined sampler.")
+            return DataLoader(self.train_dataset, batch_sampler=CombinedRandomSampler(
+                self.train_dataset.datasets, batch_size=self.args.per_device_train_batch_size), **common)
         if self.accelerator.num_processes > 1 and not getattr(self.train_dataset, "no_prepare", False):
             sampler = DistributedSampler(self.train_dataset, num_replicas=self.accelerator.num_processes,
                                          rank=self.accelerator.process_index, shuffle=True, seed=self.args.seed,
@@ -254,8 +264,7 @@ class SparseModelTrainer:
             g.manual_seed(self.args.seed)
             sampler = RandomSampler(self.train_dataset, generator=g)
         return DataLoader(self.train_dataset, batch_size=self.args.per_device_train_batch_size, sampler=sampler,
-                          collate_fn=self.data_collator, drop_last=self.args.dataloader_drop_last,
-                          num_workers=self.args.dataloader_num_workers, pin_memory=True)
+                          drop_last=self.args.dataloader_drop_last, **common)
 
     # ------------------------------------------------------------------ step driver
     def _prepare_inputs(self, obj):
@@ -352,6 +361,12 @@ class SparseModelTrainer:
             return
         step = self.state.global_step  # scheduler has been stepped `step` times so far
         lr = linear_schedule_lr(step, a.learning_rate, a.warmup_steps, a.max_steps)
+        if a.max_grad_norm:  # hf trainer.py:1780-1782 clip_grad_norm_ on the averaged gradients; no host sync: the factor stays on the device
+            grads = [bb.flat_grad] + ([sm.idf_vector.grad] if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None else [])
+            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads])) / n
+            coef = torch.clamp(float(a.max_grad_norm) / (norm + 1e-6), max=1.0).reshape(1)
+            for g in grads:
+                ops.scale_by(g.view(-1), coef)
         if self._adam is None:
             self._adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
             if sm.idf_vector.requires_grad:
@@ -365,6 +380,13 @@ class SparseModelTrainer:
             ops.adamw(sm.idf_vector.data, sm.idf_vector.grad, self._adam["im"], self._adam["iv"], lr_i, a.adam_beta1,
                       a.adam_beta2, a.adam_epsilon, a.weight_decay, step + 1, 1.0 / n)
         bb.mark_weights_dirty()
+
+    def load_trainer_state(self, checkpoint_dir: str) -> None:
+        """resume: AdamW moments + global_step written by _save next to the HF-format weights"""
+        st = torch.load(os.path.join(checkpoint_dir, "trainer_state.pt"), map_location="cpu")
+        self.state.global_step = int(st.pop("global_step"))
+        dev = self.model.sparse_model.backbone.device
+        self._adam = {k: v.to(dev) for k, v in st.items()}
 
     def zero_grad(self):
         sm = self.model.sparse_model

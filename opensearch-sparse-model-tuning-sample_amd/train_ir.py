@@ -33,7 +33,9 @@ def init_distributed():
     return world, local
 
 
-def load_training_dataset(data_args, model):
+def load_training_dataset(data_args, training_args, model):
+    """train_file: synthetic -> the built-in MS-MARCO-shaped generator; otherwise the reference's two forms
+    (train_ir.py:109-127): one dataset (`train_file`) or a directory of datasets sharded by rank (`train_file_dir`)"""
     if data_args.train_file == "synthetic":
         from scripts.dataset.synthetic import SyntheticTriplesDataset
 
@@ -41,8 +43,15 @@ def load_training_dataset(data_args, model):
         return SyntheticTriplesDataset(data_args.synthetic_samples, k, data_args.max_seq_length,
                                        data_args.synthetic_query_len, model.vocab_size,
                                        with_scores=data_args.data_type == "kd" and not data_args.kd_ensemble_teacher_kwargs)
-    raise ValueError("only train_file: synthetic is wired in this build (text datasets are host-side plumbing: "
-                     "feed any torch Dataset yielding (query, pos, negs) / (query, docs, scores) to SparseModelTrainer)")
+    from scripts.dataset.dataset import load_dataset, load_datasets
+
+    kw = dict(cls=data_args.data_type, swap_times=data_args.swap_times, sample_num_one_query=data_args.sample_num_one_query,
+              first_rank_thresh=data_args.first_rank_thresh)
+    if data_args.train_file is not None:
+        return load_dataset(path=data_args.train_file, **kw)
+    if data_args.train_file_dir is not None:
+        return load_datasets(path=data_args.train_file_dir, training_args=training_args, **kw)
+    raise ValueError("train_file or train_file_dir must be specified")
 
 
 def main():
@@ -62,7 +71,8 @@ def main():
     loss_functions = [LOSS_CLS_MAP[t](use_in_batch_negatives=data_args.use_in_batch_negatives,
                                       weight=data_args.ranking_loss_weight, temperature=data_args.temperature)
                       for t in data_args.loss_types]
-    dataset = load_training_dataset(data_args, model)
+    training_args.world_size, training_args.local_process_index = world, local
+    dataset = load_training_dataset(data_args, training_args, model)
     trainer = SparseModelTrainer(model_args=model_args, data_args=data_args, model=model, args=training_args,
                                  train_dataset=dataset, data_collator=data_collator, loss_functions=loss_functions)
     if len(data_args.kd_ensemble_teacher_kwargs) != 0:

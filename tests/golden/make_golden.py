@@ -404,6 +404,84 @@ def g6_g8(tmp, idf, rng):
     return res
 
 
+def _g7_worker(rank, world, tmp, idf, raw, case, port, out_path):
+    """one rank of the 2-process reference run: its half of the global batch through SparseModelTrainer.compute_loss"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, REF)
+    install_stubs()
+    os.chdir(REF)
+    torch.set_num_threads(2)
+    mkw, dkw, lts = case
+    trainer, model, _, _ = make_trainer(tmp, idf, mkw, dkw, lts)
+    assert trainer.accelerator.num_processes == world, trainer.accelerator.num_processes
+    trainer.model.train()
+    nq, k = raw["q_ids"].shape[0] // world, raw["d_ids"].shape[0] // raw["q_ids"].shape[0]
+    sq, sd = slice(rank * nq, (rank + 1) * nq), slice(rank * nq * k, (rank + 1) * nq * k)
+    inp = {"query": [{"input_ids": torch.tensor(raw["q_ids"][sq]), "attention_mask": torch.tensor(raw["q_mask"][sq])}],
+           "docs": [{"input_ids": torch.tensor(raw["d_ids"][sd]), "attention_mask": torch.tensor(raw["d_mask"][sd])}]}
+    if "scores" in raw:
+        inp["scores"] = torch.tensor(raw["scores"][sq])
+    trainer.state.global_step = 3
+    loss, outputs = trainer.compute_loss(trainer.model, inp, return_outputs=True)
+    loss.backward()
+    grads = {n: p.grad.numpy().copy() for n, p in model.backbone.named_parameters() if n in G7_GRADS and p.grad is not None}
+    np.savez(out_path + f".rank{rank}.npz", loss=loss.detach().numpy(), d_rep=outputs["d_rep"].detach().numpy(),
+             q_rep=outputs["q_rep"].detach().numpy(), **{"grad/" + n: g for n, g in grads.items()})
+    import torch.distributed as dist
+    dist.barrier()
+
+
+G7_GRADS = ("bert.embeddings.word_embeddings.weight", "bert.encoder.layer.0.attention.self.query.weight",
+            "bert.encoder.layer.1.output.dense.weight", "cls.predictions.bias", "cls.predictions.transform.LayerNorm.weight")
+
+
+def g7():
+    """the reference's gather_rep (scripts/utils.py:16-23) + compute_loss (scripts/train/trainer.py:81-143) run
+    by TWO gloo processes on the halves of a global batch, against ONE process on the concatenated batch: per-rank loss
+    (x num_processes), gathered representations, and the DDP-mean of the per-rank gradients must equal the single-process
+    gradients -- the invariant the build's data-parallel path is tested against.      [python make_golden.py g7]"""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, REF)
+    install_stubs()
+    os.chdir(REF)
+    tmp = tempfile.mkdtemp(prefix="golden_g7_")
+    out = {}
+    try:
+        build_model_dir(tmp, seed=0)
+        idf = {t: float(v) for t, v in zip(vocab_tokens(), np.load(os.path.join(HERE, "g2_inf_free.npz"))["idf_vector"])}
+        rng = np.random.default_rng(77)
+        cases = {
+            "infonce_ibn": (dict(inf_free=True), dict(use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10), ["infonce"]),
+            "kldiv_pairs_thr": (dict(inf_free=True), dict(use_in_batch_negatives=False, flops_d_lambda=0.05, flops_d_T=10, flops_threshold=3), ["kldiv"]),
+        }
+        for ci, (name, case) in enumerate(cases.items()):
+            _, raw = batch_inputs(rng, 6, 3 if ci == 0 else 4, 8, 16, with_scores=ci == 1)  # k = 3: two ranks do not divide it
+            for key, val in raw.items():
+                out[f"{name}/{key}"] = val
+            # one process, concatenated batch
+            base = os.path.join(tmp, name)
+            mp.spawn(_g7_worker, args=(1, tmp, idf, raw, case, 29710 + ci, base + ".one"), nprocs=1, join=True)
+            mp.spawn(_g7_worker, args=(2, tmp, idf, raw, case, 29720 + ci, base + ".two"), nprocs=2, join=True)
+            one = np.load(base + ".one.rank0.npz")
+            two = [np.load(base + f".two.rank{r}.npz") for r in range(2)]
+            out[f"{name}/loss_one"] = one["loss"]
+            out[f"{name}/loss_rank0"], out[f"{name}/loss_rank1"] = two[0]["loss"], two[1]["loss"]
+            out[f"{name}/d_rep"] = one["d_rep"]
+            for key in [k2 for k2 in one.files if k2.startswith("grad/")]:
+                out[f"{name}/{key}"] = one[key]
+                ddp_mean = (two[0][key] + two[1][key]) / 2
+                err = float(np.abs(ddp_mean - one[key]).max())
+                print(f"G7 {name} {key}: |DDP mean of 2 ranks - 1 process| = {err:.2e} (max |g| {np.abs(one[key]).max():.2e})")
+                assert err <= 1e-5 * max(1.0, float(np.abs(one[key]).max())), "reference invariant violated?"
+                out[f"{name}/ddp_mean_{key}"] = ddp_mean.astype(np.float32)
+            print(f"G7 {name}: loss one {float(one['loss']):.6f}, ranks {float(two[0]['loss']):.6f} {float(two[1]['loss']):.6f} (= 2 x one)",
+                  float(np.abs(two[0]["d_rep"] - one["d_rep"]).max()))
+        np.savez_compressed(os.path.join(HERE, "g7_gather.npz"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("g7_gather.npz", os.path.getsize(os.path.join(HERE, "g7_gather.npz")))
+
+
 def g9():
     """inference-side extraction: what the reference's post-processor returns per row"""
     install_stubs()
@@ -429,6 +507,10 @@ def g9():
     np.savez_compressed(os.path.join(HERE, "g9_postprocess.npz"), x=x, nnz=nnz, cols=cols, vals=vals)
     print("g9_postprocess.npz", nnz.tolist())
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g7":
+    g7()
+    sys.exit(0)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g9":

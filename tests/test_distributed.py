@@ -108,6 +108,62 @@ print("done", rank)
 """
 
 
+G7_WORKER = r"""
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(90, exit=True)
+import numpy as np, torch, torch.distributed as dist
+root, pkg, out = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path[:0] = [root, pkg]
+torch.cuda.set_device(0)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+rank = dist.get_rank() if world > 1 else 0
+from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+from scripts.model.sparse_encoders import SparseModel
+from scripts.train.loss import LOSS_CLS_MAP
+from scripts.train.trainer import SparseModelTrainer
+from sparse_hip.encoder import BertConfigLite, HipBertMLM
+g1 = np.load(os.path.join(root, "tests", "golden", "g1_encode.npz"))
+g2 = np.load(os.path.join(root, "tests", "golden", "g2_inf_free.npz"))
+g7 = np.load(os.path.join(root, "tests", "golden", "g7_gather.npz"))
+name = os.environ["SM_TEST_CASE"]
+cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None)
+bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
+model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
+kind = "infonce" if name == "infonce_ibn" else "kldiv"
+ibn = name == "infonce_ibn"
+dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10,
+                              flops_threshold=None if ibn else 3)
+trainer = SparseModelTrainer(model_args=ModelArguments(model_name_or_path="x", inf_free=True), data_args=dargs, model=model,
+                             args=TrainingArguments(output_dir="/tmp/sm_dist", logging_steps=1000),
+                             loss_functions=[LOSS_CLS_MAP[kind](use_in_batch_negatives=ibn, weight=1, temperature=1.0)])
+t = lambda k: torch.tensor(g7[name + "/" + k])
+nq, nd = t("q_ids").shape[0] // world, t("d_ids").shape[0] // world
+sq, sd = slice(rank * nq, (rank + 1) * nq), slice(rank * nd, (rank + 1) * nd)
+inp = {"query": [{"input_ids": t("q_ids")[sq].cuda(), "attention_mask": t("q_mask")[sq].cuda()}],
+       "docs": [{"input_ids": t("d_ids")[sd].cuda(), "attention_mask": t("d_mask")[sd].cuda()}]}
+if name + "/scores" in g7.files:
+    inp["scores"] = t("scores")[sq]
+trainer.state.global_step = 3
+trainer.model.train()
+trainer.zero_grad()
+loss = trainer.compute_loss(trainer.model, inp)
+loss.backward()
+trainer._finish_grad_reduce()   # SUM over ranks of d(loss x N)/d theta
+torch.cuda.synchronize()
+if rank == 0:
+    grads = {"grad/" + n[len(name) + 6:]: (bb.view(n[len(name) + 6:], grad=True) / world).cpu().numpy()
+             for n in g7.files if n.startswith(name + "/grad/")}
+    np.savez(out, loss=float(loss), **grads)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print("done", rank)
+"""
+
+
 SUBPROCESS_TIMEOUT = 120  # seconds per leg: a stalled leg must not eat the suite's time budget
 
 
@@ -144,6 +200,31 @@ def _two_rank_case(tmp_path, case, backend, ports):
         # differences on a handful of elements, everything else must agree to fp32 accuracy
         assert (diff > 1e-4).sum() <= 1e-3 * diff.size, (mode, int((diff > 1e-4).sum()))
         assert diff.max() <= 2.5e-3, mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["infonce_ibn", "kldiv_pairs_thr"])
+def test_two_rank_gradients_match_the_reference_two_process_run(tmp_path, name):
+    """golden G7: the REFERENCE run by two gloo processes (gather_rep + compute_loss, scripts/utils.py:16-23,
+    trainer.py:81-143).  Two ranks of the HIP path on the same halves of the batch must report the reference's per-rank
+    loss (x num_processes) and, after the gradient all-reduce and the 1/N of the DDP mean, the reference's gradients --
+    in both exchange modes (k = 3 documents per query in the in-batch case: the rank count does not divide it)."""
+    g7 = np.load(os.path.join(GOLDEN, "g7_gather.npz"))
+    script = tmp_path / "worker.py"
+    script.write_text(G7_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_TEST_CASE=name)
+    for port, mode in ((29561 if name == "infonce_ibn" else 29565, "gather"), (29563 if name == "infonce_ibn" else 29567, "scores")):
+        two = str(tmp_path / f"two_{mode}.npz")
+        r2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                   "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two], dict(env, SM_EXCHANGE=mode))
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        b = np.load(two)
+        want = float(g7[f"{name}/loss_rank0"])
+        assert abs(float(b["loss"]) - want) <= 1e-3 * (1 + abs(want)), (mode, float(b["loss"]), want)
+        for key in [k for k in b.files if k.startswith("grad/")]:
+            ref = g7[f"{name}/{key}"]
+            err = np.abs(b[key] - ref).max()
+            assert err <= 2e-3 * max(1.0, np.abs(ref).max()), (mode, key, float(err))
 
 
 CASES = ["infonce_ibn", "infonce_ibn_k3", "kd_pairs", "learned_queries"]

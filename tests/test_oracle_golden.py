@@ -156,6 +156,50 @@ def test_g6_compute_loss(name):
                 close(p[k[len(pre):]].grad, g6[k], 1e-4)
 
 
+G7_CASES = {
+    "infonce_ibn": dict(loss_types=("infonce",), use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10),
+    "kldiv_pairs_thr": dict(loss_types=("kldiv",), use_in_batch_negatives=False, flops_d_lambda=0.05, flops_d_T=10, flops_threshold=3),
+}
+
+
+@pytest.mark.parametrize("name", list(G7_CASES))
+def test_g7_two_process_reference_run(name):
+    """G7 = the reference run by TWO gloo processes (scripts/utils.py:16-23 gather_rep + trainer.py:81-143) next to one process on
+    the concatenated batch.  The oracle's per-rank view (gather_rep_sim: every shard detached but the rank's own) must give
+    each rank's loss (x num_processes) and, as the DDP mean over ranks, the single-process gradients the reference produced."""
+    g7, g1, g2 = load("g7_gather.npz"), load("g1_encode.npz"), load("g2_inf_free.npz")
+    lc = O.LossConfig(**G7_CASES[name])
+    idf = torch.tensor(g2["idf_vector"])
+    t = lambda k: torch.tensor(g7[f"{name}/{k}"])
+    scores = t("scores") if f"{name}/scores" in g7.files else None
+    nq, nd = t("q_ids").shape[0], t("d_ids").shape[0]
+    k = nd // nq
+    # one process
+    p = sd_from(g1, requires_grad=True)
+    loss, _, _, _, d_rep = O.compute_loss(p, TINY, idf, SPECIAL, t("q_ids"), t("q_mask"), t("d_ids"), t("d_mask"), scores, lc, 3)
+    close(loss.detach(), g7[f"{name}/loss_one"], 1e-5)
+    close(d_rep.detach(), g7[f"{name}/d_rep"], 2e-5)
+    # two ranks: encode the local halves, gather, evaluate the global loss x 2, average the gradients
+    grads = []
+    for rank in range(2):
+        p = sd_from(g1, requires_grad=True)
+        sq, sd_ = slice(rank * nq // 2, (rank + 1) * nq // 2), slice(rank * nd // 2, (rank + 1) * nd // 2)
+        d_loc = [O.encode_docs(p, t("d_ids")[s_], t("d_mask")[s_], TINY) if r == rank else
+                 O.encode_docs(p, t("d_ids")[s_], t("d_mask")[s_], TINY).detach()
+                 for r, s_ in enumerate((slice(0, nd // 2), slice(nd // 2, nd)))]
+        q_loc = [O.encode_inf_free(t("q_ids")[s_], idf, SPECIAL) for s_ in (slice(0, nq // 2), slice(nq // 2, nq))]
+        d_all, q_all = O.gather_rep_sim(d_loc, rank), O.gather_rep_sim(q_loc, rank)
+        loss_r = O.total_loss(q_all, d_all, scores, lc, 3, num_processes=2)[0]
+        close(loss_r.detach(), g7[f"{name}/loss_rank{rank}"], 1e-5)
+        loss_r.backward()
+        grads.append({n: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for n, v in p.items()})
+    pre = f"{name}/grad/"
+    for key in [f for f in g7.files if f.startswith(pre)]:
+        n = key[len(pre):]
+        close((grads[0][n] + grads[1][n]) / 2, g7[key], 1e-4)
+        close(g7[f"{name}/ddp_mean_grad/{n}"], g7[key], 1e-5)  # the reference's own 2-process result
+
+
 def test_g8_adamw_three_steps():
     g8, g1, g2 = load("g8_adamw.npz"), load("g1_encode.npz"), load("g2_inf_free.npz")
     p = sd_from(g1, requires_grad=True)
