@@ -70,6 +70,27 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- erf for the bf16 epilogues: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 absolute -- three orders of magnitude inside
+// the rounding of the bf16 value it feeds -- in ~16 issue slots (v_rcp_f32, v_exp_f32, 6 FMAs) against ~40 for erff().  A GELU
+// epilogue evaluates it for every element of the [T, 1536] intermediate: at 44k token rows that is ~60 us of vector work
+// per GEMM with erff(), more than half the GEMM.  The fp32 parity path keeps erff().
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
+  return fmaf(x, pdf, cdf);
+}
+
 // ---- exact-erf GELU (HF hidden_act="gelu") -----------------------------------
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
@@ -77,6 +98,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// storage-type dispatch: bf16 tensors take the fast erf, fp32 (parity mode) the library one
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_f(x); }
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_fast(x) : gelu_grad_f(x); }
 
 // d rep / d logit of the sparse activation as a function of rep itself
 // (rep = log1p(y), or log1p(log1p(y)) with the L0 activation; y = relu(max logit))

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
         if (preact) store8<T>(preact + off, v, full, N - col);
         if (e.act == 1) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+          for (int k = 0; k < 8; ++k) v[k] = gelu_t<T>(v[k]);
         }
         if (e.drop.thresh16) {
           const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
           float xv[8];
           load8<T>(ggo + off, xv, full, N - col);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_f(xv[k]);
+          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
         }
         store8<T>(C + off, v, full, N - col);
       }
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
         if (preact) store8<bf16>(preact + off, v, true, 8);
         if (e.act == 1) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+          for (int q = 0; q < 8; ++q) v[q] = gelu_t<bf16>(v[q]);
         }
         if (e.drop.thresh16) {
           const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
           float xv[8];
           load8<bf16>(ggo + off, xv, true, 8);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_f(xv[q]);
+          for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_t<bf16>(xv[q]);
         }
         store8<bf16>(C + off, v, true, 8);
       }

@@ -263,7 +263,7 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_grad_f(to_f32<T>(x[i])));
+    dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_grad_t<T>(to_f32<T>(x[i])));
 }
 
 inline int row_grid16(int rows) {
