@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 1
+#define SM_ABI_VERSION 2
 #define SM_F32 0
 #define SM_BF16 1
 
@@ -78,6 +78,8 @@ typedef struct sm_epilogue {
   sm_dropout drop;          /* hf:291/349 hidden dropout */
   const void* residual;     /* [M,N] (ldc) dtype, or NULL (hf:292/350 residual add) */
   const void* gelu_grad_of; /* [M,N] (ldc) dtype, or NULL (backward of hf:336) */
+  int residual_f32;         /* 1: `residual` is fp32 whatever dtype says   } the fp32 RESIDUAL STREAM of bf16 runs: what torch      */
+  int out_f32;              /* 1: C is written as fp32 whatever dtype says } autocast keeps in fp32 around hf:289-293, 347-351     */
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -118,6 +120,16 @@ int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const sm_dropout
 
 /* dx = dy * gelu'(x): backward of the MLM transform activation (hf:478) */
 int sm_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, long n, void* stream);
+
+/* fp32 residual stream (bf16 GEMM operands, fp32 pre-LayerNorm sums and LayerNorm outputs on the residual path):
+ * x32 [rows,H] fp32 in; y (dtype) for the next GEMM and, when y32 != NULL, its fp32 copy for the next residual add */
+int sm_layernorm_fwd_res32(int dtype, const float* x32, const float* gamma, const float* beta, void* y, float* y32,
+                           float* mean, float* rstd, int rows, int H, float eps, void* stream);
+int sm_embed_fwd_res32(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0, const float* gamma,
+                       const float* beta, void* z, void* y, float* y32, float* mean, float* rstd, int B, int S, int H, float eps,
+                       const sm_dropout* drop, const sm_ragged* rag, void* stream);
+int sm_layernorm_bwd_res32(int dtype, const void* dy, const float* x32, const float* gamma, const float* mean, const float* rstd,
+                           void* dx, void* dx_drop, const sm_dropout* drop, float* dgamma, float* dbeta, int rows, int H, void* stream);
 
 /* ---- self-attention (hf:111-136 eager attention + hf:164-204) ------------------------
  * qkv: [B*S, 3H] packed (q | k | v), heads are contiguous dh-slices; keymask: [B,S] 1 = attend.

@@ -276,6 +276,7 @@ struct EpiArgs {
   DropCfg drop;
   const void* residual;
   const void* gelu_grad_of;
+  int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
 };
 
 template <typename T, bool GLDS>
@@ -349,7 +350,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
         }
         if (residual) {
           float rv[8];
-          load8<T>(residual + off, rv, full, N - col);
+          if (e.res32) load8<float>(reinterpret_cast<const float*>(e.residual) + off, rv, full, N - col);
+          else load8<T>(residual + off, rv, full, N - col);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] += rv[k];
         }
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
         }
-        store8<T>(C + off, v, full, N - col);
+        if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);
+        else store8<T>(C + off, v, full, N - col);
       }
     }
   }
@@ -1333,18 +1336,20 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.drop = make_drop(epi ? &epi->drop : nullptr);
   e.residual = epi ? epi->residual : nullptr;
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  e.res32 = epi ? epi->residual_f32 : 0;
+  e.out32 = epi ? epi->out_f32 : 0;
   constexpr int xcd_on = 1;
   e.xcd = xcd_on;
   const uintptr_t vb = 8 * sizeof(T);
-  e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % vb == 0) && ((uintptr_t)e.preact % vb == 0) &&
-             ((uintptr_t)e.residual % vb == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
+  e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
+             ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
   constexpr int nt192 = 1;
   if constexpr (sizeof(T) == 2) {
     constexpr int nt192_mink = 1024;
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
-    if (nt192 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+    if (nt192 && !e.res32 && !e.out32 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
       (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
       hipLaunchKernelGGL(gemm_nt192_kernel<false>, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,

@@ -39,20 +39,22 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
   *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+// TX = type of the input rows (T, or float for the fp32 residual stream); y32: optional fp32 copy of the output
+template <typename T, int NCH, typename TX = T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int H, float eps) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int H, float eps,
+                                                     float* __restrict__ y32 = nullptr) {
   const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
   const int nch = H >> 3;
   for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
-    const T* xr = x + (size_t)row * H;
+    const TX* xr = x + (size_t)row * H;
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
       if (sl + 16 * i < nch) {
-        ld8<T>(xr + (sl + 16 * i) * 8, v[i]);
+        ld8<TX>(xr + (sl + 16 * i) * 8, v[i]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += v[i][k];
       }
@@ -74,13 +76,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
         st8<T>(y + (size_t)row * H + c0, o);
+        if (y32) st8<float>(y32 + (size_t)row * H + c0, o);
       }
     if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+template <typename T, int NCH, typename TX = T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, DropCfg drop,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int H) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       if (sl + 16 * i < nch) {
         float d[8];
         ld8<T>(dy + (size_t)row * H + (sl + 16 * i) * 8, d);
-        ld8<T>(x + (size_t)row * H + (sl + 16 * i) * 8, xh[i]);
+        ld8<TX>(x + (size_t)row * H + (sl + 16 * i) * 8, xh[i]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           xh[i][k] = (xh[i][k] - mu) * rs;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         T* __restrict__ z, T* __restrict__ y, float* __restrict__ mean,
                                                         float* __restrict__ rstd, int rows, int S, int H, float eps, DropCfg drop,
-                                                        const int32_t* __restrict__ pos_ids) {
+                                                        const int32_t* __restrict__ pos_ids, float* __restrict__ y32) {
   const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
   const int nch = H >> 3;
   for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         }
         st8<T>(z + (size_t)row * H + c0, v[i]);
         st8<T>(y + (size_t)row * H + c0, o);
+        if (y32) st8<float>(y32 + (size_t)row * H + c0, o);
       }
     if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
   }
@@ -306,6 +310,32 @@ extern "C" int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   return SM_OK;
 }
 
+extern "C" int sm_layernorm_fwd_res32(int dtype, const float* x32, const float* gamma, const float* beta, void* y, float* y32,
+                                      float* mean, float* rstd, int rows, int H, float eps, void* stream) {
+  SM_REQUIRE(rows > 0 && H % 64 == 0 && H <= 1024, "sm_layernorm_fwd_res32: rows=%d H=%d (H must be a multiple of 64, <= 1024)", rows, H);
+  hipStream_t st = (hipStream_t)stream;
+  SM_DISPATCH(dtype, "sm_layernorm_fwd_res32",
+              LN_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, float>), dim3(row_grid16(rows)), dim3(256), 0, st, x32, gamma, beta, (T*)y, mean, rstd,
+                                           rows, H, eps, y32)));
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_layernorm_bwd_res32(int dtype, const void* dy, const float* x32, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, void* dx_drop, const sm_dropout* drop, float* dgamma,
+                                      float* dbeta, int rows, int H, void* stream) {
+  SM_REQUIRE(rows > 0 && H % 64 == 0 && H <= 1024, "sm_layernorm_bwd_res32: rows=%d H=%d", rows, H);
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg d = make_drop(drop);
+  int grid = sm_cdiv(rows, 64);
+  if (grid > 512) grid = 512;
+  SM_DISPATCH(dtype, "sm_layernorm_bwd_res32",
+              LN_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, float>), dim3(grid), dim3(256), 0, st, (const T*)dy, x32, gamma, mean, rstd,
+                                           (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
 extern "C" int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, void* dx_drop, const sm_dropout* drop, float* dgamma,
                                 float* dbeta, int rows, int H, void* stream) {
@@ -321,9 +351,9 @@ extern "C" int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
   return SM_OK;
 }
 
-extern "C" int sm_embed_fwd(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0,
-                            const float* gamma, const float* beta, void* z, void* y, float* mean, float* rstd, int B,
-                            int S, int H, float eps, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
+static int embed_fwd_impl(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0,
+                          const float* gamma, const float* beta, void* z, void* y, float* y32, float* mean, float* rstd, int B,
+                          int S, int H, float eps, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && H % 64 == 0 && H <= 1024, "sm_embed_fwd: B=%d S=%d H=%d", B, S, H);
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(drop);
@@ -331,9 +361,20 @@ extern "C" int sm_embed_fwd(int dtype, const int64_t* ids, const void* word, con
   const int32_t* pos_ids = rag ? rag->pos_ids : nullptr;
   SM_DISPATCH(dtype, "sm_embed_fwd",
               LN_NCH(H, hipLaunchKernelGGL((embed_fwd_kernel<T, NCH>), dim3(row_grid16(rows)), dim3(256), 0, st, ids, (const T*)word, pos, type0,
-                                           gamma, beta, (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d, pos_ids)));
+                                           gamma, beta, (T*)z, (T*)y, mean, rstd, rows, S, H, eps, d, pos_ids, y32)));
   SM_LAUNCH_CHECK();
   return SM_OK;
+}
+extern "C" int sm_embed_fwd(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0,
+                            const float* gamma, const float* beta, void* z, void* y, float* mean, float* rstd, int B,
+                            int S, int H, float eps, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
+  return embed_fwd_impl(dtype, ids, word, pos, type0, gamma, beta, z, y, nullptr, mean, rstd, B, S, H, eps, drop, rag, stream);
+}
+extern "C" int sm_embed_fwd_res32(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0,
+                                  const float* gamma, const float* beta, void* z, void* y, float* y32, float* mean, float* rstd, int B,
+                                  int S, int H, float eps, const sm_dropout* drop, const sm_ragged* rag, void* stream) {
+  SM_REQUIRE(y32 != nullptr, "sm_embed_fwd_res32: y32 required");
+  return embed_fwd_impl(dtype, ids, word, pos, type0, gamma, beta, z, y, y32, mean, rstd, B, S, H, eps, drop, rag, stream);
 }
 
 extern "C" int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, float* gpos, float* gtype0,

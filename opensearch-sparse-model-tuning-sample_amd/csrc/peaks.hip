@@ -33,13 +33,19 @@ __global__ __launch_bounds__(256) void peak_mfma_bf16_kernel(float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n16) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
-    const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-    dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+  // one workgroup per 16 KiB: four independent 16-byte loads in flight per lane, no grid-stride loop (a long-lived grid of
+  // looping workgroups measured 4.4 TB/s, this form is the guide's float4 copy)
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  if (base + 768 < n16) {
+    const f32x4 v0 = __builtin_nontemporal_load(src + base), v1 = __builtin_nontemporal_load(src + base + 256),
+                v2 = __builtin_nontemporal_load(src + base + 512), v3 = __builtin_nontemporal_load(src + base + 768);
+    __builtin_nontemporal_store(v0, dst + base);
+    __builtin_nontemporal_store(v1, dst + base + 256);
+    __builtin_nontemporal_store(v2, dst + base + 512);
+    __builtin_nontemporal_store(v3, dst + base + 768);
+  } else {
+    for (size_t i = base; i < n16; i += 256) dst[i] = src[i];
   }
-  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
@@ -57,7 +63,7 @@ extern "C" int sm_peak_mfma_bf16(float* sink, int blocks, int iters, void* strea
 extern "C" int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream) {
   SM_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
              "sm_peak_copy: 16-byte aligned buffers and size required");
-  hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+  hipLaunchKernelGGL(peak_copy_kernel, dim3((unsigned)((bytes / 16 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

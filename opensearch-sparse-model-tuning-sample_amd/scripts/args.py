@@ -54,6 +54,8 @@ class ModelArguments:
     prune_ratio: Optional[float] = None
     preprocess_func: Optional[str] = None
     use_l0: bool = False
+    # extension (no reference key): bf16 runs keep the residual stream in fp32, as torch autocast does
+    residual_fp32: bool = False
 
     def __post_init__(self):
         if self.tokenizer_name is None:

@@ -30,6 +30,8 @@ class SmEpilogue(C.Structure):
         ("drop", SmDropout),
         ("residual", C.c_void_p),
         ("gelu_grad_of", C.c_void_p),
+        ("residual_f32", C.c_int),  # fp32 residual stream: `residual` is fp32 / C is written as fp32 whatever dtype says
+        ("out_f32", C.c_int),
     ]
 
 
@@ -52,6 +54,9 @@ SIGNATURES = {
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
+    "sm_layernorm_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "sm_layernorm_bwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
+    "sm_embed_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
     "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
     "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _rag, _p],
     "sm_dropout_bwd": [_i, _p, _p, _l, C.POINTER(SmDropout), _p],

@@ -39,15 +39,18 @@ def _rag_ref(rag):
 # ---------------------------------------------------------------- GEMMs
 def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
-            gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None) -> Tensor:
-    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables)."""
+            gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None,
+            out_f32: bool = False) -> Tensor:
+    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables).  fp32 residual stream of a
+    bf16 run: an fp32 `residual` is added in fp32 and `out_f32` writes the sum as fp32."""
     M, K = A.shape
     N = B.shape[0] if n is None else n
     assert B.shape[1] == K and A.dtype == B.dtype
     if out is None:
-        out = _new((M, N), A.dtype, A)
+        out = _new((M, N), torch.float32 if out_f32 else A.dtype, A)
+    res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
-                       L.ptr(residual), L.ptr(gelu_grad_of))
+                       L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32))
     L.call("sm_gemm_nt", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
            out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())
     return out
@@ -59,8 +62,8 @@ def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, 
     (then: gemm_nt(..., residual=) followed by layernorm_bwd)."""
     M, K = A.shape
     N = B.shape[0]
-    if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)):
-        return None
+    if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)) or x.dtype != A.dtype:
+        return None  # (fp32 residual stream: the LayerNorm input is fp32, the fused kernel reads bf16)
     dx = torch.empty_like(x)
     dx_drop = torch.empty_like(x) if want_drop else None
     ok = L.call_optional("sm_gemm_nt_ln_bwd", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
@@ -92,16 +95,31 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor, dbeta: Tensor,
                   drop: Optional[L.SmDropout] = None, want_drop: bool = False):
+    """x: the LayerNorm input; fp32 while dy is bf16 = the fp32 residual stream (sm_layernorm_bwd_res32)"""
     rows, H = x.shape
-    dx = torch.empty_like(x)
-    dx_drop = torch.empty_like(x) if want_drop else None
-    L.call("sm_layernorm_bwd", L.dtype_code(x.dtype), L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+    dx = torch.empty_like(dy)
+    dx_drop = torch.empty_like(dy) if want_drop else None
+    name = "sm_layernorm_bwd_res32" if x.dtype != dy.dtype else "sm_layernorm_bwd"
+    L.call(name, L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
            L.ptr(dx), L.ptr(dx_drop), _drop_ref(drop), L.ptr(dgamma), L.ptr(dbeta), rows, H, L.stream_ptr())
     return dx, dx_drop
 
 
+def layernorm_fwd_res32(x32: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype, want_y32: bool = True):
+    """fp32 residual stream: LayerNorm of fp32 rows -> y (compute dtype, the next GEMM's operand) and its fp32 copy (the next
+    residual add)"""
+    rows, H = x32.shape
+    y = _new((rows, H), out_dtype, x32)
+    y32 = _new((rows, H), torch.float32, x32) if want_y32 else None
+    mean = _new((rows,), torch.float32, x32)
+    rstd = _new((rows,), torch.float32, x32)
+    L.call("sm_layernorm_fwd_res32", L.dtype_code(out_dtype), L.ptr(x32), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(y32),
+           L.ptr(mean), L.ptr(rstd), rows, H, float(eps), L.stream_ptr())
+    return y, y32, mean, rstd
+
+
 def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tensor, beta: Tensor, eps: float,
-              drop: Optional[L.SmDropout] = None, rag: Optional[Ragged] = None):
+              drop: Optional[L.SmDropout] = None, rag: Optional[Ragged] = None, want_y32: bool = False):
     if rag is None:
         B, S = ids.shape
     else:
@@ -111,6 +129,12 @@ def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tens
     y = torch.empty_like(z)
     mean = _new((B * S,), torch.float32, word)
     rstd = _new((B * S,), torch.float32, word)
+    if want_y32:
+        y32 = _new((B * S, H), torch.float32, word)
+        L.call("sm_embed_fwd_res32", L.dtype_code(word.dtype), L.ptr(ids), L.ptr(word), L.ptr(pos), L.ptr(type0), L.ptr(gamma),
+               L.ptr(beta), L.ptr(z), L.ptr(y), L.ptr(y32), L.ptr(mean), L.ptr(rstd), B, S, H, float(eps), _drop_ref(drop),
+               _rag_ref(rag), L.stream_ptr())
+        return z, y, mean, rstd, y32
     L.call("sm_embed_fwd", L.dtype_code(word.dtype), L.ptr(ids), L.ptr(word), L.ptr(pos), L.ptr(type0), L.ptr(gamma),
            L.ptr(beta), L.ptr(z), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, S, H, float(eps), _drop_ref(drop),
            _rag_ref(rag), L.stream_ptr())

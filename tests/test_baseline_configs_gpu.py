@@ -24,7 +24,7 @@ from oracle import sparse_oracle as O  # noqa: E402
 
 SPECIAL = [0, 100, 101, 102, 103]
 V = 30522
-ELEMENTWISE_BF16 = 3e-2   # worst element, in units of (1 + |ref|)
+ELEMENTWISE_BF16 = 2e-2   # worst element, in units of (1 + |ref|): all-bf16 storage (measured 1.4e-2 at 6 layers, 2.1e-2 at 12)
 FRACTION_INSIDE = 0.999   # of the elements are inside 1e-2 * (1 + |ref|)
 
 GRAD_NAMES = ("bert.embeddings.word_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -48,7 +48,7 @@ def _elementwise(got, want, what):
     return float(err.max()), inside
 
 
-def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTION_INSIDE):
+def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTION_INSIDE, elementwise=None):
     d = out["d_rep"].detach().float().cpu()
     worst, inside = _elementwise(d, od, what + " d_rep")
     if dtype == torch.float32:
@@ -57,7 +57,8 @@ def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTI
     else:
         rel = float((d - od.detach()).norm() / od.detach().norm())
         assert rel <= 1e-2, f"{what}: d_rep relative Frobenius error {rel:.3e} > 1e-2"
-        assert worst <= ELEMENTWISE_BF16, f"{what}: d_rep worst element {worst:.3e} > {ELEMENTWISE_BF16} (1+|ref|)"
+        bound = ELEMENTWISE_BF16 if elementwise is None else elementwise
+        assert worst <= bound, f"{what}: d_rep worst element {worst:.3e} > {bound} (1+|ref|)"
         assert inside >= fraction_inside, f"{what}: only {inside:.5f} of d_rep inside 1e-2 (1+|ref|)"
         assert abs(float(loss) - float(oloss)) <= 1e-2 * (1 + abs(float(oloss))), (float(loss), float(oloss))
     if oq is not None:
@@ -77,7 +78,8 @@ def _check_grads(dtype, bb, pr, what):
             assert rel <= 1.5e-1, f"{what} grad {n}: relative Frobenius error {rel:.3e}"
 
 
-def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what=""):
+def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
+                  residual_fp32=False, elementwise=None):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
@@ -96,7 +98,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
             p[n] = 0.02 * torch.randn(p[n].shape, generator=g)
         elif n.endswith("LayerNorm.weight"):
             p[n] = 1 + 0.05 * torch.randn(p[n].shape, generator=g)
-    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32)
     bb.load_hf_state_dict(p)
     idf = torch.exp(torch.rand(V, generator=g) * 6.6 - 3.9)  # log-uniform in [0.02, 15.6] like idf.json
     use_l0 = bool(recipe.get("use_l0", False))
@@ -142,7 +144,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     del logits
     rows = inp["docs"][0]["packed"].rag.rows if inp["docs"][0].get("packed") is not None else nq * k * S
     print(f"[{what}] oracle {time.time() - t0:.1f} s, {rows} token rows on the device")
-    _check_outputs(dtype, loss, oloss, out, oq, od_free, what)
+    _check_outputs(dtype, loss, oloss, out, oq, od_free, what, elementwise=elementwise)
     if check_grads:
         _check_grads(dtype, bb, pr, what)
     return trainer, bb
@@ -167,6 +169,13 @@ def test_c1_config_infonce_v2mini_bs4_1neg_seq64(dtype):
 def test_c2_config_infonce_v2mini_seq128_15negs_bf16_slice():
     """BASELINE.json configs[1]: 8 of the 32 queries x 16 documents x seq 128 at full model size, bf16"""
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=2, what="c2 slice")
+
+
+def test_c2_slice_with_fp32_residual_stream_is_elementwise_inside_1e2():
+    """the north star's "1e-2 bf16", ELEMENTWISE: with the residual stream kept in fp32 (bf16 GEMM operands, what torch
+    autocast does) every sparse activation of the c2 slice is inside 1e-2 (1 + |ref|) of the fp32 oracle"""
+    _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=2, what="c2 slice, fp32 residual stream",
+                  residual_fp32=True, elementwise=1e-2)
 
 
 def test_c3_config_l0_recipe_on_the_c2_slice():
@@ -257,5 +266,5 @@ def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
                                              d["attention_mask"], got_t, lc, 100)
     print(f"[c4] oracle {time.time() - t0:.1f} s")
     # 12 layers of bf16 activations (6 in v2-mini): measured 99.79 % of the elements inside 1e-2 (1 + |ref|), worst 2.1e-2
-    _check_outputs(dtype, loss, oloss, out, oq, od, "c4", fraction_inside=0.995)
+    _check_outputs(dtype, loss, oloss, out, oq, od, "c4", fraction_inside=0.995, elementwise=3e-2)
     assert torch.isfinite(bbs[0].flat_grad).all() and float(bbs[0].flat_grad.abs().max()) > 0
