@@ -54,8 +54,9 @@ class ModelArguments:
     prune_ratio: Optional[float] = None
     preprocess_func: Optional[str] = None
     use_l0: bool = False
-    # extension (no reference key): bf16 runs keep the residual stream in fp32, as torch autocast does
-    residual_fp32: bool = False
+    # extension (no reference key): bf16 runs keep the residual stream in fp32, as torch autocast does; default on,
+    # false = all-bf16 activation storage (+4.5 % throughput, worst sparse activation 1.4e-2 instead of 5.9e-3 off the fp32 path)
+    residual_fp32: Optional[bool] = None
 
     def __post_init__(self):
         if self.tokenizer_name is None:

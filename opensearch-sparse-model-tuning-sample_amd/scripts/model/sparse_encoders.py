@@ -68,7 +68,7 @@ def _load_tokenizer(tokenizer_id):
 class SparseModel(torch.nn.Module):
     def __init__(self, model_id, idf=None, tokenizer_id=None, idf_requires_grad=False, prune_ratio=None,
                  preprocess_func=None, use_l0=True, compute_dtype: Optional[torch.dtype] = None, device=None,
-                 residual_fp32: bool = False):
+                 residual_fp32: Optional[bool] = None):
         super().__init__()
         compute_dtype = compute_dtype or torch.bfloat16
         if isinstance(model_id, HipBertMLM):

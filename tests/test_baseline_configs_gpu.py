@@ -10,9 +10,9 @@ against oracle.compute_loss on the same seeded inputs.
   c4  configs[3]: kd-ensemble, bert-base student (12L / 768H / 3072I), seq 256, 1 query x 8 docs, a sparse
       (bert-base MLM) and a dense (BERT-large shaped stand-in for gte-large) frozen teacher
 
-Tolerances (north star): fp32 storage 1e-3 elementwise; bf16 storage 1e-2 -- relative Frobenius error for tensors,
-plus the elementwise bound ELEMENTWISE_BF16 * (1 + |ref|) on every element (the tightest bound that holds; the
-measured fraction inside 1e-2 * (1 + |ref|) is printed and asserted >= FRACTION_INSIDE)."""
+Tolerances (north star): fp32 storage 1e-3 elementwise; bf16 1e-2 -- ELEMENTWISE, |err| <= 1e-2 (1 + |ref|) on every sparse
+activation (default: bf16 GEMM operands, fp32 residual stream), plus relative Frobenius error 1e-2; the measured worst element and
+the fraction inside the bound are printed."""
 import time
 
 import pytest
@@ -24,7 +24,8 @@ from oracle import sparse_oracle as O  # noqa: E402
 
 SPECIAL = [0, 100, 101, 102, 103]
 V = 30522
-ELEMENTWISE_BF16 = 2e-2   # worst element, in units of (1 + |ref|): all-bf16 storage (measured 1.4e-2 at 6 layers, 2.1e-2 at 12)
+ELEMENTWISE_BF16 = 1e-2   # worst element, in units of (1 + |ref|): the north star's bf16 bound, met ELEMENTWISE with the default fp32
+                          # residual stream (measured 5.9e-3 at the c2 slice); all-bf16 storage: 1.4e-2 (own test below)
 FRACTION_INSIDE = 0.999   # of the elements are inside 1e-2 * (1 + |ref|)
 
 GRAD_NAMES = ("bert.embeddings.word_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -79,7 +80,7 @@ def _check_grads(dtype, bb, pr, what):
 
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
-                  residual_fp32=False, elementwise=None):
+                  residual_fp32=None, elementwise=None):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
@@ -171,11 +172,11 @@ def test_c2_config_infonce_v2mini_seq128_15negs_bf16_slice():
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=2, what="c2 slice")
 
 
-def test_c2_slice_with_fp32_residual_stream_is_elementwise_inside_1e2():
-    """the north star's "1e-2 bf16", ELEMENTWISE: with the residual stream kept in fp32 (bf16 GEMM operands, what torch
-    autocast does) every sparse activation of the c2 slice is inside 1e-2 (1 + |ref|) of the fp32 oracle"""
-    _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=2, what="c2 slice, fp32 residual stream",
-                  residual_fp32=True, elementwise=1e-2)
+def test_c2_slice_with_all_bf16_activation_storage():
+    """the opt-in speed mode (residual_fp32=False: residual stream stored in bf16 too): relative Frobenius error 1e-2, worst
+    element 2e-2 (measured 1.4e-2), >= 99.9 % of the elements inside 1e-2 (1 + |ref|)"""
+    _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=2, what="c2 slice, all-bf16 storage",
+                  residual_fp32=False, elementwise=2e-2)
 
 
 def test_c3_config_l0_recipe_on_the_c2_slice():
@@ -265,6 +266,6 @@ def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
         oloss, _, _, oq, od = O.compute_loss(prs[0], ocs[0], idf, SPECIAL, q["input_ids"], q["attention_mask"], d["input_ids"],
                                              d["attention_mask"], got_t, lc, 100)
     print(f"[c4] oracle {time.time() - t0:.1f} s")
-    # 12 layers of bf16 activations (6 in v2-mini): measured 99.79 % of the elements inside 1e-2 (1 + |ref|), worst 2.1e-2
-    _check_outputs(dtype, loss, oloss, out, oq, od, "c4", fraction_inside=0.995, elementwise=3e-2)
+    # 12 layers: worst element 8.7e-3 (1 + |ref|) with the fp32 residual stream (2.1e-2 with all-bf16 storage)
+    _check_outputs(dtype, loss, oloss, out, oq, od, "c4")
     assert torch.isfinite(bbs[0].flat_grad).all() and float(bbs[0].flat_grad.abs().max()) > 0
