@@ -338,6 +338,9 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if os.environ.get('SM_LIB'):  # A/B two builds of the shared library in one run (development aid)
+        from sparse_hip import lib as _L
+        _L._LIB_PATH = os.environ['SM_LIB']
     from sparse_hip import ops
     other = "dense" if args.layout == "ragged" else "ragged"
     trainer, cfg, batches = build_trainer(args, device, rank, layouts=(args.layout,) if args.only_value_layout else (args.layout, other))

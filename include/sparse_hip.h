@@ -91,7 +91,8 @@ int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* 
  * kernel ran, 1 when the shape is not eligible (run sm_gemm_nt + sm_layernorm_bwd instead), < 0 on error. */
 int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                       const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
-                      const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, void* stream);
+                      const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta,
+                      int x_f32 /* 1: x is fp32 (fp32 residual stream) */, void* stream);
 
 /* Weight gradient: C[N,Kc] += A[M,N]^T . B[M,Kc]  (fp32, atomically accumulated), and
  * optionally colsum[N] += sum_m A[m,:] (the bias gradient).  Backward of every nn.Linear. */

@@ -1055,7 +1055,8 @@ static_assert(8 * 16 * NB_PS * 4 <= NB_LDS, "epilogue patches must fit the idle 
 // [T, H]) disappears.  Row sums cross the 4 column-waves of a row through LDS: pass 1 accumulates them (and the
 // gamma / beta column sums), one barrier, pass 2 replays the transposition and writes dx.
 struct LnBwdArgs {
-  const bf16* x;        // LayerNorm input (pre-normalisation), [M, N]
+  const bf16* x;        // LayerNorm input (pre-normalisation), [M, N]; fp32 when x32 is set (fp32 residual stream)
+  int x32;
   const float* gamma;
   const float* mean;
   const float* rstd;
@@ -1208,7 +1209,8 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
 #pragma unroll
             for (int q = 0; q < 8; ++q) rv[q] = 0.f;
           }
-          load8<bf16>(ln.x + off, xv, true, 8);
+          if (ln.x32) load8<float>(reinterpret_cast<const float*>(ln.x) + off, xv, true, 8);
+          else load8<bf16>(ln.x + off, xv, true, 8);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -1310,7 +1312,8 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
         }
         if (residual) {
           float rv[8];
-          load8<bf16>(residual + off, rv, true, 8);
+          if (e.res32) load8<float>(reinterpret_cast<const float*>(e.residual) + off, rv, true, 8);
+          else load8<bf16>(residual + off, rv, true, 8);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += rv[q];
         }
@@ -1320,7 +1323,8 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_t<bf16>(xv[q]);
         }
-        store8<bf16>(C + off, v, true, 8);
+        if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, true, 8);
+        else store8<bf16>(C + off, v, true, 8);
       }
     }
   }
@@ -1349,7 +1353,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
-    if (nt192 && !e.res32 && !e.out32 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+    if (nt192 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
       (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
       hipLaunchKernelGGL(gemm_nt192_kernel<false>, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
@@ -1428,7 +1432,7 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
 // ran, 1 when the shape is not eligible (the caller then runs sm_gemm_nt + sm_layernorm_bwd), < 0 on error.
 extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, void* stream) {
+                                 const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, int x_f32, void* stream) {
   constexpr int fuse = 1;
   constexpr int mink = 1024;
   if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 256) return 1;
@@ -1441,6 +1445,7 @@ extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* 
   e.vec_ok = 1;
   LnBwdArgs ln;
   ln.x = (const bf16*)x;
+  ln.x32 = x_f32;
   ln.gamma = gamma;
   ln.mean = mean;
   ln.rstd = rstd;

@@ -50,7 +50,7 @@ _rag = C.POINTER(SmRagged)
 # name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
 SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
-    "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p],
+    "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],

@@ -62,13 +62,13 @@ def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, 
     (then: gemm_nt(..., residual=) followed by layernorm_bwd)."""
     M, K = A.shape
     N = B.shape[0]
-    if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)) or x.dtype != A.dtype:
-        return None  # (fp32 residual stream: the LayerNorm input is fp32, the fused kernel reads bf16)
-    dx = torch.empty_like(x)
-    dx_drop = torch.empty_like(x) if want_drop else None
+    if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)):
+        return None
+    dx = torch.empty((M, N), dtype=A.dtype, device=A.device)  # (x is fp32 with the fp32 residual stream, the gradient stays A's type)
+    dx_drop = torch.empty_like(dx) if want_drop else None
     ok = L.call_optional("sm_gemm_nt_ln_bwd", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
                          L.ptr(residual), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), _drop_ref(drop), L.ptr(dx),
-                         L.ptr(dx_drop), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+                         L.ptr(dx_drop), L.ptr(dgamma), L.ptr(dbeta), int(x.dtype == torch.float32 and A.dtype != torch.float32), L.stream_ptr())
     return (dx, dx_drop) if ok else None
 
 
