@@ -117,6 +117,9 @@ class SparseModel(torch.nn.Module):
     def _encode(self, **kwargs):
         # reference: logits -> * mask -> max over seq -> log1p(relu) [-> log1p] [-> prune]; here
         # one fused decoder kernel, the [B,S,V] logits are never materialised
+        chunks = kwargs.get("grad_cache_chunks")
+        if chunks is not None and torch.is_grad_enabled():  # rep-level gradient caching (data_args.grad_cache_chunk)
+            return self.backbone.encode_cached(chunks, use_l0=self.use_l0, prune_ratio=self.prune_ratio)
         return self.backbone.encode(kwargs["input_ids"], kwargs["attention_mask"], use_l0=self.use_l0,
                                     prune_ratio=self.prune_ratio, packed=kwargs.get("packed"))
 

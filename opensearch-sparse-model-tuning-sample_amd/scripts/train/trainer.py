@@ -38,7 +38,7 @@ class ModelWrapper(torch.nn.Module):
 
     def forward(self, inputs):
         d_rep = self.sparse_model(inf_free=False, input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                                  packed=inputs.get("packed"))
+                                  packed=inputs.get("packed"), grad_cache_chunks=inputs.get("grad_cache_chunks"))
         q_rep = self.sparse_model(inf_free=self.inf_free, input_ids=inputs["q_input_ids"],
                                   attention_mask=inputs["q_attention_mask"])
         return d_rep, q_rep
@@ -142,6 +142,7 @@ class SparseModelTrainer:
             "input_ids": inputs["docs"][0]["input_ids"],
             "attention_mask": inputs["docs"][0]["attention_mask"],
             "packed": inputs["docs"][0].get("packed"),  # host-packed ragged layout (see _prepare_inputs)
+            "grad_cache_chunks": self._grad_cache_chunks(inputs["docs"][0]),
         }
         d_rep, q_rep = model(model_wrapper_input)
         # inference-free queries have at most one non-zero per query token: let the losses use the
@@ -173,6 +174,17 @@ class SparseModelTrainer:
             self._log_step()
         loss = loss * self.accelerator.num_processes  # DDP averages, trainer.py:139-141
         return (loss, outputs) if return_outputs else loss
+
+    def _grad_cache_chunks(self, enc):
+        """data_args.grad_cache_chunk > 0: the student's documents as chunks for HipBertMLM.encode_cached -- the host-packed
+        chunks of _prepare_inputs when they exist, otherwise slices of the padded device tensors"""
+        n = int(getattr(self.data_args, "grad_cache_chunk", 0) or 0)
+        if n <= 0:
+            return None
+        if enc.get("packed_chunks") is not None:
+            return enc["packed_chunks"]
+        ids, mask = enc["input_ids"], enc["attention_mask"]
+        return [(ids[a:a + n], mask[a:a + n], None) for a in range(0, ids.shape[0], n)]
 
     def _use_score_exchange(self) -> bool:
         """N > 1: the default is the reference's dense all-gather of the representations (utils.py:16-23).
@@ -276,9 +288,18 @@ class SparseModelTrainer:
             bb = self.model.sparse_model.backbone
             if getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda:
                 from sparse_hip.encoder import pack_documents
-                packed = pack_documents(enc["input_ids"], enc["attention_mask"], self.accelerator.device, bb.config.pad_token_id)
-                if packed is not None:
-                    out["docs"][0]["packed"] = packed
+                n = int(getattr(self.data_args, "grad_cache_chunk", 0) or 0)
+                if n > 0:  # rep-level gradient caching: every chunk gets its own ragged layout
+                    ids, mask = enc["input_ids"], enc["attention_mask"]
+                    chunks = []
+                    for a in range(0, ids.shape[0], n):
+                        pk = pack_documents(ids[a:a + n], mask[a:a + n], self.accelerator.device, bb.config.pad_token_id)
+                        chunks.append((out["docs"][0]["input_ids"][a:a + n], out["docs"][0]["attention_mask"][a:a + n], pk))
+                    out["docs"][0]["packed_chunks"] = chunks
+                else:
+                    packed = pack_documents(enc["input_ids"], enc["attention_mask"], self.accelerator.device, bb.config.pad_token_id)
+                    if packed is not None:
+                        out["docs"][0]["packed"] = packed
         except (KeyError, IndexError, TypeError, AttributeError):
             pass
         return out
@@ -297,8 +318,8 @@ class SparseModelTrainer:
         """Side-stream all-reduce of each layer's gradient slice as soon as backward has produced it."""
         bb = self.model.sparse_model.backbone
         self._comm_stream = torch.cuda.Stream(device=bb.device)
-        if not self.model_args.inf_free:
-            return  # the encoder runs twice per step (queries + docs): reduce once at the end instead
+        if not self.model_args.inf_free or int(getattr(self.data_args, "grad_cache_chunk", 0) or 0) > 0:
+            return  # the encoder's backward runs more than once per step (queries + docs / one pass per chunk): reduce once at the end
         layout = bb._layout
         names = [n for n, _ in layout]
         self._slices = {}

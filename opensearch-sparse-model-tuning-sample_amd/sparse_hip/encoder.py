@@ -416,10 +416,21 @@ class HipBertMLM(torch.nn.Module):
             ids, mask, B, S = self._prep_inputs(input_ids, attention_mask)
         rag = packed.rag if packed is not None else None
         need_grad = torch.is_grad_enabled()
-        training = self.training and need_grad
+        training = self.training and (need_grad or self._dropout_without_grad)
         self._invocation += 1
         seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._invocation) & 0xFFFFFFFFFFFFFFFF
         return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad, rag)
+
+    def encode_cached(self, chunks: List[Tuple[Tensor, Tensor, Optional[PackedDocs]]], use_l0: bool = False,
+                      prune_ratio: Optional[float] = None) -> Tensor:
+        """rep[B, V] of the concatenated chunks with REP-LEVEL GRADIENT CACHING ("GradCache"): the forward runs
+        chunk by chunk WITHOUT saving activations; the backward, once d loss / d rep is known, re-runs each chunk with
+        activations and back-propagates its slice of the gradient.  Legal because the loss sees the encoder only through rep
+        (trainer.py:101-119); costs one extra encoder forward, caps the live activations at one chunk -- what lets
+        BASELINE configs[4] (1984 documents x 512 tokens of bert-base per GPU: ~340 GB of saved activations in one piece) fit.
+        chunks: (input_ids, attention_mask, packed-or-None) per chunk.  Dropout masks are identical in both passes (same
+        per-chunk seed)."""
+        return _GradCacheFn.apply(self._anchor, self, chunks, bool(use_l0), prune_ratio)
 
     def _reattach_grads(self) -> None:
         """An external optimiser may have set .grad to None; restore the flat-buffer views."""
@@ -435,6 +446,40 @@ class HipBertMLM(torch.nn.Module):
     def set_dropout_seed(self, seed: int) -> None:
         self._drop_seed = int(seed)
         self._invocation = 0
+
+
+class _GradCacheFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model: "HipBertMLM", chunks, use_l0, prune_ratio):
+        reps, counters = [], []
+        model._dropout_without_grad = True
+        try:
+            with torch.no_grad():
+                for ids, mask, packed in chunks:
+                    counters.append(model._invocation)  # the backward replays the chunk with the same dropout seed
+                    reps.append(model.encode(ids, mask, use_l0, prune_ratio, packed))
+        finally:
+            model._dropout_without_grad = False
+        ctx.model, ctx.chunks, ctx.counters, ctx.args = model, chunks, counters, (use_l0, prune_ratio)
+        return torch.cat(reps, 0)
+
+    @staticmethod
+    def backward(ctx, grad_rep):
+        model: HipBertMLM = ctx.model
+        use_l0, prune_ratio = ctx.args
+        after = model._invocation
+        hook, model._layer_hook = model._layer_hook, None  # per-layer gradient slices are final only after the LAST chunk
+        off = 0
+        try:
+            for (ids, mask, packed), counter in zip(ctx.chunks, ctx.counters):
+                with torch.enable_grad():
+                    model._invocation = counter
+                    rep = model.encode(ids, mask, use_l0, prune_ratio, packed)
+                    rep.backward(grad_rep[off:off + rep.shape[0]])
+                off += rep.shape[0]
+        finally:
+            model._invocation, model._layer_hook = after, hook
+        return (None,) * 5
 
 
 class _WgradStream:
@@ -581,6 +626,7 @@ class _EncodeFn(torch.autograd.Function):
 
 
 HipBertMLM._layer_hook = None
+HipBertMLM._dropout_without_grad = False
 HipBertMLM._cast_table = None
 HipBertMLM._cast_key = None
 HipBertMLM._wgrad = None

@@ -270,6 +270,59 @@ def test_seq128_to_512_documents():
         close_out(loss, oloss, 1e-2, f"loss S={S}")
 
 
+@pytest.mark.parametrize("layout", ["dense", "ragged"])
+def test_rep_level_gradient_caching_matches_the_single_pass(layout):
+    """data_args.grad_cache_chunk (what BASELINE configs[4]'s 1984 x 512-token documents per GPU need): forward
+    in chunks without saved activations, then per chunk re-forward + backward of its slice of d loss / d rep.  Loss and
+    every parameter gradient must equal the ordinary single pass (fp32 storage, dropout off); with dropout ON the two passes
+    of a chunk must draw the same masks (the step is reproducible and differs from the dropout-free one)."""
+    g = load("g6_compute_loss.npz")
+    name = "infonce_ibn"
+    mkw, dkw, lts = G6_CASES[name]
+
+    def run(chunk, dropout=0.0, dtype=torch.float32):
+        trainer, model = _make_trainer(dtype, (mkw, dict(dkw, grad_cache_chunk=chunk), lts))
+        bb = model.backbone
+        bb.config.hidden_dropout_prob = bb.config.attention_probs_dropout_prob = dropout
+        bb.set_dropout_seed(7)
+        trainer.model.train()
+        trainer.state.global_step = 5
+        trainer.zero_grad()
+        t = lambda k: torch.tensor(g[f"{name}/{k}"])
+        batch = {"query": [{"input_ids": t("q_ids"), "attention_mask": t("q_mask")}],
+                 "docs": [{"input_ids": t("d_ids"), "attention_mask": t("d_mask")}]}
+        inp = trainer._prepare_inputs(batch) if layout == "ragged" else _inputs(g, name)
+        loss = trainer.compute_loss(trainer.model, inp)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), bb.flat_grad.clone()
+
+    l0, g0 = run(0)
+    l1, g1 = run(5)  # 12 documents -> chunks of 5, 5, 2
+    assert abs(l0 - l1) <= 1e-5 * (1 + abs(l0)), (l0, l1)
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-5 * scale, float((g0 - g1).abs().max())
+    assert float(g0.abs().max()) > 0
+    # dropout on: the re-forward of every chunk must reproduce the first pass bit for bit (same masks), and differ from dropout off
+    from sparse_hip.encoder import HipBertMLM
+    seen = []
+    real = HipBertMLM.encode
+
+    def spy(self, *a, **k):
+        rep = real(self, *a, **k)
+        seen.append(rep.detach().clone())
+        return rep
+    HipBertMLM.encode = spy
+    try:
+        ld, gd = run(5, dropout=0.1, dtype=torch.bfloat16)
+    finally:
+        HipBertMLM.encode = real
+    assert len(seen) == 6 and all(torch.equal(seen[i], seen[3 + i]) for i in range(3)), "pass 2 must replay pass 1's dropout masks"
+    assert torch.isfinite(gd).all()
+    lnd, _ = run(5, dropout=0.0, dtype=torch.bfloat16)
+    assert abs(ld - lnd) > 1e-4
+
+
 def test_training_mode_dropout_is_seeded_and_finite():
     from scripts.model.sparse_encoders import SparseModel
     from sparse_hip.encoder import HipBertMLM
