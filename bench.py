@@ -28,7 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
-HEAD_KERNELS = ("sparse_head_fwd_p2_kernel", "sparse_head_fwd_ares_kernel")  # roofline kernel names in the PMC summaries, newest first
+HEAD_KERNELS = ("sparse_head_fwd_vs_kernel",)  # the roofline kernel's name in the PMC summaries (a summary of an older kernel is not reported)
 
 
 def parse():
