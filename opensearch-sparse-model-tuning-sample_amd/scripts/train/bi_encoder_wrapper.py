@@ -49,11 +49,60 @@ class DenseModel(torch.nn.Module):
         return torch.nn.functional.normalize(hidden[:, 0], p=2, dim=1)
 
 
+class TeacherScoreCache:
+    """Scores of the frozen teachers, kept across epochs (the reference recomputes them every step,
+    bi_encoder_wrapper.py:117-146).  Without in-batch negatives the ensemble row of a sample depends only on that sample
+    (its query, its k documents: the min-max normalisation is per row), so it is stored under a 64-bit hash of the
+    sample's token ids and a step whose samples have all been seen skips every teacher forward.  With in-batch negatives
+    a row depends on the whole batch and nothing is cached.  The table lives on the device the scores are on."""
+
+    _MUL_Q, _MUL_D, _MUL_ROW = 0x9E3779B97F4A7C15 - (1 << 64), 0xC2B2AE3D27D4EB4F - (1 << 64), 0x165667B19E3779F9
+
+    def __init__(self):
+        self.row_of_key = {}
+        self.table = None
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _row_hash(ids, mask, mul):
+        # wrap-around int64 polynomial hash of the real tokens of every row (padding does not count)
+        ids = ids.to(torch.int64) * mask.to(torch.int64)
+        pos = torch.arange(1, ids.shape[1] + 1, device=ids.device, dtype=torch.int64)
+        return ((ids + 1) * (pos * mul + 0x2545F491)).sum(dim=1) * mul
+
+    def keys(self, q_features, d_features):
+        hq = self._row_hash(q_features["input_ids"], q_features["attention_mask"], self._MUL_Q)
+        hd = self._row_hash(d_features["input_ids"], d_features["attention_mask"], self._MUL_D).reshape(hq.shape[0], -1)
+        slot = torch.arange(1, hd.shape[1] + 1, device=hd.device, dtype=torch.int64)
+        return (hq + (hd * (slot * self._MUL_ROW + 1)).sum(dim=1)).tolist()
+
+    def lookup(self, keys):
+        rows = [self.row_of_key.get(k) for k in keys]
+        if self.table is None or any(r is None for r in rows):
+            self.misses += 1
+            return None
+        self.hits += 1
+        return self.table[torch.tensor(rows, device=self.table.device)]
+
+    def insert(self, keys, scores):
+        scores = scores.detach()
+        new = [(i, k) for i, k in enumerate(keys) if k not in self.row_of_key]
+        if not new:
+            return
+        base = 0 if self.table is None else self.table.shape[0]
+        for n, (_, k) in enumerate(new):
+            self.row_of_key[k] = base + n
+        fresh = scores[torch.tensor([i for i, _ in new], device=scores.device)]
+        self.table = fresh.clone() if self.table is None else torch.cat([self.table, fresh])
+
+
 class BiEncoderWrapper:
     CLS_MAP = {"sparse": BiSparseModel, "dense": DenseModel}
 
     def __init__(self, types, model_ids, score_scale=30, use_in_batch_negatives=False, embedding_service=None,
-                 compute_dtype=torch.bfloat16, device=None):
+                 compute_dtype=torch.bfloat16, device=None, cache_scores=False):
+        # cache_scores (kd_ensemble_teacher_kwargs key, not in the reference): see TeacherScoreCache
+        self.score_cache = TeacherScoreCache() if cache_scores and not use_in_batch_negatives else None
         assert len(types) == len(model_ids)
         assert len(types) != 0
         self.score_scale = score_scale
@@ -69,6 +118,12 @@ class BiEncoderWrapper:
 
     def get_scores_batch(self, q_features_list, d_features_list):
         assert len(q_features_list) == len(self.models)
+        keys = None
+        if self.score_cache is not None:
+            keys = self.score_cache.keys(q_features_list[0], d_features_list[0])
+            cached = self.score_cache.lookup(keys)
+            if cached is not None:
+                return cached
         per_teacher = []
         with torch.no_grad():
             for i, model in enumerate(self.models):
@@ -77,4 +132,7 @@ class BiEncoderWrapper:
                 if self.use_in_batch_negatives:
                     d_rep = gather_rep(d_rep, self.accelerator)
                 per_teacher.append(F.score_matrix(q_rep, d_rep, self.use_in_batch_negatives))
-            return F.ensemble_scores(per_teacher, self.score_scale)
+            scores = F.ensemble_scores(per_teacher, self.score_scale)
+        if keys is not None:
+            self.score_cache.insert(keys, scores)
+        return scores

@@ -251,7 +251,7 @@ class SparseModelTrainer:
         self.bi_encoder_teacher = BiEncoderWrapper(
             types=kw["types"], model_ids=kw["model_ids"], use_in_batch_negatives=self.data_args.use_in_batch_negatives,
             score_scale=kw.get("score_scale", 30), embedding_service=embedding_service,
-            compute_dtype=bb.compute_dtype, device=bb.device)
+            compute_dtype=bb.compute_dtype, device=bb.device, cache_scores=bool(kw.get("cache_scores", False)))
         self.bi_encoder_teacher.accelerator = self.accelerator
 
     def get_train_dataloader(self):

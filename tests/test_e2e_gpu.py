@@ -404,6 +404,40 @@ def test_kd_ensemble_teachers_match_oracle():
     close_out(loss, oloss, 1e-3, "kd-ensemble loss")
 
 
+def test_teacher_score_cache_skips_the_teacher_forwards_on_seen_samples():
+    """8f row 4: with kd_ensemble_teacher_kwargs.cache_scores the ensemble rows of samples seen before come from the
+    table (bit-identical to what the teachers produced, also when the samples arrive in another order) and no teacher runs"""
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.train.bi_encoder_wrapper import BiEncoderWrapper
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    kw = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+              max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bbs = [HipBertMLM(BertConfigLite(**kw), compute_dtype=torch.float32, device="cuda", init_seed=s) for s in (4, 5)]
+    nq, k = 6, 4
+    ds = SyntheticTriplesDataset(nq, k, 64, 16, 1000, seed=13, len_mean=40, len_std=15)
+    coll = PreTokenizedCollator(n_teachers=2)
+    dev = lambda f: {n: v.cuda() for n, v in f.items() if torch.is_tensor(v)}
+    feats = lambda idx: [[dev(f) for f in coll([ds[i] for i in idx])[side][1:]] for side in ("query", "docs")]
+    plain = BiEncoderWrapper(["dense", "sparse"], bbs, score_scale=30)
+    cached = BiEncoderWrapper(["dense", "sparse"], bbs, score_scale=30, cache_scores=True)
+    calls = []
+    for m in cached.models:
+        m.register_forward_hook(lambda *a: calls.append(1))
+    q, d = feats(range(nq))
+    first = cached.get_scores_batch(q, d)
+    assert torch.equal(first, plain.get_scores_batch(q, d)) and len(calls) == 4 and cached.score_cache.misses == 1
+    order = [4, 0, 5, 2]
+    q2, d2 = feats(order)
+    again = cached.get_scores_batch(q2, d2)
+    assert len(calls) == 4 and cached.score_cache.hits == 1, "seen samples must not run the teachers"
+    assert torch.equal(again, first[order]) and torch.equal(again, plain.get_scores_batch(q2, d2))
+    ds2 = SyntheticTriplesDataset(2, k, 64, 16, 1000, seed=99, len_mean=40, len_std=15)
+    mixed = coll([ds[1], ds2[0]])
+    qm, dm = [[dev(f) for f in mixed[side][1:]] for side in ("query", "docs")]
+    assert torch.equal(cached.get_scores_batch(qm, dm), plain.get_scores_batch(qm, dm)) and len(calls) == 8  # one unseen sample: recompute
+    assert BiEncoderWrapper(["dense"], bbs[:1], use_in_batch_negatives=True, cache_scores=True).score_cache is None
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bert_base_shaped_layer_matches_oracle(dtype):
     """config-4/5 model family: H=768, 12 heads (head dim 64), I=3072 (one layer to keep the oracle fast)"""

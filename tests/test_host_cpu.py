@@ -71,6 +71,30 @@ def test_lambda_and_lr_schedules_match_reference_known_answers():
         assert linear_schedule_lr(step, 1e-3, 2, 6) == O.linear_warmup_lr(step, 1e-3, 2, 6)
 
 
+def test_teacher_score_cache_keys_and_table():
+    from scripts.train.bi_encoder_wrapper import TeacherScoreCache
+    g = torch.Generator().manual_seed(0)
+    nq, k, S = 5, 3, 12
+    q = {"input_ids": torch.randint(5, 900, (nq, 8), generator=g), "attention_mask": torch.ones(nq, 8, dtype=torch.long)}
+    d = {"input_ids": torch.randint(5, 900, (nq * k, S), generator=g), "attention_mask": torch.ones(nq * k, S, dtype=torch.long)}
+    d["attention_mask"][:, 9:] = 0
+    c = TeacherScoreCache()
+    keys = c.keys(q, d)
+    assert len(set(keys)) == nq
+    d_pad = {"input_ids": d["input_ids"].clone(), "attention_mask": d["attention_mask"]}
+    d_pad["input_ids"][:, 9:] = 0  # what sits under the padding does not change a key
+    assert c.keys(q, d_pad) == keys
+    swapped = d["input_ids"].clone()
+    swapped[[0, 1]] = swapped[[1, 0]]  # the order of a sample's documents does
+    assert c.keys(q, {"input_ids": swapped, "attention_mask": d["attention_mask"]})[0] != keys[0]
+    assert c.lookup(keys) is None
+    scores = torch.rand(nq, k, generator=g)
+    c.insert(keys[:3], scores[:3])
+    assert c.lookup(keys) is None and torch.equal(c.lookup(keys[:3]), scores[:3])
+    c.insert(keys, scores)
+    assert c.table.shape[0] == nq and torch.equal(c.lookup([keys[4], keys[0]]), scores[[4, 0]])
+
+
 def test_synthetic_dataset_and_collator_layout():
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
     ds = SyntheticTriplesDataset(8, 16, 128, 32, 30522, seed=1, with_scores=True)
