@@ -155,7 +155,9 @@ long sm_sparse_head_fwd_scratch_bytes(int dtype, int B, int S, int H, int V, int
 /* scripts/model/sparse_encoders.py:115-119 ratio prune, in place on rep */
 int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream);
 /* backward of the fused head: given grad_rep[B,V] produces dt[B*S,H] (dtype),
- * dE[V,H] += (fp32), dbias[V] += .  Sparse: one non-zero logit gradient per (b,v). */
+ * dE[V,H] += (fp32), dbias[V] += .  Sparse: one non-zero logit gradient per (b,v).
+ * dt == NULL or dE == NULL (with dbias) computes only the other half, so that a caller can
+ * put the weight-gradient half on another stream. */
 int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax,
                        const void* t, const void* E, void* dt, float* dE, float* dbias,
                        int B, int S, int H, int V, int use_l0, const sm_ragged* rag, void* stream);

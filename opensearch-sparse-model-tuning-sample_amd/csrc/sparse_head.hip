@@ -456,7 +456,7 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   static thread_local hipStream_t side = nullptr;
   static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   constexpr int overlap_env = 1;
-  const bool overlap = overlap_env && !sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag);
+  const bool overlap = overlap_env && dt != nullptr && dE != nullptr && !sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag);
   hipStream_t st_de = st;
   if (overlap) {
     if (side == nullptr) {
@@ -467,6 +467,11 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     SM_HIP_CHECK(hipEventRecord(ev_fork, st));
     SM_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
     st_de = side;
+  }
+  // dt == NULL / dE == NULL: only the other half (the caller runs the halves on different streams)
+  if (dE == nullptr) {
+    SM_REQUIRE(dt != nullptr, "sm_sparse_head_bwd: dt and dE are both NULL");
+    return sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
   }
   const int de_rc = sm_head_de_launch(dtype, grad_rep, rep, argmax, t, dE, dbias, B, S, H, V, use_l0, rag, st_de);
   if (de_rc < 0) return de_rc;
@@ -491,7 +496,7 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
 #undef DISPATCH_NC
 #undef LAUNCH_DE
   SM_LAUNCH_CHECK();
-  {
+  if (dt != nullptr) {
     const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
     if (rc != SM_OK) return rc;
   }

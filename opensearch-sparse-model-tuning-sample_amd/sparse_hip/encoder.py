@@ -502,6 +502,17 @@ class _WgradStream:
         a.record_stream(self.stream)  # the caching allocator must not recycle the operands early
         b.record_stream(self.stream)
 
+    def call(self, fn, *operands: Tensor):
+        """any other weight-gradient launch (`fn()` enqueues it) on the side stream, ordered after the main stream so far"""
+        if not self.enabled:
+            fn()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in operands:
+            t.record_stream(self.stream)
+
     def join(self):
         if self.enabled:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -556,8 +567,12 @@ class _EncodeFn(torch.autograd.Function):
             model._wgrad = _WgradStream(model.device)
         wg = model._wgrad
         grad_rep = grad_rep.contiguous().float()
-        dtn = ops.sparse_head_bwd(grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"),
-                                  B, S, cfg.vocab_size, use_l0, rag)
+        # the head backward's two halves: dE / dbias are weight gradients (side stream, like every other one),
+        # dt continues the chain
+        head_args = (grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"), B, S, cfg.vocab_size, use_l0, rag)
+        wg.call(lambda: ops.sparse_head_bwd(*head_args, part="de"), grad_rep, rep, argmax, tn)
+        head_de_done = wg.mark()
+        dtn = ops.sparse_head_bwd(*head_args, part="dt")
         dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
                                    g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
         dft = ops.gelu_bwd(dgt, ft)
@@ -617,6 +632,8 @@ class _EncodeFn(torch.autograd.Function):
             dx = ops.dropout_bwd(dx, d_emb)
         dz0, _ = ops.layernorm_bwd(dx, z0, v(e + "LayerNorm.weight"), m0, r0, g(e + "LayerNorm.weight"),
                                    g(e + "LayerNorm.bias"))
+        if head_de_done is not None:  # both add into the tied word-embedding gradient, the head's half without atomics
+            torch.cuda.current_stream().wait_event(head_de_done)
         ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),
                       g(e + "token_type_embeddings.weight")[0], rag)
         wg.join()

@@ -202,11 +202,14 @@ def prune_rows(rep: Tensor, ratio: float) -> Tensor:
 
 
 def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E: Tensor, dE: Tensor, dbias: Tensor,
-                    B: int, S: int, V: int, use_l0: bool, rag: Optional[Ragged] = None) -> Tensor:
+                    B: int, S: int, V: int, use_l0: bool, rag: Optional[Ragged] = None, part: str = "both") -> Optional[Tensor]:
+    """part: "both", or one half -- "dt" (gradient w.r.t. the hidden rows, returned) / "de" (dE, dbias accumulated)"""
     H = t.shape[1]
-    dt = torch.empty_like(t)
+    dt = torch.empty_like(t) if part != "de" else None
+    want_de = part != "dt"
     L.call("sm_sparse_head_bwd", L.dtype_code(t.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(t), L.ptr(E),
-           L.ptr(dt), L.ptr(dE), L.ptr(dbias), B, S, H, V, int(use_l0), _rag_ref(rag), L.stream_ptr())
+           L.ptr(dt), L.ptr(dE) if want_de else None, L.ptr(dbias) if want_de else None, B, S, H, V, int(use_l0), _rag_ref(rag),
+           L.stream_ptr())
     return dt
 
 

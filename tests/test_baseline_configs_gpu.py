@@ -54,7 +54,7 @@ def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTI
     worst, inside = _elementwise(d, od, what + " d_rep")
     if dtype == torch.float32:
         assert worst <= 1e-3, f"{what}: d_rep worst element {worst:.3e} > 1e-3 (1+|ref|)"
-        assert abs(float(loss) - float(oloss)) <= 1e-3 * (1 + abs(float(oloss))), (float(loss), float(oloss))
+        assert abs(float(loss.detach()) - float(oloss)) <= 1e-3 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
     else:
         rel = float((d - od.detach()).norm() / od.detach().norm())
         assert rel <= 1e-2, f"{what}: d_rep relative Frobenius error {rel:.3e} > 1e-2"
