@@ -30,6 +30,21 @@ template <> struct AT<float> {
   }
 };
 
+// Dropout of the attention probabilities: S x S elements per (document, head), each needing its keep bit once in the
+// forward and in each backward phase -- with the general 64-bit-index hash (drop_keep1: two quarter-rate 32-bit multiplies,
+// ~22 issue slots) that was more than a third of these kernels' VALU work.  Here the (document, head) is folded into a
+// per-unit key once (full murmur finaliser, per wave), and the element, a 32-bit index q * S + key < 2^18, goes through two
+// rounds of FULL-rate 24-bit multiplies + xor-shifts (~8 slots; keep rate, neighbour / row / key correlations and bucket
+// uniformity checked against the expected sampling noise on 200 keys).
+__device__ __forceinline__ uint32_t drop_unit_key(const DropCfg& d, uint32_t unit) { return fmix32(d.key ^ (unit * 0x9E3779B9u)); }
+__device__ __forceinline__ bool drop_keep_local(uint32_t ukey, uint32_t thresh16, uint32_t idx) {
+  uint32_t a = __umul24(idx ^ ukey, 0xD6E8FFu);
+  a ^= a >> 15;
+  uint32_t b = __umul24(a, 0x9E3779u);
+  b ^= b >> 13;
+  return (uint16_t)b >= (uint16_t)thresh16;
+}
+
 // Byte offset of (row, byte column) in a row-major LDS image.  SWZ (bf16 images whose rows are exactly 128 B: head dim
 // 64, or two heads of 32 side by side): no padding, the 16-byte chunk index is XORed with (row & 7) -- conflict-free for
 // the ds_read_b128 fragment reads (16 rows at chunks c / c+1) AND for the transposing reads (8 rows x 32 B per half
@@ -199,6 +214,30 @@ __device__ __forceinline__ void stage(const T* __restrict__ src, size_t ld, int 
   }
 }
 
+// Two [rows][COLS] slices at once with ALL global loads issued before the first LDS store (MAXIT x 2 in flight per
+// thread): the loop above pays one global round trip per iteration and image -- with few threads per workgroup that was
+// most of a workgroup's prologue.
+template <typename T, int COLS, bool SWZ, int MAXIT>
+__device__ __forceinline__ void stage2_batched(const T* __restrict__ srcA, size_t ldA, const T* __restrict__ srcB, size_t ldB, int nvalid, int ntotal,
+                                               char* imgA, char* imgB, int rs) {
+  constexpr int EPC = 16 / (int)sizeof(T), CPR = COLS / EPC;
+  uint4 va[MAXIT], vb[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x, r = idx / CPR, c = idx % CPR;
+    va[it] = r < nvalid ? *reinterpret_cast<const uint4*>(srcA + (size_t)r * ldA + c * EPC) : make_uint4(0, 0, 0, 0);
+    vb[it] = r < nvalid ? *reinterpret_cast<const uint4*>(srcB + (size_t)r * ldB + c * EPC) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x, r = idx / CPR, c = idx % CPR;
+    if (r < ntotal) {
+      *reinterpret_cast<uint4*>(imgA + img_off<SWZ>(r, rs, c * 16)) = va[it];
+      *reinterpret_cast<uint4*>(imgB + img_off<SWZ>(r, rs, c * 16)) = vb[it];
+    }
+  }
+}
+
 template <typename T> __device__ __forceinline__ void store4(T* dst, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, f32x4 v) { *reinterpret_cast<f32x4*>(dst) = v; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
@@ -219,7 +258,8 @@ struct Lay {  // LDS row stride (bytes): 128-byte bf16 rows are XOR-swizzled (im
 // HP = heads per workgroup.  With head dim 32 a (row, head) slice is 64 B -- half a cache line, the other half
 // being the neighbouring head -- so one head per workgroup fetches every line of q/k/v twice (measured: 2x
 // the algorithmic HBM traffic forward, 3.5x backward); two adjacent heads per workgroup use whole lines.
-template <typename T, int DH, int NKT, int HP>
+// DROP: dropout on / off is a compile-time switch -- as a run-time test the compiler kept one branch PER ELEMENT in the loops
+template <typename T, int DH, int NKT, int HP, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
@@ -239,8 +279,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
   uint8_t* sM = reinterpret_cast<uint8_t*>(sV0 + S * L::RS);
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
-  stage<T, HP * DH, L::SWZ>(base0 + H, ld, Lr, nkt * 16, sK0, L::RS, nullptr, 0);
-  stage<T, HP * DH, L::SWZ>(base0 + 2 * H, ld, Lr, nkt * 16, sV0, L::RS, nullptr, 0);
+  stage2_batched<T, HP * DH, L::SWZ, NKT * 16 * (HP * DH * (int)sizeof(T) / 16) / 256>(base0 + H, ld, base0 + 2 * H, ld, Lr, nkt * 16, sK0, sV0, L::RS);
   for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
   __syncthreads();
 
@@ -285,14 +324,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     const int q = qb * 16 + li;
-    const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
+    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h)), ebase = (uint32_t)(q * S);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
       if (kt < nkt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = p[kt][r] * inv;
-          if (drop.thresh16) v = drop_keep1(drop, ebase + kt * 16 + 4 * g + r) ? v * drop.scale : 0.f;
+          if constexpr (DROP) v = drop_keep_local(ukey, drop.thresh16, ebase + kt * 16 + 4 * g + r) ? v * drop.scale : 0.f;
           p[kt][r] = v;
         }
     if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------
-template <typename T, int DH, int HP>
+template <typename T, int DH, int HP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop,
@@ -376,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       fdo[ks] = grow_frag<T>(dob, H, q, ks, g);
     }
     const float lq = sLse0[hh * S + q], dl = sDelta0[hh * S + q];
-    const uint64_t ebase = ((uint64_t)(b * A + h) * S + q) * (uint64_t)S;
+    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h)), ebase = (uint32_t)(q * S);
     f32x4 dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -394,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
           const int key = kt * 16 + 4 * g + r;
           const float pv = ((m4 >> (8 * r)) & 0xFF) ? __expf(s[r] * scale - lq) : 0.f;
           float dpv = dp[r];
-          if (drop.thresh16) dpv = drop_keep1(drop, ebase + key) ? dpv * drop.scale : 0.f;
+          if constexpr (DROP) dpv = drop_keep_local(ukey, drop.thresh16, ebase + key) ? dpv * drop.scale : 0.f;
           dsv[r] = pv * (dpv - dl) * scale;
         }
         ds[hh] = PT<T>::pack(dsv);
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const uint64_t hbase = (uint64_t)(b * A + h) * S;
+    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
     for (int t2 = 0; t2 < nt / 2; ++t2) {
       typename PT<T>::type pd[2], ds[2];
 #pragma unroll
@@ -448,7 +487,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
           const int q = qt * 16 + 4 * g + r;
           const float pv = kvalid ? __expf(s[r] * scale - l4[r]) : 0.f;
           float keepf = 1.f;
-          if (drop.thresh16) keepf = drop_keep1(drop, (hbase + q) * (uint64_t)S + key) ? drop.scale : 0.f;
+          if constexpr (DROP) keepf = drop_keep_local(ukey, drop.thresh16, (uint32_t)(q * S + key)) ? drop.scale : 0.f;
           pdv[r] = pv * keepf;
           dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
         }
@@ -469,6 +508,173 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Single-pass backward (bf16, S <= 128).  The two-phase kernel above evaluates every (query, key) element twice -- exp,
+// dropout keep bit, dS -- once per orientation, and that element work (VALU: ~35 instructions per element and pass, 56 M
+// wave instructions per launch at config 2 against 14 MFMAs per tile pair) is what bounds it.  Here ONE WAVE owns a whole
+// (document, head): it walks the key blocks (S orientation as in phase B: accumulator rows = queries, col = key; dK, dV
+// of the block accumulate in registers) and keeps dQ of ALL query tiles in registers (NQT x DH/16 accumulators): each dS
+// tile is turned around through a 512-byte wave-private LDS patch (one ds_write_b64 + one transposing read per lane) into
+// the A operand of  dQ[q tile] += dS[q, keys] . K[keys, :]  (16x16x16 MFMA, contraction over the block's 16 keys, K^T
+// fragments loaded once per block).  No cross-wave sums at all -- the LDS float atomics a key-block-per-wave split needs
+// for dQ ran at ~50 cycles per instruction (690 us per launch).  Workgroup = the HP heads that share the LDS images.
+template <int DH, int HP, int NQT, bool DROP>
+__global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+                                                            const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                            const float* __restrict__ lse, bf16* __restrict__ dqkv, int S, int A, DropCfg drop,
+                                                            const int32_t* __restrict__ doc_off) {
+  using T = bf16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = Lay<T, HP * DH>;
+  constexpr int NKS = DH / 32;
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  const int H = A * DH;
+  const size_t ld = 3 * (size_t)H;
+  const int AP = A / HP;
+  const int b = blockIdx.x / AP, h0 = (blockIdx.x % AP) * HP;
+  const int row0 = doc_off ? doc_off[b] : b * S;
+  const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
+  const int nblk = Lr / 16;
+  const int nt = (nblk + 1) & ~1;
+  char* sX0 = smem;                                            // Q image
+  char* sY0 = sX0 + S * L::RS;                                 // dO image
+  float* sLse0 = reinterpret_cast<float*>(sY0 + S * L::RS);    // [HP][S]
+  float* sDelta0 = sLse0 + HP * S;                             // [HP][S]
+  char* sPatch0 = reinterpret_cast<char*>(sDelta0 + HP * S);   // [HP waves][16 keys][16 queries] bf16
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sPatch0 + HP * 512);
+  const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
+  const T* dob0 = dctx + (size_t)row0 * H + h0 * DH;
+  const T* ob0 = ctx + (size_t)row0 * H + h0 * DH;
+  {
+    // Q, dO images and delta = rowsum(dO . O) in one batch: the thread that stages chunk (row, c) of dO also loads the same
+    // chunk of O; the DH/8 chunks of a head's row sit in adjacent lanes
+    constexpr int CPR = HP * DH / 8, MAXIT = NQT * 16 * CPR / (64 * HP), CPH = DH / 8;
+    uint4 vq[MAXIT], vd[MAXIT], vo[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * blockDim.x, r = idx / CPR, c = idx % CPR;
+      const bool live = r < Lr;
+      vq[it] = live ? *reinterpret_cast<const uint4*>(base0 + (size_t)r * ld + c * 8) : make_uint4(0, 0, 0, 0);
+      vd[it] = live ? *reinterpret_cast<const uint4*>(dob0 + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
+      vo[it] = live ? *reinterpret_cast<const uint4*>(ob0 + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+    for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
+      sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
+#pragma unroll
+      for (int hh = 0; hh < HP; ++hh) sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * blockDim.x, r = idx / CPR, c = idx % CPR;
+      const T* ea = reinterpret_cast<const T*>(&vd[it]);
+      const T* eo = reinterpret_cast<const T*>(&vo[it]);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)ea[j] * (float)eo[j];
+#pragma unroll
+      for (int sft = 1; sft < CPH; sft <<= 1) d += __shfl_xor(d, sft, 64);
+      if (r < nt * 16) {
+        *reinterpret_cast<uint4*>(sX0 + img_off<L::SWZ>(r, L::RS, c * 16)) = vq[it];
+        *reinterpret_cast<uint4*>(sY0 + img_off<L::SWZ>(r, L::RS, c * 16)) = vd[it];
+        if (c % CPH == 0) sDelta0[(c / CPH) * S + r] = d;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const int h = h0 + hh;
+  const float scale = rsqrtf((float)DH);
+  const int cof = hh * DH * (int)sizeof(T);
+  const T* base = base0 + hh * DH;
+  T* dq_out = dqkv + (size_t)row0 * ld + h * DH;
+  const float* sLse = sLse0 + hh * S;
+  const float* sDelta = sDelta0 + hh * S;
+  char* patch = sPatch0 + hh * 512;
+  char* patch_w = patch + li * 32 + g * 8;                                                   // dS[q = 4g .. 4g+3][key = li] -> patch[key][q]
+  const lds_v4* patch_r = (const lds_v4*)(patch + (4 * g + (li >> 2)) * 32 + (li & 3) * 8);  // -> column li of rows 4g .. 4g+3
+  const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+  f32x4 dq[NQT][DH / 16];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int key = kb * 16 + li;
+    bf16x8 fk[NKS], fv[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      fk[ks] = grow_frag<T>(base + H, ld, key, ks, g);
+      fv[ks] = grow_frag<T>(base + 2 * H, ld, key, ks, g);
+    }
+    // B operand of the dQ product: K[key = kb*16 + 4g + r][d = dt*16 + li]
+    s16x4 kB[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        kB[dt][r] = *reinterpret_cast<const short*>(base + H + (size_t)(kb * 16 + 4 * g + r) * ld + dt * 16 + li);
+    const bool kvalid = sM[key] != 0;
+    f32x4 dv[DH / 16], dk[DH / 16];
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < NQT / 2; ++t2) {
+      if (2 * t2 < nt) {
+        bf16x4 pd[2], ds[2];
+#pragma unroll
+        for (int hh2 = 0; hh2 < 2; ++hh2) {
+          const int qt = 2 * t2 + hh2;
+          const f32x4 sv = dh_product<T, DH, L::SWZ>(sX0, L::RS, cof, qt * 16 + li, g, fk);
+          const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, qt * 16 + li, g, fv);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
+          f32x4 pdv, dsv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            const float pv = kvalid ? __expf(sv[r] * scale - l4[r]) : 0.f;
+            float keepf = 1.f;
+            if constexpr (DROP) keepf = drop_keep_local(ukey, drop.thresh16, (uint32_t)(q * S + key)) ? drop.scale : 0.f;
+            pdv[r] = pv * keepf;
+            dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
+          }
+          pd[hh2] = PT<T>::pack(pdv);
+          ds[hh2] = PT<T>::pack(dsv);
+          *reinterpret_cast<bf16x4*>(patch_w) = ds[hh2];
+          const s16x4 dsT = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)patch_r);
+#pragma unroll
+          for (int dt = 0; dt < DH / 16; ++dt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, kB[dt], dq[qt][dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          dv[dt] = SeqPair<T, L::SWZ>::acc(dv[dt], sY0, L::RS, cof, dt * 16, g, li, pd[0], pd[1], t2);
+          dk[dt] = SeqPair<T, L::SWZ>::acc(dk[dt], sX0, L::RS, cof, dt * 16, g, li, ds[0], ds[1], t2);
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv[dt]);
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt]);
+    }
+  }
+  // dQ accumulators: rows = queries 4g + r, col = d = li
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+    if (qt < nblk)
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)dq[qt][dt][r];
+}
+template <int DH, int HP>
+size_t bwd1_lds(int S) { return 2 * (size_t)S * Lay<bf16, HP * DH>::RS + HP * 8 * (size_t)S + HP * 512 + S; }
+
 template <typename T, int DH, int HP>
 size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + S; }
 template <typename T, int DH, int HP>
@@ -486,32 +692,46 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = fwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
-    auto kern = attn_fwd_kernel<T, DH, NKT, 2>;
+    auto kern = d.thresh16 ? attn_fwd_kernel<T, DH, NKT, 2, true> : attn_fwd_kernel<T, DH, NKT, 2, false>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
     return SM_OK;
   }
   const size_t lds = fwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
-  auto kern = attn_fwd_kernel<T, DH, NKT, 1>;
+  auto kern = d.thresh16 ? attn_fwd_kernel<T, DH, NKT, 1, true> : attn_fwd_kernel<T, DH, NKT, 1, false>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
 }
+template <int DH, int HP>
+int launch_bwd1(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
+  const size_t lds = bwd1_lds<DH, HP>(S);
+  auto kern = d.thresh16 ? attn_bwd1_kernel<DH, HP, 8, true> : attn_bwd1_kernel<DH, HP, 8, false>;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B * A / HP), dim3(64 * HP), lds, st, (const bf16*)qkv, km, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, S, A, d,
+                     doc_off);
+  return SM_OK;
+}
+
 template <typename T, int DH>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && DH == 32) {  // single pass: dQ of 8 query tiles in registers
+    if (S <= 128 && pair_heads<T, DH>(A, S)) return launch_bwd1<DH, 2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
+  }
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = bwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-    auto kern = attn_bwd_kernel<T, DH, 2>;
+    auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 2, true> : attn_bwd_kernel<T, DH, 2, false>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
     return SM_OK;
   }
   const size_t lds = bwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-  auto kern = attn_bwd_kernel<T, DH, 1>;
+  auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 1, true> : attn_bwd_kernel<T, DH, 1, false>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
   return SM_OK;
