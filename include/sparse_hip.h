@@ -92,7 +92,10 @@ int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* 
 int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                       const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta,
-                      int x_f32 /* 1: x is fp32 (fp32 residual stream) */, void* stream);
+                      int x_f32 /* 1: x is fp32 (fp32 residual stream) */,
+                      const sm_dropout* dy_drop /* NULL, or the dropout between the LayerNorm output and the consumer
+                                                   (embeddings): dy is masked with it first */,
+                      void* stream);
 
 /* Weight gradient: C[N,Kc] += A[M,N]^T . B[M,Kc]  (fp32, atomically accumulated), and
  * optionally colsum[N] += sum_m A[m,:] (the bias gradient).  Backward of every nn.Linear. */
@@ -161,6 +164,15 @@ int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream);
 int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax,
                        const void* t, const void* E, void* dt, float* dE, float* dbias,
                        int B, int S, int H, int V, int use_l0, const sm_ragged* rag, void* stream);
+
+/* The dt half fused with the backward of the head transform (hf:477-479: dense -> GELU -> LayerNorm -> decoder):
+ * dft[T,H] = LayerNorm'(G.E ; x = LayerNorm input, gamma, mean, rstd) * gelu'(gelu_of), dgamma / dbeta accumulated; dt itself
+ * never goes to HBM.  Returns 0 when the fused kernel ran, 1 when the shape is not eligible (bf16, H = 384 only: run
+ * sm_sparse_head_bwd + sm_layernorm_bwd + sm_gelu_bwd instead), < 0 on error. */
+int sm_sparse_head_bwd_dt_ln(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E,
+                             void* dft, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x,
+                             const float* gamma, const float* mean, const float* rstd, const void* gelu_of,
+                             float* dgamma, float* dbeta, void* stream);
 
 /* ---- inference-free query encoder (scripts/model/sparse_encoders.py:121-127) ----------- */
 int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,

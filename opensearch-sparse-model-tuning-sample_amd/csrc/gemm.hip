@@ -1064,9 +1064,151 @@ struct LnBwdArgs {
   float* dgamma;
   float* dbeta;
   DropCfg drop;
+  const bf16* post_gelu_of;  // may be null: dx is multiplied by gelu'(post_gelu_of) (the GELU that precedes the LayerNorm in the forward)
+  DropCfg dy_drop;      // dropout that sits between the LayerNorm output and the consumer of dy (embeddings): applied to dy first
 };
 
-template <bool LNB>
+// LayerNorm BACKWARD as the epilogue of a [192 x 384] accumulator tile that holds whole rows (8 waves, wave (wm, wn) owns
+// the 96 x 96 block, lane = (row li, columns 4g .. 4g+3) of each 16 x 16 tile): shared by gemm_nt192_kernel<true> and the
+// fused head backward (head_dt192_kernel).  `smem` must be idle (no LDS-DMA in flight, every wave past its last read) and
+// hold NB_LDS + 2 * 384 * 4 bytes.  ln.post_gelu_of: the result is additionally multiplied by gelu'(that tensor).
+// LMODE: 0 plain, 1 with ln.dy_drop, 2 with ln.post_gelu_of (compile-time: as run-time branches they cost the plain case 20 spilled registers)
+template <int LMODE>
+__device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_t sbase, int m0, int M, int N, int ldc, bf16* __restrict__ C,
+                                                     const bf16* residual, const LnBwdArgs& ln, int tid, int lane, int w, int wm,
+                                                     int wn, int g, int li) {
+  // (1) accumulators -> bf16 image dy'[192][384] in the idle ring (exactly NB_LDS bytes); 16-byte chunks are
+  //     XOR-swizzled with (row & 7) so that the 16 rows a store instruction covers spread over the banks
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int trow = wm * 96 + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int chunk = wn * 12 + j * 2 + (g >> 1);
+      union { bf16x4 v; unsigned long long u; } pk;
+      pk.v = pack4(acc[i][j]);
+      asm volatile("ds_write_b64 %0, %1" ::"v"(sbase + trow * 768 + ((chunk ^ (trow & 7)) << 4) + (g & 1) * 8), "v"(pk.u) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // (2) LayerNorm backward, a row per 16 lanes (24 columns per lane), 4 rows of the wave's 24 at a time
+  const int sl = lane & 15, sub = lane >> 4;
+  float dg[3][8], db[3][8], gm[3][8];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    *reinterpret_cast<f32x4*>(gm[u]) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8);
+    *reinterpret_cast<f32x4*>(gm[u] + 4) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8 + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { dg[u][q] = 0.f; db[u][q] = 0.f; }
+  }
+  const float invn = 1.f / (float)N;
+  // unrolled by two: two iterations' global loads in flight (a rolled loop pays the full load latency six times,
+  // a fully unrolled one spills)
+#pragma unroll 2
+  for (int it = 0; it < 6; ++it) {
+    const int trow = w * 24 + it * 4 + sub, row = m0 + trow;
+    const bool live = row < M;
+    bf16x8 raw[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) raw[u] = lds_b128(sbase + trow * 768 + (((sl + 16 * u) ^ (trow & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
+    const float mu = live ? ln.mean[row] : 0.f, rs = live ? ln.rstd[row] : 0.f;
+    float dy[3][8], xn[3][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const size_t off = (size_t)row * ldc + (sl + 16 * u) * 8;
+      float rv[8], xv[8];
+      if (live) {
+        if (residual) {
+          load8<bf16>(residual + off, rv, true, 8);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = 0.f;
+        }
+        if (ln.x32) load8<float>(reinterpret_cast<const float*>(ln.x) + off, xv, true, 8);
+        else load8<bf16>(ln.x + off, xv, true, 8);
+      }
+      if constexpr (LMODE == 1) {
+        const uint64_t eb = (uint64_t)row * (uint64_t)N + (sl + 16 * u) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float t = (float)(bf16)((float)raw[u][q] + rv[q]);  // the gradient the un-fused path stores before its dropout pass
+          raw[u][q] = (bf16)(drop_keep1(ln.dy_drop, eb + q) ? t * ln.dy_drop.scale : 0.f);
+          rv[q] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        dy[u][q] = live ? (float)(bf16)((float)raw[u][q] + rv[q]) : 0.f;
+        xn[u][q] = live ? (xv[q] - mu) * rs : 0.f;
+        const float dyg = dy[u][q] * gm[u][q];
+        s1 += dyg;
+        s2 += dyg * xn[u][q];
+        dg[u][q] += dy[u][q] * xn[u][q];
+        db[u][q] += dy[u][q];
+      }
+    }
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) { s1 += __shfl_xor(s1, sft, 64); s2 += __shfl_xor(s2, sft, 64); }
+    const float c1 = s1 * invn, c2 = s2 * invn;
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int col = (sl + 16 * u) * 8;
+        const size_t off = (size_t)row * ldc + col;
+        float gx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gx[q] = rs * (dy[u][q] * gm[u][q] - c1 - xn[u][q] * c2);
+        if constexpr (LMODE == 2) {
+          float pv[8];
+          load8<bf16>(ln.post_gelu_of + off, pv, true, 8);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) gx[q] = (float)(bf16)gx[q] * gelu_grad_t<bf16>(pv[q]);  // (the un-fused path rounds dx to bf16 first)
+        }
+        store8<bf16>(C + off, gx, true, 8);
+        if (ln.dx_drop) {
+          if (ln.drop.thresh16) {
+            const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gx[q] = drop_keep1(ln.drop, eb + q) ? gx[q] * ln.drop.scale : 0.f;
+          }
+          store8<bf16>(ln.dx_drop + off, gx, true, 8);
+        }
+      }
+    }
+  }
+  // (3) gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, then ONE global
+  //     atomic per column and workgroup (768 hot addresses shared by every workgroup: per-wave atomics cost 4 ms)
+  const uint32_t colsum = sbase + NB_LDS;  // [2][384] fp32 behind the dy image
+  for (int c = tid; c < 2 * NB_C; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float a = dg[u][q], b = db[u][q];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (sub == 0) {
+        const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
+        asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(a) : "memory");
+        asm volatile("ds_add_f32 %0, %1" ::"v"(ca + NB_C * 4), "v"(b) : "memory");
+      }
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = tid; c < 2 * NB_C; c += 512) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
+    atomicAdd(c < NB_C ? ln.dgamma + c : ln.dbeta + (c - NB_C), v);
+  }
+}
+
+template <bool LNB, int LMODE = 0>
 __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                          bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, LnBwdArgs ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1158,120 +1300,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   const uint32_t patch = sbase + w * (16 * NB_PS * 4);
   const int prow = lane >> 2, pc = (lane & 3) * 8;  // patch row / first column (within each 32-column third) of this lane
   if constexpr (LNB) {
-    // (1) accumulators -> bf16 image dy'[192][384] in the idle ring (exactly NB_LDS bytes); 16-byte chunks are
-    //     XOR-swizzled with (row & 7) so that the 16 rows a store instruction covers spread over the banks
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int trow = wm * 96 + i * 16 + li;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int chunk = wn * 12 + j * 2 + (g >> 1);
-        union { bf16x4 v; unsigned long long u; } pk;
-        pk.v = pack4(acc[i][j]);
-        asm volatile("ds_write_b64 %0, %1" ::"v"(sbase + trow * 768 + ((chunk ^ (trow & 7)) << 4) + (g & 1) * 8), "v"(pk.u) : "memory");
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // (2) LayerNorm backward, a row per 16 lanes (24 columns per lane), 4 rows of the wave's 24 at a time
-    const int sl = lane & 15, sub = lane >> 4;
-    float dg[3][8], db[3][8], gm[3][8];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      *reinterpret_cast<f32x4*>(gm[u]) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8);
-      *reinterpret_cast<f32x4*>(gm[u] + 4) = *reinterpret_cast<const f32x4*>(ln.gamma + (sl + 16 * u) * 8 + 4);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { dg[u][q] = 0.f; db[u][q] = 0.f; }
-    }
-    const float invn = 1.f / (float)N;
-    // unrolled by two: two iterations' global loads in flight (a rolled loop pays the full load latency six times,
-    // a fully unrolled one spills)
-#pragma unroll 2
-    for (int it = 0; it < 6; ++it) {
-      const int trow = w * 24 + it * 4 + sub, row = m0 + trow;
-      const bool live = row < M;
-      bf16x8 raw[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) raw[u] = lds_b128(sbase + trow * 768 + (((sl + 16 * u) ^ (trow & 7)) << 4));
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
-      const float mu = live ? ln.mean[row] : 0.f, rs = live ? ln.rstd[row] : 0.f;
-      float dy[3][8], xn[3][8];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const size_t off = (size_t)row * ldc + (sl + 16 * u) * 8;
-        float rv[8], xv[8];
-        if (live) {
-          if (residual) {
-            load8<bf16>(residual + off, rv, true, 8);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rv[q] = 0.f;
-          }
-          if (ln.x32) load8<float>(reinterpret_cast<const float*>(ln.x) + off, xv, true, 8);
-          else load8<bf16>(ln.x + off, xv, true, 8);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          dy[u][q] = live ? (float)(bf16)((float)raw[u][q] + rv[q]) : 0.f;
-          xn[u][q] = live ? (xv[q] - mu) * rs : 0.f;
-          const float dyg = dy[u][q] * gm[u][q];
-          s1 += dyg;
-          s2 += dyg * xn[u][q];
-          dg[u][q] += dy[u][q] * xn[u][q];
-          db[u][q] += dy[u][q];
-        }
-      }
-#pragma unroll
-      for (int sft = 1; sft < 16; sft <<= 1) { s1 += __shfl_xor(s1, sft, 64); s2 += __shfl_xor(s2, sft, 64); }
-      const float c1 = s1 * invn, c2 = s2 * invn;
-      if (live) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int col = (sl + 16 * u) * 8;
-          const size_t off = (size_t)row * ldc + col;
-          float gx[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) gx[q] = rs * (dy[u][q] * gm[u][q] - c1 - xn[u][q] * c2);
-          store8<bf16>(C + off, gx, true, 8);
-          if (ln.dx_drop) {
-            if (ln.drop.thresh16) {
-              const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
-#pragma unroll
-              for (int q = 0; q < 8; ++q) gx[q] = drop_keep1(ln.drop, eb + q) ? gx[q] * ln.drop.scale : 0.f;
-            }
-            store8<bf16>(ln.dx_drop + off, gx, true, 8);
-          }
-        }
-      }
-    }
-    // (3) gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, then ONE global
-    //     atomic per column and workgroup (768 hot addresses shared by every workgroup: per-wave atomics cost 4 ms)
-    const uint32_t colsum = sbase + NB_LDS;  // [2][384] fp32 behind the dy image
-    for (int c = tid; c < 2 * NB_C; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float a = dg[u][q], b = db[u][q];
-        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-        if (sub == 0) {
-          const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
-          asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(a) : "memory");
-          asm volatile("ds_add_f32 %0, %1" ::"v"(ca + NB_C * 4), "v"(b) : "memory");
-        }
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int c = tid; c < 2 * NB_C; c += 512) {
-      float v;
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
-      atomicAdd(c < NB_C ? ln.dgamma + c : ln.dbeta + (c - NB_C), v);
-    }
+    ln_bwd_tile_epilogue<LMODE>(acc, sbase, m0, M, N, ldc, C, residual, ln, tid, lane, w, wm, wn, g, li);
     return;
   }
 #pragma unroll
@@ -1432,9 +1461,12 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
 // ran, 1 when the shape is not eligible (the caller then runs sm_gemm_nt + sm_layernorm_bwd), < 0 on error.
 extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                                  const void* residual, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, int x_f32, void* stream) {
+                                 const sm_dropout* drop, void* dx, void* dx_drop, float* dgamma, float* dbeta, int x_f32,
+                                 const sm_dropout* dy_drop, void* stream) {
   constexpr int fuse = 1;
-  constexpr int mink = 1024;
+  // (at K = 384 the 192 x 384 tile is ~8 % slower than the 128 x 128 GEMM, but the LayerNorm-backward launch it absorbs
+  // costs more than the whole GEMM)
+  constexpr int mink = 384;
   if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 256) return 1;
   const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)residual | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_drop |
                        (uintptr_t)gamma;
@@ -1453,12 +1485,14 @@ extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* 
   ln.dgamma = dgamma;
   ln.dbeta = dbeta;
   ln.drop = make_drop(drop);
+  ln.dy_drop = make_drop(dy_drop);
+  ln.post_gelu_of = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int items = sm_cdiv(M, NB_R);
   constexpr int LNB_LDS = NB_LDS + 2 * NB_C * 4;  // + the [2][384] column-sum patch
-  SM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_LDS));
-  hipLaunchKernelGGL(gemm_nt192_kernel<true>, dim3((items + 7) / 8 * 8), dim3(512), LNB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb,
-                     (bf16*)dx, N, M, N, K, e, ln);
+  auto kern = ln.dy_drop.thresh16 ? gemm_nt192_kernel<true, 1> : gemm_nt192_kernel<true, 0>;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_LDS));
+  hipLaunchKernelGGL(kern, dim3((items + 7) / 8 * 8), dim3(512), LNB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)dx, N, M, N, K, e, ln);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -1564,11 +1598,14 @@ constexpr int DT_R = 192, DT_C = 384, DT_NST = 4, DT_ESTAGE = 3 * TG_STAGE, DT_G
 constexpr int DT_CSLOT = 3 * 512 * 4;  // per step: grad_rep, rep, argmax-pair words of the 512 (document, column) slots
 constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT;
 
+template <bool LNF>
 __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
                                                          const uint16_t* __restrict__ argmax, const bf16* __restrict__ E,
                                                          bf16* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0,
                                                          const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
-                                                         int rag_rows) {
+                                                         int rag_rows, LnBwdArgs ln) {
+  // LNF (H == 384: the tile holds whole rows): dt does not go to HBM, `dt` receives LayerNorm'(dt) . gelu'(ln.post_gelu_of),
+  // the gradient w.r.t. the head transform's dense output -- the LayerNorm-backward and GELU-backward launches disappear
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
   char* const sE = smem;
@@ -1732,6 +1769,13 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     //    they are here so is everything older -- including E stage k+1, which the next step reads
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     write_g(k + 1);
+  }
+  if constexpr (LNF) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the redundant tail loads must not land in the image
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ln_bwd_tile_epilogue<2>(acc, (uint32_t)(uintptr_t)(lds_char*)smem, m0, Ttot, H, H, dt, nullptr, ln, tid, lane, w, wm, wn, g, li);
+    return;
   }
   // ---- epilogue: lane = (row li, columns 4g..4g+3) of each 16 x 16 tile ----
 #pragma unroll
@@ -1959,6 +2003,31 @@ int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const 
 }
 
 // dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
+// the fused form of the dt half: LayerNorm' and GELU' of the head transform in the epilogue (1 = shape not eligible)
+int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dft,
+                         int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x, const float* gamma,
+                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, hipStream_t st) {
+  const long T = rag ? rag->rows : (long)B * S;
+  if (dtype != SM_BF16 || H != DT_C || V % 2 != 0 || ((uintptr_t)E % 16) != 0 || !(rag || S % 16 == 0)) return 1;
+  if ((((uintptr_t)x | (uintptr_t)gelu_of | (uintptr_t)dft | (uintptr_t)gamma) % 16) != 0) return 1;
+  LnBwdArgs ln{};
+  ln.x = (const bf16*)x;
+  ln.x32 = 0;
+  ln.gamma = gamma;
+  ln.mean = mean;
+  ln.rstd = rstd;
+  ln.dx_drop = nullptr;
+  ln.dgamma = dgamma;
+  ln.dbeta = dbeta;
+  ln.post_gelu_of = (const bf16*)gelu_of;
+  constexpr int lds = (DT_LDS > NB_LDS ? DT_LDS : NB_LDS) + 2 * NB_C * 4;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(head_dt192_kernel<true>, dim3(1, sm_cdiv(T, DT_R)), dim3(512), lds, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dft, B, S, H, V,
+                     use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0, ln);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st) {
   SM_REQUIRE(rag || (S % 16 == 0 && ((S <= 128 && 128 % S == 0) || S % 128 == 0)), "sm_sparse_head_bwd: S=%d unsupported", S);
@@ -1969,9 +2038,9 @@ int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const 
   const int rrows = rag ? rag->rows : 0;
   constexpr int dt192 = 1;
   if (dt192 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
-    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
-    hipLaunchKernelGGL(head_dt192_kernel, dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
-                       B, S, H, V, use_l0, doc_off, blk_doc, rrows);
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
+    hipLaunchKernelGGL(head_dt192_kernel<false>, dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
+                       B, S, H, V, use_l0, doc_off, blk_doc, rrows, LnBwdArgs{});
     SM_LAUNCH_CHECK();
     return SM_OK;
   }

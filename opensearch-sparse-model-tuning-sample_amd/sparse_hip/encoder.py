@@ -572,15 +572,29 @@ class _EncodeFn(torch.autograd.Function):
         head_args = (grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"), B, S, cfg.vocab_size, use_l0, rag)
         wg.call(lambda: ops.sparse_head_bwd(*head_args, part="de"), grad_rep, rep, argmax, tn)
         head_de_done = wg.mark()
-        dtn = ops.sparse_head_bwd(*head_args, part="dt")
-        dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
-                                   g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
-        dft = ops.gelu_bwd(dgt, ft)
+        dft = ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, st["E"], B, S, cfg.vocab_size, use_l0, rag, gt,
+                                        v(c + "transform.LayerNorm.weight"), mt, rt, ft,
+                                        g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
+        if dft is None:
+            dtn = ops.sparse_head_bwd(*head_args, part="dt")
+            dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
+                                       g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
+            dft = ops.gelu_bwd(dgt, ft)
         wg.run(dft, x_last, g(c + "transform.dense.weight"), g(c + "transform.dense.bias"))
-        dx = ops.gemm_nt(dft, st["tT"])
+        # the transform's input gradient feeds the output LayerNorm of the last layer: GEMM + LayerNorm backward in one launch
+        # where the kernel takes the shape (pending = (dz2, dz2d) of the layer about to run)
+        pending = None
+        if cfg.num_hidden_layers > 0:
+            pl = f"bert.encoder.layer.{cfg.num_hidden_layers - 1}."
+            z2l, m2l, r2l = ctx.saved["layers"][-1][10:13]
+            d_h2l = model._drop(ph, training, seed, cfg.num_hidden_layers, _Site.HID2)
+            pending = ops.gemm_nt_ln_bwd(dft, st["tT"], None, z2l, v(pl + "output.LayerNorm.weight"), m2l, r2l,
+                                         g(pl + "output.LayerNorm.weight"), g(pl + "output.LayerNorm.bias"),
+                                         d_h2l, want_drop=d_h2l is not None)
+        if pending is None:
+            dx = ops.gemm_nt(dft, st["tT"])
         if model._layer_hook is not None:
             model._layer_hook("head", wg.mark())
-        pending = None  # (dz2, dz2d) of the layer about to run, when the previous GEMM already produced them (fused)
         for l in reversed(range(cfg.num_hidden_layers)):
             p = f"bert.encoder.layer.{l}."
             x, qkv, ctxt, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2 = ctx.saved["layers"][l]
@@ -622,16 +636,25 @@ class _EncodeFn(torch.autograd.Function):
                 pending = ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z2p, v(pp + "output.LayerNorm.weight"), m2p, r2p,
                                              g(pp + "output.LayerNorm.weight"), g(pp + "output.LayerNorm.bias"),
                                              d_h2p, want_drop=d_h2p is not None)
-            if pending is None:
+            dz0 = None
+            if l == 0:  # ... and of the embedding LayerNorm (with the embedding dropout in between)
+                z0, m0, r0 = ctx.saved["emb"]
+                d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
+                fused = ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z0, v(e + "LayerNorm.weight"), m0, r0,
+                                           g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"), dy_drop=d_emb)
+                if fused is not None:
+                    dz0 = fused[0]
+            if pending is None and dz0 is None:
                 dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
             if model._layer_hook is not None:
                 model._layer_hook(l, wg.mark())
         z0, m0, r0 = ctx.saved["emb"]
-        d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
-        if d_emb is not None:
-            dx = ops.dropout_bwd(dx, d_emb)
-        dz0, _ = ops.layernorm_bwd(dx, z0, v(e + "LayerNorm.weight"), m0, r0, g(e + "LayerNorm.weight"),
-                                   g(e + "LayerNorm.bias"))
+        if cfg.num_hidden_layers == 0 or dz0 is None:
+            d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
+            if d_emb is not None:
+                dx = ops.dropout_bwd(dx, d_emb)
+            dz0, _ = ops.layernorm_bwd(dx, z0, v(e + "LayerNorm.weight"), m0, r0, g(e + "LayerNorm.weight"),
+                                       g(e + "LayerNorm.bias"))
         if head_de_done is not None:  # both add into the tied word-embedding gradient, the head's half without atomics
             torch.cuda.current_stream().wait_event(head_de_done)
         ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),

@@ -50,7 +50,7 @@ _rag = C.POINTER(SmRagged)
 # name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
 SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
-    "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, _p],
+    "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
@@ -67,6 +67,7 @@ SIGNATURES = {
     "sm_sparse_head_fwd_scratch_bytes": [_i, _i, _i, _i, _i, _i],
     "sm_prune_rows": [_p, _i, _i, _f, _p],
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
+    "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],
     "sm_flops_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p],

@@ -57,9 +57,11 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
 
 
 def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                   dgamma: Tensor, dbeta: Tensor, drop: Optional[L.SmDropout] = None, want_drop: bool = False):
-    """(dx, dx_drop) = LayerNorm'(A @ B^T + residual) in one launch, or None when the fused kernel does not take the shape
-    (then: gemm_nt(..., residual=) followed by layernorm_bwd)."""
+                   dgamma: Tensor, dbeta: Tensor, drop: Optional[L.SmDropout] = None, want_drop: bool = False,
+                   dy_drop: Optional[L.SmDropout] = None):
+    """(dx, dx_drop) = LayerNorm'(dropout'(A @ B^T + residual)) in one launch, or None when the fused kernel does not take
+    the shape (then: gemm_nt(..., residual=), dropout_bwd, layernorm_bwd).  dy_drop: the dropout that follows the LayerNorm
+    in the forward (embeddings only)."""
     M, K = A.shape
     N = B.shape[0]
     if not (x.is_contiguous() and (residual is None or residual.is_contiguous()) and tuple(x.shape) == (M, N)):
@@ -68,7 +70,8 @@ def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, 
     dx_drop = torch.empty_like(dx) if want_drop else None
     ok = L.call_optional("sm_gemm_nt_ln_bwd", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), M, N, K,
                          L.ptr(residual), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd), _drop_ref(drop), L.ptr(dx),
-                         L.ptr(dx_drop), L.ptr(dgamma), L.ptr(dbeta), int(x.dtype == torch.float32 and A.dtype != torch.float32), L.stream_ptr())
+                         L.ptr(dx_drop), L.ptr(dgamma), L.ptr(dbeta), int(x.dtype == torch.float32 and A.dtype != torch.float32), _drop_ref(dy_drop),
+                         L.stream_ptr())
     return (dx, dx_drop) if ok else None
 
 
@@ -211,6 +214,21 @@ def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E:
            L.ptr(dt), L.ptr(dE) if want_de else None, L.ptr(dbias) if want_de else None, B, S, H, V, int(use_l0), _rag_ref(rag),
            L.stream_ptr())
     return dt
+
+
+def sparse_head_bwd_dt_ln(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tensor, B: int, S: int, V: int, use_l0: bool,
+                          rag: Optional[Ragged], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, gelu_of: Tensor,
+                          dgamma: Tensor, dbeta: Tensor) -> Optional[Tensor]:
+    """dt half of the head backward fused with the backward of the transform's LayerNorm (input x) and GELU (input gelu_of):
+    the gradient w.r.t. the transform's dense output, or None when the fused kernel does not take the shape"""
+    H = x.shape[1]
+    if not (x.is_contiguous() and gelu_of.is_contiguous() and x.dtype == gelu_of.dtype == E.dtype):
+        return None
+    dft = torch.empty_like(x)
+    ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(x.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
+                         L.ptr(dft), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+    return dft if ok else None
 
 
 # ---------------------------------------------------------------- [B,V] kernels

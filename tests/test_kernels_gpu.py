@@ -119,7 +119,7 @@ def test_gemm_nt_fused_with_layernorm_backward_matches_the_two_separate_kernels(
     gemm_nt followed by layernorm_bwd, and against torch autograd in fp32"""
     from sparse_hip import lib
     dtype = torch.bfloat16
-    for M, K in ((6200, 1024), (6151, 1536)):
+    for M, K in ((6200, 1024), (6151, 1536), (6160, 384)):
         N = 384
         A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.05), dtype)
         res, x = q(rnd(M, N, seed=3), dtype), q(rnd(M, N, seed=4, scale=2.0), dtype)
@@ -144,12 +144,54 @@ def test_gemm_nt_fused_with_layernorm_backward_matches_the_two_separate_kernels(
         xr = x.clone().requires_grad_(True)
         torch.nn.functional.layer_norm(xr, (N,), gamma, beta, 1e-12).backward(dyr)
         assert fro(dx1.cpu(), xr.grad) <= 2e-2
+        # no residual (the head transform's input gradient), and the embedding form: dropout between the LayerNorm and dy
+        dyd = lib.dropout(0.1, 77, 3)
+        dy = ops.gemm_nt(dev(A, dtype), dev(B, dtype))
+        dg0, db0 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        dx0, _ = ops.layernorm_bwd(ops.dropout_bwd(dy, dyd), dev(x, dtype), dev(gamma), mean, rstd, dg0, db0)
+        dg1, db1 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        out = ops.gemm_nt_ln_bwd(dev(A, dtype), dev(B, dtype), None, dev(x, dtype), dev(gamma), mean, rstd, dg1, db1, dy_drop=dyd)
+        assert out is not None and out[1] is None
+        assert fro(out[0], dx0) <= 1e-2 and fro(dg1, dg0) <= 1e-2 and fro(db1, db0) <= 1e-2, (fro(out[0], dx0), fro(dg1, dg0))
     # shapes the fused kernel does not take are declined, not mis-computed
     A, B = dev(q(rnd(500, 1024, seed=1), dtype), dtype), dev(q(rnd(384, 1024, seed=2), dtype), dtype)
     xs = dev(q(rnd(500, 384, seed=3), dtype), dtype)
     _, mean, rstd = ops.layernorm_fwd(xs, dev(torch.ones(384)), dev(torch.zeros(384)), 1e-12)
     z = torch.zeros(384, device="cuda")
     assert ops.gemm_nt_ln_bwd(A, B, xs, xs, dev(torch.ones(384)), mean, rstd, z, z.clone()) is None
+
+
+def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops):
+    """dt = G.E never goes to HBM: LayerNorm' and GELU' of the head transform run in the kernel's epilogue (bf16, H = 384);
+    against sparse_head_bwd(dt) -> layernorm_bwd -> gelu_bwd"""
+    dtype = torch.bfloat16
+    B, S, H, V = 24, 128, 384, 3000
+    t = q(rnd(B * S, H, seed=1), dtype)
+    E = q(rnd(V, H, seed=2, scale=0.2), dtype)
+    bias = 0.1 * rnd(V, seed=3)
+    mask = (torch.arange(S)[None, :] < torch.randint(20, S + 1, (B, 1), generator=torch.Generator().manual_seed(4))).to(torch.uint8)
+    rep, argmax = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask, torch.uint8), B, S, V, False, None)
+    grad_rep = dev(rnd(B, V, seed=5).abs())
+    gt = q(rnd(B * S, H, seed=6, scale=1.5), dtype)   # LayerNorm input
+    ft = q(rnd(B * S, H, seed=7), dtype)              # GELU input
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=8), 0.1 * rnd(H, seed=9)
+    _, mean, rstd = ops.layernorm_fwd(dev(gt, dtype), dev(gamma), dev(beta), 1e-12)
+    dE, db = torch.zeros(V, H, device="cuda"), torch.zeros(V, device="cuda")
+    dt = ops.sparse_head_bwd(grad_rep, rep, argmax, dev(t, dtype), dev(E, dtype), dE, db, B, S, V, False, None, part="dt")
+    dg0, db0 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    dgt, _ = ops.layernorm_bwd(dt, dev(gt, dtype), dev(gamma), mean, rstd, dg0, db0)
+    dft0 = ops.gelu_bwd(dgt, dev(ft, dtype))
+    dg1, db1 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    dft1 = ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, dev(E, dtype), B, S, V, False, None, dev(gt, dtype), dev(gamma), mean, rstd,
+                                     dev(ft, dtype), dg1, db1)
+    assert dft1 is not None, "the fused kernel must take this shape"
+    fro = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    assert fro(dft1, dft0) <= 1e-2 and fro(dg1, dg0) <= 1e-2 and fro(db1, db0) <= 1e-2, (fro(dft1, dft0), fro(dg1, dg0), fro(db1, db0))
+    assert float((dft1.float() - dft0.float()).abs().max()) <= 2e-2 * float(dft0.float().abs().max())
+    # other hidden sizes are declined
+    x256 = dev(q(rnd(B * S, 256, seed=1), dtype), dtype)
+    assert ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, dev(q(rnd(V, 256, seed=2), dtype), dtype), B, S, V, False, None, x256, dev(torch.ones(256)),
+                                     mean, rstd, x256, torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")) is None
 
 
 # ------------------------------------------------------------------ GEMM TN
