@@ -241,6 +241,13 @@ typedef struct sm_cast_desc {
 int sm_cast_weights_multi(int dtype, const sm_cast_desc* descs_dev, int n, int total_tiles, void* stream);
 /* scalar helpers on device: out = a*x + b*y (all device scalars or arrays of n) */
 int sm_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
+/* The scalar tail of compute_loss (trainer.py:101-141) in one launch, all values DEVICE scalars:
+ *   ranking = sum_i weights[i] * losses[i][0]        (losses / weights: HOST arrays of n_losses <= 4 device pointers / floats)
+ *   total   = ranking + lambda_d * flops_d[0] + lambda_q * flops_q[0]      (either flops pointer may be NULL)
+ *   moving_avg = ma_new * ranking + (1 - ma_new) * moving_avg              (NULL: skipped; trainer.py:120-122) */
+int sm_loss_combine(const float* const* losses, const float* weights, int n_losses, const float* flops_d, float lambda_d,
+                    const float* flops_q, float lambda_q, float* ranking, float* total, float* moving_avg, float ma_new,
+                    void* stream);
 /* x[i] *= s[0] * c with s a DEVICE scalar (autograd's upstream gradient): no host sync */
 int sm_scale_by(float* x, const float* s, float c, long n, void* stream);
 

@@ -591,8 +591,11 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
   const float* sLse = sLse0 + hh * S;
   const float* sDelta = sDelta0 + hh * S;
   char* patch = sPatch0 + hh * 512;
-  char* patch_w = patch + li * 32 + g * 8;                                                   // dS[q = 4g .. 4g+3][key = li] -> patch[key][q]
-  const lds_v4* patch_r = (const lds_v4*)(patch + (4 * g + (li >> 2)) * 32 + (li & 3) * 8);  // -> column li of rows 4g .. 4g+3
+  // dS[q = 4g .. 4g+3][key = li] -> patch[key][q] (32-byte rows); the 8-byte chunk index is XORed with 2 * (row >> 3): rows r and
+  // r + 8 start in the same bank, and a half wave writes both (25 % of this kernel's LDS cycles were bank conflicts without it)
+  char* patch_w = patch + li * 32 + ((g ^ ((li >> 3) << 1)) * 8);
+  const int prow = 4 * g + (li >> 2);
+  const lds_v4* patch_r = (const lds_v4*)(patch + prow * 32 + (((li & 3) ^ ((prow >> 3) << 1)) * 8));  // -> column li of rows 4g .. 4g+3
   const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
   f32x4 dq[NQT][DH / 16];
 #pragma unroll

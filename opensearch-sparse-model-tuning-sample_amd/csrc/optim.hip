@@ -103,7 +103,50 @@ __global__ void scale_by_kernel(float* __restrict__ x, const float* __restrict__
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= f;
 }
 
+// ranking = sum_i w_i * l_i ; total = ranking + lambda_d * flops_d + lambda_q * flops_q ; ma = ma_new * ranking + (1 - ma_new) * ma
+struct LossTerms {
+  const float* l[4];
+  float w[4];
+  const float* flops_d;
+  const float* flops_q;
+  float lambda_d, lambda_q, ma_new;
+};
+__global__ void loss_combine_kernel(LossTerms t, float* __restrict__ ranking, float* __restrict__ total, float* __restrict__ ma) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (t.l[i]) r += t.w[i] * t.l[i][0];
+  float tot = r;
+  if (t.flops_d) tot += t.lambda_d * t.flops_d[0];
+  if (t.flops_q) tot += t.lambda_q * t.flops_q[0];
+  ranking[0] = r;
+  total[0] = tot;
+  if (ma) ma[0] = t.ma_new * r + (1.f - t.ma_new) * ma[0];
+}
+
 }  // namespace
+
+extern "C" int sm_loss_combine(const float* const* losses, const float* weights, int n_losses, const float* flops_d, float lambda_d,
+                               const float* flops_q, float lambda_q, float* ranking, float* total, float* moving_avg, float ma_new,
+                               void* stream) {
+  SM_REQUIRE(n_losses >= 0 && n_losses <= 4, "sm_loss_combine: %d loss terms (at most 4)", n_losses);
+  SM_REQUIRE(ranking && total, "sm_loss_combine: null output");
+  LossTerms t{};
+  for (int i = 0; i < n_losses; ++i) {
+    SM_REQUIRE(losses[i] != nullptr, "sm_loss_combine: null loss term %d", i);
+    t.l[i] = losses[i];
+    t.w[i] = weights[i];
+  }
+  t.flops_d = flops_d;
+  t.flops_q = flops_q;
+  t.lambda_d = lambda_d;
+  t.lambda_q = lambda_q;
+  t.ma_new = ma_new;
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, ranking, total, moving_avg);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
 
 extern "C" int sm_scale_by(float* x, const float* s, float c, long n, void* stream) {
   SM_REQUIRE(n > 0, "sm_scale_by: n=%ld", n);

@@ -150,8 +150,8 @@ class SparseModelTrainer:
         cap = model_wrapper_input["q_input_ids"].shape[1] if self.model_args.inf_free else None
         for loss_function in self.loss_functions:
             loss_function.sparse_query_cap = cap
-        if self._use_score_exchange():
-            return self._compute_loss_score_exchange(d_rep, q_rep, inputs, cap, return_outputs)
+        if self._use_fused_loss():
+            return self._compute_loss_fused(d_rep, q_rep, inputs, cap, return_outputs)
         d_rep = gather_rep(d_rep, self.accelerator)
         q_rep = gather_rep(q_rep, self.accelerator)
         if "scores" in inputs:
@@ -197,25 +197,36 @@ class SparseModelTrainer:
             raise KeyError(mode)
         return mode == "scores"
 
-    def _compute_loss_score_exchange(self, d_rep, q_rep, inputs, cap, return_outputs):
-        kinds = {InfoNCELoss: "infonce", KLDivLoss: "kldiv", MarginMSELoss: "marginmse"}
-        losses = [(kinds[type(lf)], lf.weight, bool(lf.use_in_batch_negatives), float(getattr(lf, "temperature", 1.0)))
+    _BUILTIN_LOSSES = {InfoNCELoss: "infonce", KLDivLoss: "kldiv", MarginMSELoss: "marginmse"}
+
+    def _use_fused_loss(self) -> bool:
+        """The whole loss head as ONE autograd node (sparse_hip.functional.distributed_loss: same values and gradients as the
+        reference-form code below it, one launch for the scalar tail, no autograd add of the two d_rep gradients): a single
+        process, or N > 1 with the score exchange -- when every loss object is one of the built-in classes (a user subclass
+        with its own get_loss takes the reference-form path)."""
+        if any(type(lf) not in self._BUILTIN_LOSSES for lf in self.loss_functions) or len(self.loss_functions) > 4:
+            return False
+        return self.accelerator.num_processes <= 1 or self._use_score_exchange()
+
+    def _compute_loss_fused(self, d_rep, q_rep, inputs, cap, return_outputs):
+        losses = [(self._BUILTIN_LOSSES[type(lf)], lf.weight, bool(lf.use_in_batch_negatives), float(getattr(lf, "temperature", 1.0)))
                   for lf in self.loss_functions]
+        n = self.accelerator.num_processes
         teacher = None
         if "scores" in inputs:
             teacher = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
-        cfg = {"losses": losses, "q_cap": cap, "flops_threshold": self.data_args.flops_threshold,
+        # (the moving average ma = 0.01 * ranking + 0.99 * ma of trainer.py:120-122 is updated by the same launch)
+        cfg = {"losses": losses, "q_cap": cap, "flops_threshold": self.data_args.flops_threshold, "moving_avg": self._ma,
                "lambda_d": self.get_lambda(self.data_args.flops_d_lambda, self.data_args.flops_d_T),
                "lambda_q": None if self.model_args.inf_free else self.get_lambda(self.data_args.flops_q_lambda,
                                                                                  self.data_args.flops_q_T)}
         loss = F.distributed_loss(d_rep, q_rep, teacher, cfg)
         out = cfg["out"]
-        rl = out["ranking"].reshape(1).float()
-        ops.axpby(0.01, rl, 0.99, self._ma, self._ma)
-        self._last = {"d_flops": out["d_flops"], "flops_loss": (loss.detach() - out["ranking"]), "d_rep": d_rep.detach()}
+        self._last = {"d_flops": out["d_flops"], "total": loss.detach(), "ranking": out["ranking"], "d_rep": d_rep.detach()}
         if self.state.global_step % self.args.logging_steps == 0:
             self._log_step()
-        loss = loss * self.accelerator.num_processes  # DDP averages, trainer.py:139-141
+        if n > 1:
+            loss = loss * n  # DDP averages, trainer.py:139-141
         if not return_outputs:
             return loss
         with torch.no_grad():  # the reference returns the gathered representations
@@ -224,6 +235,8 @@ class SparseModelTrainer:
 
     def _log_step(self):
         d_rep = self._last["d_rep"]
+        if "flops_loss" not in self._last:
+            self._last["flops_loss"] = self._last["total"] - self._last["ranking"]
         nz = d_rep[d_rep > 0]
         logger.info(
             "Step %d. ranking loss moving avg:%s, d_flops: %s, flops_loss: %s avg doc length: %s",

@@ -172,43 +172,66 @@ def gather_rep(rep: Tensor, accelerator=None, group=None) -> Tensor:
 # Per rank the traffic drops from (N-1) x 62.5 MB to a few MB and the loss kernels keep working on the LOCAL
 # documents (at N = 8 the dense form costs 2.1 ms of loss kernels on the gathered tensors against 0.27 ms).
 # The dense all-gather stays available as the parity mode (gather_rep + the single-process functions above).
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
 class _DistLossFn(torch.autograd.Function):
+    """One autograd node for the whole loss head.  N = 1 (also without torch.distributed): no collectives, and the scalar
+    tail (weights, lambdas, moving average) is one launch (ops.loss_combine) -- as separate nodes the loss section of a step
+    was ~30 launches of ~6 us each plus autograd's 62 MB add of the two d_rep gradients."""
+
     @staticmethod
     def forward(ctx, d_local: Tensor, q_local: Tensor, teacher: Optional[Tensor], cfg: dict):
         group = cfg.get("group")
-        N, rank = dist.get_world_size(group), dist.get_rank(group)
+        N, rank = _world(group)
         d, q = _f32c(d_local), _f32c(q_local)
         nq, nd, V = q.shape[0], d.shape[0], d.shape[1]
         if nd % nq:
             raise L.SparseHipError(f"d_rep rows {nd} must be a multiple of q_rep rows {nq}")
         k = nd // nq
         thr, cap = cfg.get("flops_threshold"), cfg.get("q_cap")
-        q_all = torch.empty((N * nq, V), dtype=torch.float32, device=q.device)
-        dist.all_gather_into_tensor(q_all, q, group=group)
+        if N > 1:
+            q_all = torch.empty((N * nq, V), dtype=torch.float32, device=q.device)
+            dist.all_gather_into_tensor(q_all, q, group=group)
+        else:
+            q_all = q
 
         # FLOPS regulariser: global column means = mean of the per-rank column means (equal local batch sizes)
-        _, cm_d, keep_d = ops.flops_fwd(d, k, thr)
-        dist.all_reduce(cm_d, group=group)
-        cm_d.div_(N)
-        d_flops = (cm_d * cm_d).sum()
-        total = d_flops * float(cfg["lambda_d"])
-        cm_q = keep_q = None
+        d_flops, cm_d, keep_d = ops.flops_fwd(d, k, thr)
+        if N > 1:
+            dist.all_reduce(cm_d, group=group)
+            cm_d.div_(N)
+            d_flops = (cm_d * cm_d).sum().reshape(1)
+        cm_q = keep_q = q_flops = None
         if cfg.get("lambda_q") is not None:
-            _, cm_q, keep_q = ops.flops_fwd(q, 1, thr)
-            dist.all_reduce(cm_q, group=group)
-            cm_q.div_(N)
-            total = total + (cm_q * cm_q).sum() * float(cfg["lambda_q"])
+            q_flops, cm_q, keep_q = ops.flops_fwd(q, 1, thr)
+            if N > 1:
+                dist.all_reduce(cm_q, group=group)
+                cm_q.div_(N)
+                q_flops = (cm_q * cm_q).sum().reshape(1)
 
         losses = cfg["losses"]  # [(kind, weight, ibn, tau)]
-        ranking = torch.zeros((), dtype=torch.float32, device=d.device)
+        terms = []              # (device scalar, weight) of the ranking loss
         ds_ibn = ds_pairs = csr_all = csr_loc = None
+
+        def weighted(acc, g, w):
+            if acc is None:
+                return g if float(w) == 1.0 else g * float(w)
+            return acc.add_(g, alpha=float(w)) if acc is not g else acc
+
         if any(ibn for _, _, ibn, _ in losses):
             csr_all = ops.row_compact(q_all, int(cap)) if cap else None
             s_r = ops.scores_csr_fwd(csr_all, d, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, d, pairs=False)
-            s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
-            dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
-            scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
-            ds_full = torch.zeros_like(scores)
+            if N > 1:
+                s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
+                dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
+                scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
+            else:
+                scores = s_r
+            ds_full, owned = None, False
             for kind, w, ibn, tau in losses:
                 if not ibn:
                     continue
@@ -219,30 +242,39 @@ class _DistLossFn(torch.autograd.Function):
                     if tuple(t.shape) != tuple(scores.shape):
                         raise L.SparseHipError(f"teacher scores {tuple(t.shape)} do not match student scores {tuple(scores.shape)}")
                     l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(scores, t, tau)
-                ranking = ranking + l.reshape(()) * float(w)
-                ds_full.add_(g, alpha=float(w))
-            ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous()
+                terms.append((l, float(w)))
+                ds_full = weighted(ds_full, g, w)
+            ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous() if N > 1 else ds_full
+        lp_terms = []
         if any(not ibn for _, _, ibn, _ in losses):
             csr_loc = ops.row_compact(q, int(cap)) if cap else None
             sp = ops.scores_csr_fwd(csr_loc, d, pairs=True) if csr_loc is not None else ops.scores_fwd(q, d, pairs=True)
-            ds_pairs = torch.zeros_like(sp)
-            lp = torch.zeros((), dtype=torch.float32, device=d.device)
             for kind, w, ibn, tau in losses:
                 if ibn:
                     continue
                 if kind == "infonce":
                     l, g = ops.infonce(sp, k, pairs=True)
                 else:
-                    t = _f32c(teacher)[rank * nq:(rank + 1) * nq].contiguous()  # teacher arrives gathered [N*bs, k]
+                    t = _f32c(teacher)
+                    if N > 1:
+                        t = t[rank * nq:(rank + 1) * nq].contiguous()  # teacher arrives gathered [N*bs, k]
                     l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(sp, t, tau)
-                lp = lp + l.reshape(()) * float(w)
-                ds_pairs.add_(g, alpha=float(w))
-            lp_all = lp.reshape(1).clone()
-            dist.all_reduce(lp_all, group=group)  # mean over all queries = mean of the per-rank means
-            ranking = ranking + lp_all.reshape(()) / N
-            ds_pairs.div_(N)
-        total = total + ranking
-        cfg["out"] = {"d_flops": d_flops.detach(), "ranking": ranking.detach()}
+                lp_terms.append((l, float(w)))
+                ds_pairs = weighted(ds_pairs, g, w)
+            if N > 1:  # mean over all queries = mean of the per-rank means
+                lp = lp_terms[0][0].reshape(()) * lp_terms[0][1]
+                for l, w in lp_terms[1:]:
+                    lp = lp + l.reshape(()) * w
+                lp_all = lp.reshape(1).clone()
+                dist.all_reduce(lp_all, group=group)
+                terms.append((lp_all, 1.0 / N))
+                ds_pairs = ds_pairs / N
+            else:
+                terms += lp_terms
+        ranking, total = ops.loss_combine(terms, d_flops, float(cfg["lambda_d"]), q_flops,
+                                          float(cfg["lambda_q"]) if q_flops is not None else 0.0,
+                                          cfg.get("moving_avg"), float(cfg.get("ma_new", 0.01)))
+        cfg["out"] = {"d_flops": d_flops.reshape(()), "ranking": ranking}
         ctx.cfg, ctx.N, ctx.rank, ctx.k = cfg, N, rank, k
         ctx.csr_all, ctx.csr_loc, ctx.group = csr_all, csr_loc, group
         ctx.has = (ds_ibn is not None, ds_pairs is not None, keep_d is not None, cm_q is not None, keep_q is not None)
@@ -272,7 +304,8 @@ class _DistLossFn(torch.autograd.Function):
                 ops.scores_bwd(q_all, d, ds, False, dq_all, dd, False)
             wrote = True
             if need_q:  # every rank holds the part of dL/dq_all that flows through ITS documents
-                dist.all_reduce(dq_all, group=group)
+                if N > 1:
+                    dist.all_reduce(dq_all, group=group)
                 dq.add_(dq_all[rank * nq:(rank + 1) * nq])
         if has_pairs:
             ds = ops.scale_by(ds_pairs.clone(), gs)
@@ -299,7 +332,8 @@ class _DistLossFn(torch.autograd.Function):
 def distributed_loss(d_local: Tensor, q_local: Tensor, teacher: Optional[Tensor], cfg: dict) -> Tensor:
     """Global ranking + FLOPS loss from LOCAL representations (see _DistLossFn).  cfg: losses = [(kind, weight,
     in_batch_negatives, temperature)], lambda_d, lambda_q (None when the queries are inference-free), flops_threshold,
-    q_cap, group.  After the call cfg["out"] holds {"d_flops", "ranking"} for logging."""
+    q_cap, group, and optionally moving_avg (a device scalar updated in place with ma_new, default 0.01, of the ranking
+    loss).  Works for a single process too (no collectives).  After the call cfg["out"] holds {"d_flops", "ranking"}."""
     for kind, _, _, _ in cfg["losses"]:
         if kind not in ("infonce", "kldiv", "marginmse"):
             raise KeyError(kind)

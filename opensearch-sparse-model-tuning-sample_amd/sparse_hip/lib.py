@@ -85,6 +85,7 @@ SIGNATURES = {
     "sm_cast_weight": [_i, _p, _i, _i, _p, _i, _p, _i, _p],
     "sm_cast_weights_multi": [_i, _p, _i, _i, _p],
     "sm_axpby": [_f, _p, _f, _p, _p, _l, _p],
+    "sm_loss_combine": [C.POINTER(C.c_void_p), C.POINTER(C.c_float), _i, _p, _f, _p, _f, _p, _p, _p, _f, _p],
     "sm_scale_by": [_p, _p, _f, _l, _p],
     "sm_peak_mfma_bf16": [_p, _i, _i, _p],
     "sm_peak_copy": [_p, _p, C.c_size_t, _p],

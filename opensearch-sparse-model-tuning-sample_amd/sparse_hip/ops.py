@@ -386,5 +386,20 @@ def scale_by(x: Tensor, s: Tensor, c: float = 1.0) -> Tensor:
     return x
 
 
+def loss_combine(terms, flops_d: Optional[Tensor], lambda_d: float, flops_q: Optional[Tensor], lambda_q: float,
+                 moving_avg: Optional[Tensor] = None, ma_new: float = 0.01):
+    """(ranking, total) device scalars: ranking = sum w_i l_i over terms = [(l_i, w_i)], total = ranking + lambda_d flops_d +
+    lambda_q flops_q; moving_avg (in place) = ma_new ranking + (1 - ma_new) moving_avg.  One launch, no host sync."""
+    import ctypes as C
+    n = len(terms)
+    ref = flops_d if flops_d is not None else terms[0][0]
+    out = torch.empty(2, dtype=torch.float32, device=ref.device)
+    ptrs = (C.c_void_p * max(n, 1))(*[L.ptr(l) for l, _ in terms])
+    ws = (C.c_float * max(n, 1))(*[float(w) for _, w in terms])
+    L.call("sm_loss_combine", ptrs, ws, n, L.ptr(flops_d), float(lambda_d), L.ptr(flops_q), float(lambda_q), L.ptr(out[0:1]),
+           L.ptr(out[1:2]), L.ptr(moving_avg), float(ma_new), L.stream_ptr())
+    return out[0], out[1]
+
+
 def axpby(a: float, x: Optional[Tensor], b: float, y: Optional[Tensor], out: Tensor):
     L.call("sm_axpby", float(a), L.ptr(x), float(b), L.ptr(y), L.ptr(out), out.numel(), L.stream_ptr())
