@@ -80,6 +80,12 @@ typedef struct sm_epilogue {
   const void* gelu_grad_of; /* [M,N] (ldc) dtype, or NULL (backward of hf:336) */
   int residual_f32;         /* 1: `residual` is fp32 whatever dtype says   } the fp32 RESIDUAL STREAM of bf16 runs: what torch      */
   int out_f32;              /* 1: C is written as fp32 whatever dtype says } autocast keeps in fp32 around hf:289-293, 347-351     */
+  /* residual_f32 only, all four or none: `residual` holds the fp32 INPUT z of the LayerNorm whose output is the residual, and
+   * the epilogue adds (z - mean[m]) * rstd[m] * gamma[n] + beta[n] -- the fp32 LayerNorm output never has to be stored */
+  const float* res_ln_mean;
+  const float* res_ln_rstd;
+  const float* res_ln_gamma;
+  const float* res_ln_beta;
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

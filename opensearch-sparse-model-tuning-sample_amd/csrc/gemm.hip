@@ -277,6 +277,7 @@ struct EpiArgs {
   const void* residual;
   const void* gelu_grad_of;
   int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
+  const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // res32: residual = LayerNorm(residual) recomputed from its fp32 input
 };
 
 template <typename T, bool GLDS>
@@ -352,6 +353,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
           float rv[8];
           if (e.res32) load8<float>(reinterpret_cast<const float*>(e.residual) + off, rv, full, N - col);
           else load8<T>(residual + off, rv, full, N - col);
+          if (e.rl_mean) {
+            const float mu = e.rl_mean[row], rs = e.rl_rstd[row];
+            float ga[8], be[8];
+            load8<float>(e.rl_gamma + col, ga, full, N - col);
+            load8<float>(e.rl_beta + col, be, full, N - col);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = (rv[k] - mu) * rs * ga[k] + be[k];
+          }
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] += rv[k];
         }
@@ -1343,6 +1352,14 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
           float rv[8];
           if (e.res32) load8<float>(reinterpret_cast<const float*>(e.residual) + off, rv, true, 8);
           else load8<bf16>(residual + off, rv, true, 8);
+          if (e.rl_mean) {
+            const float mu = e.rl_mean[row], rs = e.rl_rstd[row];
+            float ga[8], be[8];
+            load8<float>(e.rl_gamma + col, ga, true, 8);
+            load8<float>(e.rl_beta + col, be, true, 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = (rv[q] - mu) * rs * ga[q] + be[q];
+          }
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += rv[q];
         }
@@ -1371,6 +1388,13 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
   e.res32 = epi ? epi->residual_f32 : 0;
   e.out32 = epi ? epi->out_f32 : 0;
+  e.rl_mean = epi ? epi->res_ln_mean : nullptr;
+  e.rl_rstd = epi ? epi->res_ln_rstd : nullptr;
+  e.rl_gamma = epi ? epi->res_ln_gamma : nullptr;
+  e.rl_beta = epi ? epi->res_ln_beta : nullptr;
+  SM_REQUIRE(!e.rl_mean || (e.res32 && e.residual && e.rl_rstd && e.rl_gamma && e.rl_beta && N % 8 == 0 && ((uintptr_t)e.rl_gamma % 16) == 0 &&
+                            ((uintptr_t)e.rl_beta % 16) == 0),
+             "sm_gemm_nt: res_ln_* need an fp32 residual, all four pointers, N %% 8 == 0");
   constexpr int xcd_on = 1;
   e.xcd = xcd_on;
   const uintptr_t vb = 8 * sizeof(T);

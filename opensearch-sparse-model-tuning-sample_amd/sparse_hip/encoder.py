@@ -367,7 +367,11 @@ class HipBertMLM(torch.nn.Module):
                             v(e + "token_type_embeddings.weight")[0], v(e + "LayerNorm.weight"),
                             v(e + "LayerNorm.bias"), eps, d_emb, rag, want_y32=r32)
         z0, x, m0, r0 = emb[:4]
-        x32 = emb[4] if r32 else None  # fp32 copy of the residual stream (None: the residual is x itself)
+        # fp32 residual stream: the residual of a block is the fp32 OUTPUT of the previous LayerNorm.  Only the embedding
+        # stores it (x32); inside the layers the consuming GEMM epilogue recomputes it from that LayerNorm's stored fp32
+        # input and statistics (res_ln), so the [T, H] fp32 LayerNorm outputs are never written
+        x32 = emb[4] if r32 else None
+        res_ln = None  # (mean, rstd, gamma, beta) of the LayerNorm whose fp32 input x32 currently holds
         if save:
             saved["emb"] = (z0, m0, r0)
         for l in range(cfg.num_hidden_layers):
@@ -377,20 +381,23 @@ class HipBertMLM(torch.nn.Module):
             d_h2 = self._drop(ph, training, seed, l + 1, _Site.HID2)
             qkv = ops.gemm_nt(x, st[f"qkv{l}"], bias=self.qkv_bias(l))
             ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at, rag)
-            z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32)
+            z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
+                             residual_ln=res_ln)
             if r32:
-                x1, x1_32, m1, r1 = ops.layernorm_fwd_res32(z1, v(p + "attention.output.LayerNorm.weight"),
-                                                           v(p + "attention.output.LayerNorm.bias"), eps, x.dtype)
+                g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
+                x1, _, m1, r1 = ops.layernorm_fwd_res32(z1, g1, b1, eps, x.dtype, want_y32=False)
+                res1, res1_ln = z1, (m1, r1, g1, b1)
             else:
                 x1, m1, r1 = ops.layernorm_fwd(z1, v(p + "attention.output.LayerNorm.weight"),
                                                v(p + "attention.output.LayerNorm.bias"), eps)
-                x1_32 = None
+                res1, res1_ln = x1, None
             f1 = torch.empty((x1.shape[0], cfg.intermediate_size), dtype=x1.dtype, device=x1.device) if save else None
             ga = ops.gemm_nt(x1, st[f"w1{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
-            z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=x1_32 if r32 else x1, out_f32=r32)
+            z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
             if r32:
-                x2, x32, m2, r2 = ops.layernorm_fwd_res32(z2, v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias"), eps, x.dtype,
-                                                         want_y32=l + 1 < cfg.num_hidden_layers)
+                g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
+                x2, _, m2, r2 = ops.layernorm_fwd_res32(z2, g2, b2, eps, x.dtype, want_y32=False)
+                x32, res_ln = z2, (m2, r2, g2, b2)
             else:
                 x2, m2, r2 = ops.layernorm_fwd(z2, v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias"), eps)
             if save:

@@ -32,6 +32,10 @@ class SmEpilogue(C.Structure):
         ("gelu_grad_of", C.c_void_p),
         ("residual_f32", C.c_int),  # fp32 residual stream: `residual` is fp32 / C is written as fp32 whatever dtype says
         ("out_f32", C.c_int),
+        ("res_ln_mean", C.c_void_p),  # residual = LayerNorm(residual; mean, rstd, gamma, beta) computed in the epilogue
+        ("res_ln_rstd", C.c_void_p),
+        ("res_ln_gamma", C.c_void_p),
+        ("res_ln_beta", C.c_void_p),
     ]
 
 

@@ -161,6 +161,24 @@ def test_gemm_nt_fused_with_layernorm_backward_matches_the_two_separate_kernels(
     assert ops.gemm_nt_ln_bwd(A, B, xs, xs, dev(torch.ones(384)), mean, rstd, z, z.clone()) is None
 
 
+def test_gemm_nt_residual_recomputed_from_the_layernorm_input(ops):
+    """fp32 residual stream without storing the fp32 LayerNorm outputs: residual_ln = (mean, rstd, gamma, beta) makes the
+    epilogue add LayerNorm(residual) -- against the same GEMM fed the stored fp32 LayerNorm output (both GEMM kernels)"""
+    from sparse_hip import lib
+    dtype = torch.bfloat16
+    N = 384
+    for M, K in ((6200, 384), (6200, 1536), (333, 384)):
+        A, B = dev(q(rnd(M, K, seed=1, scale=0.5), dtype), dtype), dev(q(rnd(N, K, seed=2, scale=0.05), dtype), dtype)
+        z = dev(rnd(M, N, seed=3, scale=1.5) + 0.2)
+        gamma, beta, bias = dev(1.0 + 0.1 * rnd(N, seed=4)), dev(0.1 * rnd(N, seed=5)), dev(0.1 * rnd(N, seed=6))
+        y, y32, mean, rstd = ops.layernorm_fwd_res32(z, gamma, beta, 1e-12, dtype)
+        assert ops.layernorm_fwd_res32(z, gamma, beta, 1e-12, dtype, want_y32=False)[1] is None
+        drop = lib.dropout(0.1, 5, 2)
+        want = ops.gemm_nt(A, B, bias=bias, drop=drop, residual=y32, out_f32=True)
+        got = ops.gemm_nt(A, B, bias=bias, drop=drop, residual=z, out_f32=True, residual_ln=(mean, rstd, gamma, beta))
+        assert got.dtype == torch.float32 and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), (M, K)
+
+
 def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops):
     """dt = G.E never goes to HBM: LayerNorm' and GELU' of the head transform run in the kernel's epilogue (bf16, H = 384);
     against sparse_head_bwd(dt) -> layernorm_bwd -> gelu_bwd"""
