@@ -34,16 +34,26 @@ template <> struct AT<float> {
 // forward and in each backward phase -- with the general 64-bit-index hash (drop_keep1: two quarter-rate 32-bit multiplies,
 // ~22 issue slots) that was more than a third of these kernels' VALU work.  Here the (document, head) is folded into a
 // per-unit key once (full murmur finaliser, per wave), and the element, a 32-bit index q * S + key < 2^18, goes through two
-// rounds of FULL-rate 24-bit multiplies + xor-shifts (~8 slots; keep rate, neighbour / row / key correlations and bucket
-// uniformity checked against the expected sampling noise on 200 keys).
+// rounds of FULL-rate 24-bit multiplies + xor-shifts (keep rate, neighbour / row / key / byte-pair correlations and bucket
+// uniformity checked against the expected sampling noise on 300 keys).
 __device__ __forceinline__ uint32_t drop_unit_key(const DropCfg& d, uint32_t unit) { return fmix32(d.key ^ (unit * 0x9E3779B9u)); }
-__device__ __forceinline__ bool drop_keep_local(uint32_t ukey, uint32_t thresh16, uint32_t idx) {
-  uint32_t a = __umul24(idx ^ ukey, 0xD6E8FFu);
+// ONE hash serves the 2 x 2 block (q >> 1, key >> 1) of elements: element (q, key) owns byte (q & 1) * 2 + (key & 1) and is
+// kept when that byte >= the 8-bit threshold (p quantised to 1/256; the scale uses the quantised p, so the expectation is
+// exact).  A lane holds 4 consecutive keys of one query (S^T orientation) or 4 consecutive queries of one key (S
+// orientation): two blocks either way, so two hashes per four elements.
+__device__ __forceinline__ uint32_t drop_block_hash(uint32_t ukey, uint32_t blk) {
+  uint32_t a = __umul24(blk ^ ukey, 0xD6E8FFu);
   a ^= a >> 15;
   uint32_t b = __umul24(a, 0x9E3779u);
   b ^= b >> 13;
-  return (uint16_t)b >= (uint16_t)thresh16;
+  return b;
 }
+__device__ __forceinline__ bool drop_keep_byte(uint32_t h, uint32_t shift, uint32_t th8) { return ((h >> shift) & 0xFFu) >= th8; }
+struct Drop8 {
+  uint32_t th8;
+  float scale;
+  __device__ explicit Drop8(const DropCfg& d) : th8(d.thresh16 >> 8), scale(256.f / (256.f - (float)(d.thresh16 >> 8))) {}
+};
 
 // Byte offset of (row, byte column) in a row-major LDS image.  SWZ (bf16 images whose rows are exactly 128 B: head dim
 // 64, or two heads of 32 side by side): no padding, the 16-byte chunk index is XORed with (row & 7) -- conflict-free for
@@ -277,14 +287,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
   char* sK0 = smem;                         // [S][HP*DH] row-major
   char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
-  uint8_t* sM = reinterpret_cast<uint8_t*>(sV0 + S * L::RS);
+  float* sBias = reinterpret_cast<float*>(sV0 + S * L::RS);  // per key: 0, or -inf for masked / padding keys
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
   stage2_batched<T, HP * DH, L::SWZ, NKT * 16 * (HP * DH * (int)sizeof(T) / 16) / 256>(base0 + H, ld, base0 + 2 * H, ld, Lr, nkt * 16, sK0, sV0, L::RS);
-  for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
+  for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sBias[i] = (i < Lr && keymask[(size_t)row0 + i]) ? 0.f : -INFINITY;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-  const float scale = rsqrtf((float)DH);
+  // scores in the log2 domain: exp(x - m) = exp2(x * log2e - m * log2e), one v_exp_f32 and no extra multiply
+  const float scale2 = rsqrtf((float)DH) * 1.4426950408889634f;
+  const Drop8 d8(drop);
   for (int u = w; u < nqb * HP; u += 4) {  // units = (query block, head)
     const int qb = u / HP, hh = u % HP, h = h0 + hh;
     const T* base = base0 + hh * DH;
@@ -298,11 +310,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
         p[kt] = dh_product<T, DH, L::SWZ>(sK0, L::RS, cof, kt * 16 + li, g, fq);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float s = sM[kt * 16 + 4 * g + r] ? p[kt][r] * scale : -INFINITY;
-          p[kt][r] = s;
-          mx = fmaxf(mx, s);
+          const float sc = fmaf(p[kt][r], scale2, bias[r]);
+          p[kt][r] = sc;
+          mx = fmaxf(mx, sc);
         }
       } else {
         p[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -310,13 +323,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = fmaxf(mx, -1e30f);  // a fully masked row: exp2(-inf - (-1e30)) = 0 without a select per element
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
       if (kt < nkt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = mx == -INFINITY ? 0.f : __expf(p[kt][r] - mx);
+          const float e = __builtin_amdgcn_exp2f(p[kt][r] - mxs);
           p[kt][r] = e;
           sum += e;
         }
@@ -324,17 +338,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     const int q = qb * 16 + li;
-    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h)), ebase = (uint32_t)(q * S);
+    if constexpr (DROP) {
+      const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+      const uint32_t blk0 = (uint32_t)((q >> 1) * (S >> 1) + 2 * g), sh = 16u * (li & 1);
+      const float invd = inv * d8.scale;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-      if (kt < nkt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = p[kt][r] * inv;
-          if constexpr (DROP) v = drop_keep_local(ukey, drop.thresh16, ebase + kt * 16 + 4 * g + r) ? v * drop.scale : 0.f;
-          p[kt][r] = v;
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+          const uint32_t h0 = drop_block_hash(ukey, blk0 + kt * 8), h1 = drop_block_hash(ukey, blk0 + kt * 8 + 1);
+          p[kt][0] *= drop_keep_byte(h0, sh, d8.th8) ? invd : 0.f;
+          p[kt][1] *= drop_keep_byte(h0, sh + 8, d8.th8) ? invd : 0.f;
+          p[kt][2] *= drop_keep_byte(h1, sh, d8.th8) ? invd : 0.f;
+          p[kt][3] *= drop_keep_byte(h1, sh + 8, d8.th8) ? invd : 0.f;
         }
-    if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx + __logf(sum);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[kt][r] *= inv;
+    }
+    if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx * 0.6931471805599453f + __logf(sum);
     typename PT<T>::type pp[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) pp[kt] = PT<T>::pack(p[kt]);
@@ -415,7 +439,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       fdo[ks] = grow_frag<T>(dob, H, q, ks, g);
     }
     const float lq = sLse0[hh * S + q], dl = sDelta0[hh * S + q];
-    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h)), ebase = (uint32_t)(q * S);
+    const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+    const uint32_t blk0 = (uint32_t)((q >> 1) * (S >> 1) + 2 * g), sh = 16u * (li & 1);
+    const Drop8 d8(drop);
     f32x4 dq[DH / 16];
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -427,13 +453,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         const f32x4 s = dh_product<T, DH, L::SWZ>(sX0, L::RS, cof, kt * 16 + li, g, fq);
         const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, kt * 16 + li, g, fdo);
         const uint32_t m4 = *reinterpret_cast<const uint32_t*>(sM + kt * 16 + 4 * g);
+        uint32_t hk[2] = {0u, 0u};
+        if constexpr (DROP) {
+          hk[0] = drop_block_hash(ukey, blk0 + kt * 8);
+          hk[1] = drop_block_hash(ukey, blk0 + kt * 8 + 1);
+        }
         f32x4 dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
           const float pv = ((m4 >> (8 * r)) & 0xFF) ? __expf(s[r] * scale - lq) : 0.f;
           float dpv = dp[r];
-          if constexpr (DROP) dpv = drop_keep_local(ukey, drop.thresh16, ebase + key) ? dpv * drop.scale : 0.f;
+          if constexpr (DROP) dpv = drop_keep_byte(hk[r >> 1], sh + 8 * (r & 1), d8.th8) ? dpv * d8.scale : 0.f;
           dsv[r] = pv * (dpv - dl) * scale;
         }
         ds[hh] = PT<T>::pack(dsv);
@@ -472,6 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+    const Drop8 d8(drop);
     for (int t2 = 0; t2 < nt / 2; ++t2) {
       typename PT<T>::type pd[2], ds[2];
 #pragma unroll
@@ -481,13 +512,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, qt * 16 + li, g, fv);
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
+        uint32_t hq[2] = {0u, 0u};
+        if constexpr (DROP) {
+          const uint32_t blk = (uint32_t)((qt * 8 + 2 * g) * (S >> 1) + (key >> 1));
+          hq[0] = drop_block_hash(ukey, blk);
+          hq[1] = drop_block_hash(ukey, blk + (uint32_t)(S >> 1));
+        }
         f32x4 pdv, dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * g + r;
           const float pv = kvalid ? __expf(s[r] * scale - l4[r]) : 0.f;
           float keepf = 1.f;
-          if constexpr (DROP) keepf = drop_keep_local(ukey, drop.thresh16, (uint32_t)(q * S + key)) ? drop.scale : 0.f;
+          if constexpr (DROP) keepf = drop_keep_byte(hq[r >> 1], 16u * (r & 1) + 8u * (li & 1), d8.th8) ? d8.scale : 0.f;
           pdv[r] = pv * keepf;
           dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
         }
@@ -561,7 +597,7 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
     for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
       sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
 #pragma unroll
-      for (int hh = 0; hh < HP; ++hh) sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] : 0.f;
+      for (int hh = 0; hh < HP; ++hh) sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] * 1.4426950408889634f : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -584,7 +620,8 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 
   const int lane = threadIdx.x & 63, hh = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int h = h0 + hh;
-  const float scale = rsqrtf((float)DH);
+  const float scale = rsqrtf((float)DH), scale2 = scale * 1.4426950408889634f;
+  const Drop8 d8(drop);
   const int cof = hh * DH * (int)sizeof(T);
   const T* base = base0 + hh * DH;
   T* dq_out = dqkv + (size_t)row0 * ld + h * DH;
@@ -634,17 +671,22 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
           const int qt = 2 * t2 + hh2;
           const f32x4 sv = dh_product<T, DH, L::SWZ>(sX0, L::RS, cof, qt * 16 + li, g, fk);
           const f32x4 dp = dh_product<T, DH, L::SWZ>(sY0, L::RS, cof, qt * 16 + li, g, fv);
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);  // (log2 domain, see the staging loop)
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
+          uint32_t hq[2] = {0u, 0u};
+          if constexpr (DROP) {
+            const uint32_t blk = (uint32_t)((qt * 8 + 2 * g) * (S >> 1) + (key >> 1));
+            hq[0] = drop_block_hash(ukey, blk);
+            hq[1] = drop_block_hash(ukey, blk + (uint32_t)(S >> 1));
+          }
           f32x4 pdv, dsv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int q = qt * 16 + 4 * g + r;
-            const float pv = kvalid ? __expf(sv[r] * scale - l4[r]) : 0.f;
+            const float pv = kvalid ? __builtin_amdgcn_exp2f(fmaf(sv[r], scale2, -l4[r])) : 0.f;
             float keepf = 1.f;
-            if constexpr (DROP) keepf = drop_keep_local(ukey, drop.thresh16, (uint32_t)(q * S + key)) ? drop.scale : 0.f;
+            if constexpr (DROP) keepf = drop_keep_byte(hq[r >> 1], 16u * (r & 1) + 8u * (li & 1), d8.th8) ? d8.scale : 0.f;
             pdv[r] = pv * keepf;
-            dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
+            dsv[r] = pv * (dp[r] * keepf - d4[r]);  // (the 1/sqrt(dh) factor of dS is applied to dQ and dK when they are stored)
           }
           pd[hh2] = PT<T>::pack(pdv);
           ds[hh2] = PT<T>::pack(dsv);
@@ -663,7 +705,7 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
       store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv[dt]);
-      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt]);
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt] * scale);
     }
   }
   // dQ accumulators: rows = queries 4g + r, col = d = li
@@ -673,13 +715,13 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)dq[qt][dt][r];
+        for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)(dq[qt][dt][r] * scale);
 }
 template <int DH, int HP>
 size_t bwd1_lds(int S) { return 2 * (size_t)S * Lay<bf16, HP * DH>::RS + HP * 8 * (size_t)S + HP * 512 + S; }
 
 template <typename T, int DH, int HP>
-size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + S; }
+size_t fwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + 4 * (size_t)S; }
 template <typename T, int DH, int HP>
 size_t bwd_lds(int S) { return 2 * (size_t)S * Lay<T, HP * DH>::RS + HP * 8 * (size_t)S + S; }
 // two heads per workgroup where a head's row is half a cache line and the pair's images fit
