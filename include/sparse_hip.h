@@ -43,7 +43,8 @@ const char* sm_last_error(void);
 int sm_abi_version(void);
 
 /* ---- dropout descriptor (torch.nn.Dropout inside hf:63,158,287,345) -----------
- * mask = hash(seed, site, element index) >= p, regenerated identically in backward. */
+ * keep(e) = one byte of hash(seed, site, e >> 2) >= p_q, p_q = p rounded to 1/256 (at least 1/256); kept values are scaled
+ * by 1 / (1 - p_q), so the expectation is exact for the rate actually applied.  Regenerated identically in backward. */
 typedef struct sm_dropout {
   float p;        /* 0 disables */
   uint64_t seed;  /* per step */

@@ -122,16 +122,34 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 
 struct DropCfg {
   uint32_t key;       // fmix32(seed_lo + site * golden) ^ seed_hi
-  uint32_t thresh16;  // 0 => dropout disabled
-  float scale;        // 1 / (1 - p_effective)
+  uint32_t thresh16;  // 0 => dropout disabled; otherwise the 8-bit threshold << 8
+  float scale;        // 1 / (1 - p_effective), p_effective = p rounded to 1/256
 };
 
+// ONE hash per aligned group of 4 consecutive elements (of the flat [rows, N] index): element e owns byte (e & 3) and is
+// kept when that byte >= the 8-bit threshold.  First round a full 32-bit multiply (the group index exceeds 24 bits for
+// large T x N), second round a full-rate 24-bit one.  The murmur finaliser per element this replaces was 22 issue slots
+// per element -- in the GEMM epilogues that apply the hidden dropout more than the rest of the epilogue together.
+__device__ __forceinline__ uint32_t drop_hash4(const DropCfg& d, uint32_t group) {
+  uint32_t a = (group ^ d.key) * 0x9E3779B1u;
+  a ^= a >> 15;
+  uint32_t b = __umul24(a, 0xD6E8FFu);
+  b ^= b >> 13;
+  return b;
+}
 __device__ __forceinline__ bool drop_keep1(const DropCfg& d, uint64_t elem) {
-  // one murmur3 finaliser (full avalanche; v_mul_lo_u32 is quarter rate, so two multiplies, not four); the
-  // high word of the element index is folded in rotated so that it cannot cancel against the low word
-  const uint32_t hi = (uint32_t)(elem >> 32);
-  const uint32_t h = fmix32((uint32_t)elem ^ d.key ^ ((hi << 16) | (hi >> 16)));
-  return (h & 0xFFFFu) >= d.thresh16;
+  const uint32_t h = drop_hash4(d, (uint32_t)(elem >> 2));
+  return ((h >> (8u * ((uint32_t)elem & 3u))) & 0xFFu) >= (d.thresh16 >> 8);
+}
+// v[0..8) = dropout(v) for the 8 consecutive elements starting at e0 (a multiple of 4)
+__device__ __forceinline__ void drop_apply8(const DropCfg& d, uint64_t e0, float (&v)[8]) {
+  const uint32_t g0 = (uint32_t)(e0 >> 2), th8 = d.thresh16 >> 8;
+  const uint32_t h0 = drop_hash4(d, g0), h1 = drop_hash4(d, g0 + 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = ((h0 >> (8 * k)) & 0xFFu) >= th8 ? v[k] * d.scale : 0.f;
+    v[4 + k] = ((h1 >> (8 * k)) & 0xFFu) >= th8 ? v[4 + k] * d.scale : 0.f;
+  }
 }
 
 static inline uint32_t sm_fmix32_host(uint32_t h) {
@@ -144,9 +162,10 @@ static inline DropCfg make_drop(const sm_dropout* s) {
   d.key = 0; d.thresh16 = 0; d.scale = 1.f;
   if (s == nullptr || s->p <= 0.f) return d;
   d.key = sm_fmix32_host((uint32_t)s->seed + s->site * 0x9E3779B9u) ^ (uint32_t)(s->seed >> 32);
-  uint32_t t = (uint32_t)(s->p * 65536.0f + 0.5f);
-  if (t > 65535u) t = 65535u;
-  d.thresh16 = t;
-  d.scale = 1.0f / (1.0f - (float)t / 65536.0f);
+  uint32_t t = (uint32_t)(s->p * 256.0f + 0.5f);  // p quantised to 1/256 (the keep test compares one byte of a hash)
+  if (t < 1u) t = 1u;
+  if (t > 255u) t = 255u;
+  d.thresh16 = t << 8;
+  d.scale = 256.0f / (256.0f - (float)t);
   return d;
 }

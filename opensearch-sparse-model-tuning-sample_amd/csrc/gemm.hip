@@ -346,8 +346,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
         }
         if (e.drop.thresh16) {
           const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
+          if (full && (N & 3) == 0) {
+            drop_apply8(e.drop, eb, v);
+          } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = drop_keep1(e.drop, eb + k) ? v[k] * e.drop.scale : 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = drop_keep1(e.drop, eb + k) ? v[k] * e.drop.scale : 0.f;
+          }
         }
         if (residual) {
           float rv[8];
@@ -1142,10 +1146,13 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
       }
       if constexpr (LMODE == 1) {
         const uint64_t eb = (uint64_t)row * (uint64_t)N + (sl + 16 * u) * 8;
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (float)(bf16)((float)raw[u][q] + rv[q]);  // the gradient the un-fused path stores before its dropout pass
+        drop_apply8(ln.dy_drop, eb, t);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float t = (float)(bf16)((float)raw[u][q] + rv[q]);  // the gradient the un-fused path stores before its dropout pass
-          raw[u][q] = (bf16)(drop_keep1(ln.dy_drop, eb + q) ? t * ln.dy_drop.scale : 0.f);
+          raw[u][q] = (bf16)t[q];
           rv[q] = 0.f;
         }
       }
@@ -1180,9 +1187,7 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
         store8<bf16>(C + off, gx, true, 8);
         if (ln.dx_drop) {
           if (ln.drop.thresh16) {
-            const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) gx[q] = drop_keep1(ln.drop, eb + q) ? gx[q] * ln.drop.scale : 0.f;
+            drop_apply8(ln.drop, (uint64_t)row * (uint64_t)N + col, gx);
           }
           store8<bf16>(ln.dx_drop + off, gx, true, 8);
         }
@@ -1344,9 +1349,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
           for (int q = 0; q < 8; ++q) v[q] = gelu_t<bf16>(v[q]);
         }
         if (e.drop.thresh16) {
-          const uint64_t eb = (uint64_t)row * (uint64_t)N + col;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = drop_keep1(e.drop, eb + q) ? v[q] * e.drop.scale : 0.f;
+          drop_apply8(e.drop, (uint64_t)row * (uint64_t)N + col, v);
         }
         if (residual) {
           float rv[8];

@@ -128,9 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         st8<T>(dx + (size_t)row * H + c0, gx);
         if (dx_drop) {
           if (drop.thresh16) {
-            const uint64_t eb = (uint64_t)row * (uint64_t)H + c0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gx[k] = drop_keep1(drop, eb + k) ? gx[k] * drop.scale : 0.f;
+            drop_apply8(drop, (uint64_t)row * (uint64_t)H + c0, gx);
           }
           st8<T>(dx_drop + (size_t)row * H + c0, gx);
         }
@@ -199,10 +197,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         ld8<float>(beta + c0, be);
         const uint64_t eb = (uint64_t)row * (uint64_t)H + c0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
-          if (drop.thresh16) o[k] = drop_keep1(drop, eb + k) ? o[k] * drop.scale : 0.f;
-        }
+        for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
+        if (drop.thresh16) drop_apply8(drop, eb, o);
         st8<T>(z + (size_t)row * H + c0, v[i]);
         st8<T>(y + (size_t)row * H + c0, o);
         if (y32) st8<float>(y32 + (size_t)row * H + c0, o);

@@ -61,7 +61,7 @@ def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTI
         bound = ELEMENTWISE_BF16 if elementwise is None else elementwise
         assert worst <= bound, f"{what}: d_rep worst element {worst:.3e} > {bound} (1+|ref|)"
         assert inside >= fraction_inside, f"{what}: only {inside:.5f} of d_rep inside 1e-2 (1+|ref|)"
-        assert abs(float(loss) - float(oloss)) <= 1e-2 * (1 + abs(float(oloss))), (float(loss), float(oloss))
+        assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
     if oq is not None:
         assert torch.equal(out["q_rep"].detach().cpu(), oq.detach()), "inference-free query encoding must be bit-exact"
 
