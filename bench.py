@@ -375,7 +375,7 @@ def main():
         head_ms = kt.mean_ms()
         rows = list(kt.rows)
     elapsed_other = float("nan") if args.only_value_layout else timed(other)  # the other layout, outside the headline region
-    gemm_lines = None
+    gemm_lines = gemm_lines_serial = None
     if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
         with GemmRoofline(ops) as gr:
             bs_ = batches[args.layout]
@@ -383,6 +383,20 @@ def main():
                 trainer.training_step(bs_[i % len(bs_)])
             torch.cuda.synchronize()
         gemm_lines = gr.summary(3, MFMA_PEAK[args.dtype])
+        # the same three steps with the weight-gradient launches on the main queue: every GEMM alone on the chip.  In the
+        # overlapped step a GEMM's time includes what its neighbour on the other queue takes from it.
+        wg = getattr(trainer.model.sparse_model.backbone, "_wgrad", None)
+        gemm_lines_serial = None
+        if wg is not None and wg.enabled:
+            wg.enabled = False
+            try:
+                with GemmRoofline(ops) as gr2:
+                    for i in range(3):
+                        trainer.training_step(bs_[i % len(bs_)])
+                    torch.cuda.synchronize()
+                gemm_lines_serial = gr2.summary(3, MFMA_PEAK[args.dtype])
+            finally:
+                wg.enabled = True
     barrier()
 
     k = args.negs + 1
@@ -429,6 +443,13 @@ def main():
         ms = sum(g["ms_per_step"] for g in gemm_lines)
         result["roofline_encoder_gemms_aggregate"] = {"gflop_per_step": fl, "ms_per_step": ms, "achieved_tflops": fl / ms,
                                                       "frac": fl / ms * 1e12 / peak}
+        if gemm_lines_serial:
+            fl2 = sum(g["gflop_per_step"] for g in gemm_lines_serial)
+            ms2 = sum(g["ms_per_step"] for g in gemm_lines_serial)
+            result["roofline_encoder_gemms_one_queue"] = {
+                "how": "same ops, weight-gradient launches on the main queue (no kernel shares the chip with another)",
+                "per_op_tflops": {g["op"]: g["achieved_tflops"] for g in gemm_lines_serial},
+                "gflop_per_step": fl2, "ms_per_step": ms2, "achieved_tflops": fl2 / ms2, "frac": fl2 / ms2 * 1e12 / peak}
     if rank == 0:
         if world == 1:
             pm = measured_peaks(device)
