@@ -323,6 +323,75 @@ def test_rep_level_gradient_caching_matches_the_single_pass(layout):
     assert abs(ld - lnd) > 1e-4
 
 
+def test_train_loop_prefetcher_checkpoint_and_resume(tmp_path):
+    """SparseModelTrainer.train() -- DataLoader + collator + host packing + H2D on the prefetch thread's
+    stream -- must produce exactly the weights of the same batches fed by hand in the sampler's order; a checkpoint
+    written mid-run (HF weights + trainer_state.pt: AdamW moments, step) resumes into the same final weights."""
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    ds = SyntheticTriplesDataset(20, 3, 32, 16, 520, seed=21, len_mean=20, len_std=8)
+
+    def make(out, max_steps, save_steps=0):
+        margs = ModelArguments(model_name_or_path="unused", inf_free=True)
+        dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=4)
+        targs = TrainingArguments(output_dir=str(out), per_device_train_batch_size=4, logging_steps=1000, learning_rate=1e-3, weight_decay=0.01,
+                                  warmup_steps=2, max_steps=max_steps, save_strategy="steps" if save_steps else "no", save_steps=save_steps,
+                                  dataloader_drop_last=True, seed=3)
+        model = tiny_sparse_model(torch.float32)
+        bb = model.backbone
+        bb.config.hidden_dropout_prob = bb.config.attention_probs_dropout_prob = 0.1  # the seeded masks must line up as well
+        losses = [LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1, temperature=1.0)]
+        return SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs, loss_functions=losses, train_dataset=ds,
+                                  data_collator=PreTokenizedCollator())
+
+    steps = 7  # 5 batches per epoch: crosses an epoch boundary
+    probe = PreTokenizedCollator()([ds[i] for i in range(4)])["docs"][0]
+
+    def outputs(tr):  # what the trained weights encode (weight-gradient atomics make single weights differ in the last bits,
+        m = tr.model.sparse_model  # and AdamW turns the pure-rounding-noise gradient of the key biases into +-lr steps)
+        m.eval()
+        with torch.no_grad():
+            return m(inf_free=False, input_ids=probe["input_ids"].cuda(), attention_mask=probe["attention_mask"].cuda()).clone()
+
+    a = make(tmp_path / "a", steps, save_steps=4)
+    w0 = a.model.sparse_model.backbone.flat_param.clone()
+    last = a.train()
+    assert a.state.global_step == steps and torch.isfinite(last)
+    assert float((a.model.sparse_model.backbone.flat_param - w0).abs().max()) > 1e-4
+    ra = outputs(a)
+    # (1) the same batches by hand, without the prefetch thread
+    b = make(tmp_path / "b", steps)
+    dl = b.get_train_dataloader()
+    it = iter(dl)
+    for _ in range(steps):
+        try:
+            batch = next(it)
+        except StopIteration:
+            it = iter(dl)
+            batch = next(it)
+        lb = b.training_step(b._prepare_inputs(batch))
+    assert abs(float(lb) - float(last)) <= 1e-4 * (1 + abs(float(last))), (float(lb), float(last))
+    close_out(outputs(b), ra, 1e-3, "train() vs the same batches by hand")
+    # (2) resume from the step-4 checkpoint of run a: HF-layout weights + trainer_state.pt (AdamW moments, step)
+    from safetensors.torch import load_file
+    ck = tmp_path / "a" / "checkpoint-4"
+    assert (ck / "trainer_state.pt").exists() and (ck / "config.json").exists()
+    c = make(tmp_path / "c", steps)
+    c.model.sparse_model.backbone.load_hf_state_dict(load_file(str(ck / "model.safetensors")))
+    c.load_trainer_state(str(ck))
+    assert c.state.global_step == 4
+    dl = c.get_train_dataloader()
+    batches = list(iter(dl))
+    for i in range(4, steps):  # step 4 = last batch of epoch 0, then epoch 1: the sampler's generator continues as in run a
+        if i == 5:
+            batches = list(iter(dl))
+        lc = c.training_step(c._prepare_inputs(batches[i % 5]))
+    assert abs(float(lc) - float(last)) <= 1e-4 * (1 + abs(float(last))), (float(lc), float(last))
+    close_out(outputs(c), ra, 1e-3, "resumed run")
+
+
 def test_training_mode_dropout_is_seeded_and_finite():
     from scripts.model.sparse_encoders import SparseModel
     from sparse_hip.encoder import HipBertMLM
