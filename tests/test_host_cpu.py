@@ -30,6 +30,27 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
 
 
+def test_entry_points_reject_bad_arguments_with_a_message_before_touching_the_gpu():
+    """argument validation runs first and reports through the return code + sm_last_error (no device needed, nothing launched)"""
+    from sparse_hip import lib as L
+    lib = L.load()
+    cases = [
+        ("sm_loss_combine", (None, None, 5, None, 0.0, None, 0.0, None, None, None, 0.01, None), "at most 4"),
+        ("sm_attention_fwd", (1, None, None, None, None, 2, 64, 4, 48, None, None, None), "head dim 48"),
+        ("sm_attention_bwd", (1, None, None, None, None, None, None, 2, 100, 4, 32, None, None, None), "S=100"),
+        ("sm_flops_fwd", (None, 0, 1, 10, -1, None, None, None, None), "rows=0"),
+        ("sm_sparse_head_bwd", (1, None, None, None, None, None, None, None, None, 0, 128, 384, 30522, 0, None, None), "empty problem"),
+        ("sm_layernorm_fwd", (1, None, None, None, None, None, None, 16, 100, 1e-12, None), "multiple of 64"),
+        ("sm_adamw", (None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None), "n=0"),
+    ]
+    for name, args, needle in cases:
+        rc = getattr(lib, name)(*args)
+        msg = lib.sm_last_error().decode()
+        assert rc < 0 and name.split("_fwd")[0].split("_bwd")[0] in msg and needle in msg, (name, rc, msg)
+    with pytest.raises(L.SparseHipError, match="no CPU fallback"):
+        L.ptr(torch.zeros(4))
+
+
 def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():
     from sparse_hip import functional as F
     from sparse_hip.lib import SparseHipError
