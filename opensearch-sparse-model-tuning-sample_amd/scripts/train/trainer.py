@@ -429,15 +429,20 @@ class SparseModelTrainer:
             sm.idf_vector.grad.zero_()
 
     def training_step(self, inputs) -> torch.Tensor:
-        """One optimisation step (hf trainer.py:1892-1963 + 1780-1797). Returns the detached loss."""
+        """One optimisation step (hf trainer.py:1892-1963 + 1780-1797). Returns the detached loss.
+        SM_TRACE_RANGES=1 brackets the phases with roctx ranges (rocprofv3 --marker-trace)."""
         self.model.train()
         bb = self.model.sparse_model.backbone
         bb.set_dropout_seed(self.args.seed * 1000003 + self.state.global_step * 64 + self.accelerator.process_index)
-        loss = self.compute_loss(self.model, inputs)
-        loss.backward()
-        self._finish_grad_reduce()
-        self._optimizer_step()
-        self.zero_grad()
+        with _trace_range("forward+loss"):
+            loss = self.compute_loss(self.model, inputs)
+        with _trace_range("backward"):
+            loss.backward()
+        with _trace_range("grad_reduce"):
+            self._finish_grad_reduce()
+        with _trace_range("optimizer"):
+            self._optimizer_step()
+            self.zero_grad()
         self.state.global_step += 1
         return loss.detach()
 
@@ -472,6 +477,24 @@ class SparseModelTrainer:
         if feed is not None:
             feed.close()
         return loss
+
+
+_TRACE_RANGES = os.environ.get("SM_TRACE_RANGES", "0") == "1"
+
+
+class _trace_range:
+    """roctx range around a phase of the step (torch.cuda.nvtx is roctx on ROCm); a no-op unless SM_TRACE_RANGES=1"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TRACE_RANGES:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if _TRACE_RANGES:
+            torch.cuda.nvtx.range_pop()
 
 
 # ---------------------------------------------------------------------------------------
