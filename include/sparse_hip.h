@@ -126,6 +126,11 @@ int sm_embed_fwd(int dtype, const int64_t* ids, const void* word /*dtype [*,H]*/
 /* dz[T,H] -> gword[ids] += , gpos[s] += , gtype0 += (fp32 atomics) */
 int sm_embed_bwd(int dtype, const void* dz, const int64_t* ids, float* gword, float* gpos, float* gtype0,
                  int B, int S, int H, const sm_ragged* rag, void* stream);
+/* The same from HOST-SORTED rows (bf16): order_id[n] = the batch's valid rows sorted by token id, ids_sorted[n] their ids;
+ * order_pos[n] / pos_sorted[n] the same rows sorted by position.  Runs of equal keys are summed in registers and added to
+ * the table row once; rows that are not listed (padding) contribute nothing. */
+int sm_embed_bwd_sorted(int dtype, const void* dz, const int32_t* order_id, const int32_t* ids_sorted, const int32_t* order_pos,
+                        const int32_t* pos_sorted, int n, float* gword, float* gpos, float* gtype0, int H, void* stream);
 /* elementwise y = dropout_bwd(dy) (used for the embedding dropout backward) */
 int sm_dropout_bwd(int dtype, const void* dy, void* dx, long n, const sm_dropout* drop, void* stream);
 

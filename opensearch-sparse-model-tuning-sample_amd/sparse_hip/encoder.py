@@ -70,6 +70,11 @@ def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_
     # dtype conversions in numpy: a torch CPU op fans out to every visible core (slow on a CPU-quota'd host)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)
     rag = ops.Ragged(t(doc_off, np.int32), t(row_doc[::16], np.int32), t(pos, np.int32), rows, B, smax)
+    # the valid rows sorted by token id and by position: the embedding backward sums runs of equal keys in registers and
+    # touches a table row once per run (ops.embed_bwd; [CLS] / [SEP] and every position occur in every document)
+    vrows = np.flatnonzero(valid)
+    by_id, by_pos = np.argsort(pids[vrows], kind="stable"), np.argsort(pos[vrows], kind="stable")
+    rag.emb_sorted = (t(vrows[by_id], np.int32), t(pids[vrows][by_id], np.int32), t(vrows[by_pos], np.int32), t(pos[vrows][by_pos], np.int32))
     return PackedDocs(t(pids, np.int64), t(valid, np.uint8), rag)
 
 

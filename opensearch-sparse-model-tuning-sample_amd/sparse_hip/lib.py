@@ -63,6 +63,7 @@ SIGNATURES = {
     "sm_embed_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
     "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
     "sm_embed_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _rag, _p],
+    "sm_embed_bwd_sorted": [_i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p],
     "sm_dropout_bwd": [_i, _p, _p, _l, C.POINTER(SmDropout), _p],
     "sm_gelu_bwd": [_i, _p, _p, _p, _l, _p],
     "sm_attention_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(SmDropout), _rag, _p],

@@ -153,6 +153,13 @@ def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tens
     else:
         B, S = rag.rows, 1
     H = dz.shape[1]
+    srt = getattr(rag, "emb_sorted", None) if rag is not None else None
+    if srt is not None and dz.dtype == torch.bfloat16 and H % 128 == 0:
+        # rows sorted on the host by token id and by position (pack_documents): run sums instead of one atomic row per token row
+        order_id, ids_sorted, order_pos, pos_sorted = srt
+        L.call("sm_embed_bwd_sorted", L.dtype_code(dz.dtype), L.ptr(dz), L.ptr(order_id), L.ptr(ids_sorted), L.ptr(order_pos),
+               L.ptr(pos_sorted), order_id.numel(), L.ptr(gword), L.ptr(gpos), L.ptr(gtype0), H, L.stream_ptr())
+        return
     L.call("sm_embed_bwd", L.dtype_code(dz.dtype), L.ptr(dz), L.ptr(ids), L.ptr(gword), L.ptr(gpos), L.ptr(gtype0),
            B, S, H, _rag_ref(rag), L.stream_ptr())
 

@@ -273,6 +273,42 @@ def test_embed_fwd_bwd(ops, dtype):
     close(gt, dz.sum(0), 1e-4, "type grad")
 
 
+def test_embed_bwd_from_host_sorted_rows_matches_the_scatter(ops):
+    """packed layout, bf16: run sums over the rows sorted by token id / by position (pack_documents -> rag.emb_sorted; [CLS] /
+    [SEP] in every document, a token repeated 100 times) against index_add in fp32 and against the atomic scatter kernel"""
+    from sparse_hip.encoder import pack_documents
+    dtype = torch.bfloat16
+    B, S, H, V = 150, 64, 128, 500
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(3, S + 1, (B,), generator=g)
+    ids = torch.randint(10, V, (B, S), generator=g)
+    ids[:, 0] = 101
+    ids[torch.arange(B), lens - 1] = 102
+    ids[:100, 1] = 7
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    pk = pack_documents(ids, mask, "cuda")
+    assert pk is not None and pk.rag.emb_sorted is not None
+    rows = pk.rag.rows
+    dz = q(rnd(rows, H, seed=6), dtype) * pk.mask.cpu()[:, None].float()  # padding rows carry a zero gradient
+    out = {}
+    for name in ("sorted", "scatter"):
+        gw, gp, gt = torch.ones(V, H, device="cuda"), torch.ones(S, H, device="cuda"), torch.ones(H, device="cuda")  # accumulate semantics
+        srt = pk.rag.emb_sorted
+        if name == "scatter":
+            pk.rag.emb_sorted = None
+        ops.embed_bwd(dev(dz, dtype), pk.ids, gw, gp, gt, pk.rag)
+        pk.rag.emb_sorted = srt
+        out[name] = (gw.cpu() - 1, gp.cpu() - 1, gt.cpu() - 1)
+    pid, ppos = pk.ids.cpu(), pk.rag.pos_ids.cpu().long()
+    rw = torch.zeros(V, H).index_add_(0, pid, dz)
+    rp = torch.zeros(S, H).index_add_(0, ppos, dz)
+    for name, (gw, gp, gt) in out.items():
+        close(gw, rw, 1e-4, name + " word grad")
+        close(gp, rp, 1e-4, name + " pos grad")
+        close(gt, dz.sum(0), 1e-4, name + " type grad")
+
+
 # ------------------------------------------------------------------ attention
 def ref_attention(qkv, mask, B, S, A, dh):
     H = A * dh
