@@ -20,6 +20,7 @@ s=$(find $out/pmc_sq -name 's_counter_collection.csv' | head -1)
 python3 tools/pmc_summary.py $f $w $out/pmc_traffic.json $git > $out/pmc_traffic.txt 2>&1
 python3 tools/sq_summary.py $s $git > $out/pmc_mfma_util.txt 2>&1
 cp $(find $out/stats -name 's_kernel_stats.csv' | head -1) $out/kernel_stats.csv
+python3 tools/step_timeline.py $(find $out/stats -name 's_kernel_trace.csv' | head -1) > $out/step_timeline.txt 2>&1
 # the raw per-dispatch CSVs are large: keep the summaries only
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/stats
 head -12 $out/kernel_stats.csv; cat $out/pmc_traffic.txt | head -8; head -8 $out/pmc_mfma_util.txt; cat $out/bench_n1.json
