@@ -319,6 +319,9 @@ def latest_traffic(kernel_names):
 
 def main():
     args = parse()
+    if os.environ.get("SM_FAULTHANDLER_S"):  # tests: a stalled rank prints every thread's stack and exits instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SM_FAULTHANDLER_S"]), exit=True)
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_child(args)), flush=True)
         return

@@ -12,6 +12,22 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline", "value_layout", "value_dense_layout", "value_ragged_layout"}
 
 
+def _run(cmd, env=None, timeout=120):
+    """own process group, killed as a whole on expiry: rank processes left behind would hold the GPU for every later test"""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        pytest.fail(f"timed out after {timeout}s: {' '.join(cmd[-8:])}\n{(out + err)[-6000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 def _line(out):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-3000:]
@@ -33,8 +49,7 @@ def test_cli_defaults_follow_the_measurement_protocol():
 
 @pytest.mark.gpu
 def test_bench_one_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=120)
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     assert REQUIRED <= set(j), REQUIRED - set(j)
@@ -53,10 +68,10 @@ def test_bench_one_gpu_line():
 def test_bench_two_ranks_on_one_gpu_over_gloo():
     """the N > 1 launch contract (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, barrier + max over ranks, one line
     from rank 0); RCCL needs one GPU per rank, so on the single test GPU the transport is gloo (SM_BENCH_BACKEND)"""
-    env = dict(os.environ, SM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1"], capture_output=True, text=True, timeout=120, env=env)
+    env = dict(os.environ, SM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_FAULTHANDLER_S="90")
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+              "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+              "--warmup", "1"], env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"

@@ -168,13 +168,21 @@ SUBPROCESS_TIMEOUT = 120  # seconds per leg: a stalled leg must not eat the suit
 
 
 def _run(cmd, env):
-    """subprocess with a hard limit; on expiry the captured output (incl. the faulthandler stack dump the worker
-    arms at 90 s) becomes the failure message"""
+    """subprocess with a hard limit, in its own process group: on expiry the WHOLE group is killed (torch.distributed.run's
+    rank processes would otherwise stay behind, holding the GPU, and every later test would time out as well) and the
+    captured output (incl. the faulthandler stack dump the worker arms at 90 s) becomes the failure message"""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        return subprocess.run(cmd, capture_output=True, text=True, timeout=SUBPROCESS_TIMEOUT, env=env)
-    except subprocess.TimeoutExpired as e:
-        out = (e.stdout or b"").decode(errors="replace") + (e.stderr or b"").decode(errors="replace")
-        pytest.fail(f"timed out after {SUBPROCESS_TIMEOUT}s: {' '.join(cmd[-6:])}\n{out[-6000:]}")
+        out, err = p.communicate(timeout=SUBPROCESS_TIMEOUT)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        pytest.fail(f"timed out after {SUBPROCESS_TIMEOUT}s: {' '.join(cmd[-6:])}\n{(out + err)[-6000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
 def _two_rank_case(tmp_path, case, backend, ports):
