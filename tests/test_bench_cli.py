@@ -12,7 +12,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline", "value_layout", "value_dense_layout", "value_ragged_layout"}
 
 
-def _run(cmd, env=None, timeout=120):
+def _run(cmd, env=None, timeout=240):
     """own process group, killed as a whole on expiry: rank processes left behind would hold the GPU for every later test"""
     import signal
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
