@@ -270,6 +270,10 @@ int sm_scale_by(float* x, const float* s, float c, long n, void* stream);
  * streaming copy (reads `bytes`, writes `bytes`). */
 int sm_peak_mfma_bf16(float* sink, int blocks, int iters, void* stream);
 int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream);
+/* LDS-DMA throughput of the CUs: `blocks` workgroups of `waves` waves, every wave streams `iters` 1-KiB pieces
+ * (global_load_lds, 16 bytes per lane, `depth` in flight per wave) from its workgroup's window of `span_per_block` bytes
+ * into LDS.  Bytes moved = blocks * waves * iters * 1024.  waves in {1,2,4,8,16}, depth in {8,16,32}. */
+int sm_peak_lds_dma(const void* src, size_t span_per_block, int blocks, int waves, int depth, int iters, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,51 @@ __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict_
   }
 }
 
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA (global_load_lds, 16 bytes per lane = 1 KiB per wave instruction) throughput of a CU: every wave of the workgroup
+// streams `iters` pieces from its own window of `src` into a private 8 KiB LDS ring with at most DEPTH loads in flight.  The
+// window of a workgroup is `span` bytes (a few MB in total: L2-resident; hundreds of MB: from HBM).  One workgroup per CU.
+template <int WAVES, int DEPTH>
+__global__ __launch_bounds__(WAVES * 64) void peak_lds_dma_kernel(const char* __restrict__ src, size_t span, int iters, float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) char ring[WAVES * 8192];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const char* base = src + (size_t)blockIdx.x * span;
+  const uint32_t mask = (uint32_t)(span / 1024) - 1;  // span is a power of two: no division in the issue loop
+  char* dst = ring + w * 8192;
+  const char* lbase = base + lane * 16;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t piece = ((uint32_t)it * WAVES + w) & mask;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(lbase + (size_t)piece * 1024), (lds_void_t*)(dst + (it & 7) * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");  // (the 8 ring slots are reused: the data is not consumed)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float v = reinterpret_cast<const float*>(ring)[threadIdx.x];
+  if (v == 123.456f) sink[threadIdx.x & 1023] = v;
+}
+
 }  // namespace
+
+// Bytes moved by the launch = blocks * waves * iters * 1024.  waves in {1, 2, 4, 8, 16}, depth (loads in flight per wave) in {8, 16, 32}.
+extern "C" int sm_peak_lds_dma(const void* src, size_t span_per_block, int blocks, int waves, int depth, int iters, float* sink, void* stream) {
+  SM_REQUIRE(src && sink && blocks > 0 && iters > 0 && span_per_block >= 1024 && (span_per_block & (span_per_block - 1)) == 0 && ((uintptr_t)src % 16) == 0,
+             "sm_peak_lds_dma: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+#define LDS_DMA_CASE(W, D)                                                                                                          \
+  if (waves == W && depth == D) {                                                                                                    \
+    hipLaunchKernelGGL((peak_lds_dma_kernel<W, D>), dim3(blocks), dim3(W * 64), 0, st, (const char*)src, span_per_block, iters, sink); \
+    SM_LAUNCH_CHECK();                                                                                                               \
+    return SM_OK;                                                                                                                    \
+  }
+  LDS_DMA_CASE(1, 8) LDS_DMA_CASE(1, 16) LDS_DMA_CASE(1, 32) LDS_DMA_CASE(2, 8) LDS_DMA_CASE(2, 16) LDS_DMA_CASE(2, 32)
+  LDS_DMA_CASE(4, 8) LDS_DMA_CASE(4, 16) LDS_DMA_CASE(4, 32) LDS_DMA_CASE(8, 8) LDS_DMA_CASE(8, 16) LDS_DMA_CASE(8, 32)
+  LDS_DMA_CASE(16, 8) LDS_DMA_CASE(16, 16)
+#undef LDS_DMA_CASE
+  SM_REQUIRE(false, "sm_peak_lds_dma: waves=%d depth=%d unsupported", waves, depth);
+  return SM_OK;
+}
 
 // One launch of `blocks` x 4 waves, each issuing iters x 16 independent v_mfma_f32_16x16x32_bf16 (16384 FLOP each).
 // FLOPs of the launch = blocks * 4 * iters * 16 * 16384.

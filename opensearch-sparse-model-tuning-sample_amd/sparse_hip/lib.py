@@ -94,6 +94,7 @@ SIGNATURES = {
     "sm_scale_by": [_p, _p, _f, _l, _p],
     "sm_peak_mfma_bf16": [_p, _i, _i, _p],
     "sm_peak_copy": [_p, _p, C.c_size_t, _p],
+    "sm_peak_lds_dma": [_p, C.c_size_t, _i, _i, _i, _i, _p, _p],
 }
 
 _lib = None
