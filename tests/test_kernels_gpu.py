@@ -309,6 +309,20 @@ def test_embed_bwd_from_host_sorted_rows_matches_the_scatter(ops):
         close(gt, dz.sum(0), 1e-4, name + " type grad")
 
 
+def test_loss_combine_scalar_tail(ops):
+    """ranking = sum w_i l_i; total = ranking + lambda_d flops_d + lambda_q flops_q; moving average updated in place (trainer.py:101-141)"""
+    l = [torch.tensor([v], device="cuda") for v in (1.25, 0.5, 3.0)]
+    fd, fq = torch.tensor([2.0], device="cuda"), torch.tensor([0.75], device="cuda")
+    ma = torch.tensor([10.0], device="cuda")
+    ranking, total = ops.loss_combine([(l[0], 1.0), (l[1], 0.5), (l[2], 2.0)], fd, 0.1, fq, 0.01, ma, 0.01)
+    assert abs(float(ranking) - 7.5) < 1e-6 and abs(float(total) - (7.5 + 0.2 + 0.0075)) < 1e-6
+    assert abs(float(ma) - (0.01 * 7.5 + 0.99 * 10.0)) < 1e-5
+    ranking, total = ops.loss_combine([(l[0], 1.0)], fd, 0.5, None, 0.0)
+    assert abs(float(ranking) - 1.25) < 1e-6 and abs(float(total) - 2.25) < 1e-6
+    with pytest.raises(Exception, match="at most 4"):
+        ops.loss_combine([(l[0], 1.0)] * 5, fd, 0.5, None, 0.0)
+
+
 # ------------------------------------------------------------------ attention
 def ref_attention(qkv, mask, B, S, A, dh):
     H = A * dh
