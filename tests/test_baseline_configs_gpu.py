@@ -80,7 +80,7 @@ def _check_grads(dtype, bb, pr, what):
 
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
-                  residual_fp32=None, elementwise=None):
+                  residual_fp32=None, elementwise=None, grad_cache_chunk=0):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
@@ -112,7 +112,8 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     ibn = recipe["use_in_batch_negatives"]
     margs = ModelArguments(model_name_or_path="x", inf_free=True, use_l0=use_l0)
     dargs = DataTrainingArguments(loss_types=lts, use_in_batch_negatives=ibn, flops_d_lambda=recipe["flops_d_lambda"],
-                                  flops_d_T=recipe["flops_d_T"], flops_threshold=recipe.get("flops_threshold"))
+                                  flops_d_T=recipe["flops_d_T"], flops_threshold=recipe.get("flops_threshold"),
+                                  grad_cache_chunk=grad_cache_chunk)
     targs = TrainingArguments(output_dir="/tmp/sm_test_out", logging_steps=100000)
     losses = [LOSS_CLS_MAP[t](use_in_batch_negatives=ibn, weight=1, temperature=1.0) for t in lts]
     trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs, loss_functions=losses)
@@ -125,7 +126,12 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     loss, out = trainer.compute_loss(trainer.model, inp, return_outputs=True)
     loss.backward()
     torch.cuda.synchronize()
-    route = bb._argmax_log[0].cpu().long() & 0xFFFF
+    if grad_cache_chunk:  # the first pass logs one entry per chunk (the second pass repeats them bit for bit)
+        nchunks = -(-nq * k // grad_cache_chunk)
+        assert len(bb._argmax_log) == 2 * nchunks, len(bb._argmax_log)
+        route = torch.cat([a.cpu().long() & 0xFFFF for a in bb._argmax_log[:nchunks]])
+    else:
+        route = bb._argmax_log[0].cpu().long() & 0xFFFF
     bb._argmax_log = None
     pr = _round_like_staged(p, dtype)
     lc = O.LossConfig(loss_types=tuple(lts), use_in_batch_negatives=ibn, flops_d_lambda=recipe["flops_d_lambda"],
@@ -182,6 +188,17 @@ def test_c2_slice_with_all_bf16_activation_storage():
 def test_c3_config_l0_recipe_on_the_c2_slice():
     """BASELINE.json configs[2] (single rank): use_l0 + flops_threshold=150 + lambda 0.08 on the c2 slice"""
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=L0, seed=3, what="c3 slice")
+
+
+def test_c5_kd_precomputed_scores_bert_base_seq512_gradient_caching():
+    """BASELINE.json configs[4] (bf16 operands: this build has no fp8 GEMMs): bert-base student, documents of up to 512 tokens,
+    KL distillation on precomputed teacher scores (per-query pairs), rep-level gradient caching in chunks of 4 documents --
+    1 query x 8 documents against the oracle (config_kd.yaml:9-16 with data_type kd; sparse_encoders.py:107-119)"""
+    KD = dict(loss_types=["kldiv"], use_in_batch_negatives=False, flops_d_lambda=0.002, flops_d_T=200)
+    g = torch.Generator().manual_seed(77)
+    scores = torch.rand(1, 8, generator=g) * 30
+    _student_step(BASE, torch.bfloat16, nq=1, k=8, S=512, Sq=32, recipe=KD, seed=5, teacher_scores=scores, what="c5 slice",
+                  grad_cache_chunk=4)
 
 
 def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
