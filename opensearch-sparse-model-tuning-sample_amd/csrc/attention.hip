@@ -415,13 +415,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       }
     }
     if (hh == 0) sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
-    sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] : 0.f;
+    sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] * 1.4426950408889634f : 0.f;  // log2 domain: exp(x - l) = exp2(x log2e - l log2e)
     sDelta0[hh * S + i] = d;
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-  const float scale = rsqrtf((float)DH);
+  const float scale = rsqrtf((float)DH), scale2 = scale * 1.4426950408889634f;
   T* dq_out0 = dqkv + (size_t)row0 * ld + h0 * DH;
 
   // ---- phase A: per query block, S^T orientation (rows = keys, col = query) -> dQ ----
@@ -461,10 +461,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         f32x4 dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = ((m4 >> (8 * r)) & 0xFF) ? __expf(s[r] * scale - lq) : 0.f;
+          const float pv = ((m4 >> (8 * r)) & 0xFF) ? __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -lq)) : 0.f;
           float dpv = dp[r];
           if constexpr (DROP) dpv = drop_keep_byte(hk[r >> 1], sh + 8 * (r & 1), d8.th8) ? dpv * d8.scale : 0.f;
-          dsv[r] = pv * (dpv - dl) * scale;
+          dsv[r] = pv * (dpv - dl);  // (the 1/sqrt(dh) factor of dS is applied to dQ / dK when they are stored)
         }
         ds[hh] = PT<T>::pack(dsv);
       }
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       for (int dt = 0; dt < DH / 16; ++dt) dq[dt] = SeqPair<T, L::SWZ>::acc(dq[dt], sX0, L::RS, cof, dt * 16, g, li, ds[0], ds[1], t2);
     }
 #pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, dq[dt]);
+    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dq_out + (size_t)q * ld + dt * 16 + 4 * g, dq[dt] * scale);
   }
   __syncthreads();  // every wave is done with the K,V images
   stage<T, HP * DH, L::SWZ>(base0, ld, Lr, nt * 16, sX0, L::RS, nullptr, 0);
@@ -521,11 +521,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         f32x4 pdv, dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = kvalid ? __expf(s[r] * scale - l4[r]) : 0.f;
+          const float pv = kvalid ? __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -l4[r])) : 0.f;
           float keepf = 1.f;
           if constexpr (DROP) keepf = drop_keep_byte(hq[r >> 1], 16u * (r & 1) + 8u * (li & 1), d8.th8) ? d8.scale : 0.f;
           pdv[r] = pv * keepf;
-          dsv[r] = pv * (dp[r] * keepf - d4[r]) * scale;
+          dsv[r] = pv * (dp[r] * keepf - d4[r]);
         }
         pd[hh] = PT<T>::pack(pdv);
         ds[hh] = PT<T>::pack(dsv);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) {
       store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, dv[dt]);
-      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt]);
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, dk[dt] * scale);
     }
   }
 }
