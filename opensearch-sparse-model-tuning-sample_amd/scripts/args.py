@@ -95,6 +95,9 @@ class TrainingArguments:
     dataloader_drop_last: bool = False
     dataloader_num_workers: int = 0
     log_level: str = "info"
+    # a checkpoint-N directory written by this trainer (HF-layout weights + trainer_state.pt): weights, AdamW moments and the
+    # step counter are restored (the reference never wires this, train_ir.py:143; a set key must not restart silently)
+    resume_from_checkpoint: Optional[str] = None
     # set by the launcher (train_ir.py) from the torchrun environment; what the dataset loaders shard by
     world_size: int = 1
     local_process_index: int = 0
@@ -104,15 +107,21 @@ class TrainingArguments:
     # to a non-default value must not pass silently (the reference recipes leave all of them at their defaults)
     _UNSUPPORTED = {"gradient_accumulation_steps": 1, "num_train_epochs": 3.0, "warmup_ratio": 0.0, "label_smoothing_factor": 0.0,
                     "optim": "adamw_torch", "gradient_checkpointing": False}
+    _ADAMW_EQUIVALENTS = ("adamw_torch", "adamw_torch_fused", "adamw_hf")
 
     def __post_init__(self):
         if self.lr_scheduler_type != "linear":
             raise ValueError(f"lr_scheduler_type={self.lr_scheduler_type!r}: only the linear warm-up / decay schedule of the "
                              "reference recipes (train_ir.py:103-107) is implemented")
         for key, default in self._UNSUPPORTED.items():
-            if key in self.extra and self.extra[key] not in (default, None) and not (key == "optim" and str(self.extra[key]).startswith("adamw")):
-                raise ValueError(f"TrainingArguments.{key}={self.extra[key]!r} is not supported by this step driver "
-                                 f"(only the default {default!r}): it would train with different semantics than asked for")
+            if key not in self.extra or self.extra[key] in (default, None):
+                continue
+            if key == "optim" and str(self.extra[key]) in self._ADAMW_EQUIVALENTS:
+                continue  # torch AdamW under another name: same update rule as the fused kernel
+            if key == "num_train_epochs" and self.max_steps > 0:
+                continue  # HF (so the reference) ignores the epoch count when max_steps is set
+            raise ValueError(f"TrainingArguments.{key}={self.extra[key]!r} is not supported by this step driver "
+                             f"(only the default {default!r}): it would train with different semantics than asked for")
 
     @property
     def compute_dtype(self):

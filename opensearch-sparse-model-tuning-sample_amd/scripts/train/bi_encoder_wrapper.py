@@ -60,15 +60,20 @@ class TeacherScoreCache:
 
     def __init__(self):
         self.row_of_key = {}
-        self.table = None
+        self.table = None   # [capacity, k] device buffer, grown geometrically; rows [0, self.rows) are in use
+        self.rows = 0
         self.hits = self.misses = 0
 
     @staticmethod
     def _row_hash(ids, mask, mul):
-        # wrap-around int64 polynomial hash of the real tokens of every row (padding does not count)
-        ids = ids.to(torch.int64) * mask.to(torch.int64)
+        # wrap-around int64 polynomial hash of the REAL tokens of every row: a masked position contributes nothing, so the
+        # key of a sample does not depend on the width its batch happened to be padded to (collators pad to the longest
+        # row of the batch); the row's true length is mixed in
+        m = mask.to(torch.int64).ne(0).to(torch.int64)
+        ids = ids.to(torch.int64)
         pos = torch.arange(1, ids.shape[1] + 1, device=ids.device, dtype=torch.int64)
-        return ((ids + 1) * (pos * mul + 0x2545F491)).sum(dim=1) * mul
+        body = ((ids + 1) * m * (pos * mul + 0x2545F491)).sum(dim=1)
+        return (body + m.sum(dim=1) * 0x9E3779B1) * mul
 
     def keys(self, q_features, d_features):
         hq = self._row_hash(q_features["input_ids"], q_features["attention_mask"], self._MUL_Q)
@@ -86,14 +91,24 @@ class TeacherScoreCache:
 
     def insert(self, keys, scores):
         scores = scores.detach()
-        new = [(i, k) for i, k in enumerate(keys) if k not in self.row_of_key]
+        new, seen = [], set()
+        for i, k in enumerate(keys):
+            if k not in self.row_of_key and k not in seen:
+                seen.add(k)
+                new.append((i, k))
         if not new:
             return
-        base = 0 if self.table is None else self.table.shape[0]
+        need = self.rows + len(new)
+        if self.table is None or need > self.table.shape[0]:  # geometric growth: O(N) copies in total
+            cap = max(1024, 2 * need)
+            grown = torch.empty((cap, scores.shape[1]), dtype=scores.dtype, device=scores.device)
+            if self.table is not None:
+                grown[:self.rows] = self.table[:self.rows]
+            self.table = grown
         for n, (_, k) in enumerate(new):
-            self.row_of_key[k] = base + n
-        fresh = scores[torch.tensor([i for i, _ in new], device=scores.device)]
-        self.table = fresh.clone() if self.table is None else torch.cat([self.table, fresh])
+            self.row_of_key[k] = self.rows + n
+        self.table[self.rows:need] = scores[torch.tensor([i for i, _ in new], device=scores.device)]
+        self.rows = need
 
 
 class BiEncoderWrapper:

@@ -252,9 +252,16 @@ class SparseModelTrainer:
         if self.accelerator.is_main_process:
             self.accelerator.unwrap_model(self.model).save(
                 output_dir, state_dict=state_dict, safe_serialization=getattr(self.args, "save_safetensors", True))
-            if self._adam is not None:  # what a resume needs besides the weights: AdamW moments and the step counter
-                torch.save({"global_step": self.state.global_step, **{k: v.detach().cpu() for k, v in self._adam.items()}},
-                           os.path.join(output_dir, "trainer_state.pt"))
+            # what a resume needs besides the weights: the step counter and the optimiser state (the fused AdamW's moments, or
+            # the caller-supplied optimiser's / scheduler's own state_dict)
+            st = {"global_step": self.state.global_step}
+            if self._adam is not None:
+                st.update({k: v.detach().cpu() for k, v in self._adam.items()})
+            if self.optimizer is not None:
+                st["optimizer"] = self.optimizer.state_dict()
+                if self.lr_scheduler is not None:
+                    st["lr_scheduler"] = self.lr_scheduler.state_dict()
+            torch.save(st, os.path.join(output_dir, "trainer_state.pt"))
 
     def set_bi_encoder_teacher(self, embedding_service=None):
         from .bi_encoder_wrapper import BiEncoderWrapper
@@ -383,6 +390,13 @@ class SparseModelTrainer:
         bb = sm.backbone
         a = self.args
         n = self.accelerator.num_processes
+        if a.max_grad_norm:  # hf trainer.py:1780-1782 clip_grad_norm_ on the averaged gradients, for the built-in AND a caller-supplied
+            # optimiser; no host sync: the factor stays on the device (the gradients hold the SUM over ranks here: norm / n)
+            grads = [bb.flat_grad] + ([sm.idf_vector.grad] if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None else [])
+            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads])) / n
+            coef = torch.clamp(float(a.max_grad_norm) / (norm + 1e-6), max=1.0).reshape(1)
+            for g in grads:
+                ops.scale_by(g.view(-1), coef)
         if self.optimizer is not None:  # caller-supplied torch optimiser (train_ir.py:85-107 style)
             if n > 1:  # SUM all-reduce -> the reference's DDP mean of (loss x N) gradients
                 bb.flat_grad.div_(n)
@@ -395,12 +409,6 @@ class SparseModelTrainer:
             return
         step = self.state.global_step  # scheduler has been stepped `step` times so far
         lr = linear_schedule_lr(step, a.learning_rate, a.warmup_steps, a.max_steps)
-        if a.max_grad_norm:  # hf trainer.py:1780-1782 clip_grad_norm_ on the averaged gradients; no host sync: the factor stays on the device
-            grads = [bb.flat_grad] + ([sm.idf_vector.grad] if sm.idf_vector.requires_grad and sm.idf_vector.grad is not None else [])
-            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads])) / n
-            coef = torch.clamp(float(a.max_grad_norm) / (norm + 1e-6), max=1.0).reshape(1)
-            for g in grads:
-                ops.scale_by(g.view(-1), coef)
         if self._adam is None:
             self._adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
             if sm.idf_vector.requires_grad:
@@ -420,7 +428,15 @@ class SparseModelTrainer:
         st = torch.load(os.path.join(checkpoint_dir, "trainer_state.pt"), map_location="cpu")
         self.state.global_step = int(st.pop("global_step"))
         dev = self.model.sparse_model.backbone.device
-        self._adam = {k: v.to(dev) for k, v in st.items()}
+        opt, sch = st.pop("optimizer", None), st.pop("lr_scheduler", None)
+        if opt is not None:
+            if self.optimizer is None:
+                raise ValueError("checkpoint holds a caller-supplied optimizer's state but this trainer has none")
+            self.optimizer.load_state_dict(opt)
+            if sch is not None and self.lr_scheduler is not None:
+                self.lr_scheduler.load_state_dict(sch)
+        if st:
+            self._adam = {k: v.to(dev) for k, v in st.items()}
 
     def zero_grad(self):
         sm = self.model.sparse_model

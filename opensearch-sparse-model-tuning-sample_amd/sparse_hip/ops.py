@@ -154,7 +154,7 @@ def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tens
         B, S = rag.rows, 1
     H = dz.shape[1]
     srt = getattr(rag, "emb_sorted", None) if rag is not None else None
-    if srt is not None and dz.dtype == torch.bfloat16 and H % 128 == 0:
+    if srt is not None and dz.dtype == torch.bfloat16 and H % 128 == 0 and H // 128 in (1, 2, 3, 4, 6, 8):  # the widths the kernel instantiates
         # rows sorted on the host by token id and by position (pack_documents): run sums instead of one atomic row per token row
         order_id, ids_sorted, order_pos, pos_sorted = srt
         L.call("sm_embed_bwd_sorted", L.dtype_code(dz.dtype), L.ptr(dz), L.ptr(order_id), L.ptr(ids_sorted), L.ptr(order_pos),

@@ -74,6 +74,21 @@ def test_yaml_configs_parse_into_the_three_argument_groups():
     assert targs.compute_dtype == torch.bfloat16  # fp16: true in the reference maps to bf16 here
 
 
+def test_training_arguments_reject_what_the_step_driver_does_not_implement():
+    """keys that would change the optimisation must not pass silently; keys HF itself ignores must not be rejected"""
+    from scripts.args import TrainingArguments
+    TrainingArguments(max_steps=10, extra={"num_train_epochs": 1})           # HF ignores epochs when max_steps > 0
+    TrainingArguments(max_steps=10, extra={"optim": "adamw_torch_fused"})    # torch AdamW under another name
+    with pytest.raises(ValueError, match="num_train_epochs"):
+        TrainingArguments(max_steps=0, extra={"num_train_epochs": 1})
+    for bad in ("adamw_8bit", "adamw_bnb_8bit", "adafactor", "sgd"):
+        with pytest.raises(ValueError, match="optim"):
+            TrainingArguments(max_steps=10, extra={"optim": bad})
+    with pytest.raises(ValueError, match="gradient_accumulation_steps"):
+        TrainingArguments(max_steps=10, extra={"gradient_accumulation_steps": 4})
+    assert TrainingArguments(resume_from_checkpoint="x/checkpoint-5").resume_from_checkpoint == "x/checkpoint-5"
+
+
 def test_lambda_and_lr_schedules_match_reference_known_answers():
     from scripts.train.trainer import SparseModelTrainer, linear_schedule_lr
 
@@ -113,7 +128,28 @@ def test_teacher_score_cache_keys_and_table():
     c.insert(keys[:3], scores[:3])
     assert c.lookup(keys) is None and torch.equal(c.lookup(keys[:3]), scores[:3])
     c.insert(keys, scores)
-    assert c.table.shape[0] == nq and torch.equal(c.lookup([keys[4], keys[0]]), scores[[4, 0]])
+    assert c.rows == nq and torch.equal(c.lookup([keys[4], keys[0]]), scores[[4, 0]])
+    # the same samples re-padded to other widths (collators pad to the longest row of the batch): same keys, no new table rows
+    def repad(f, width):
+        ids = torch.full((f["input_ids"].shape[0], width), 7, dtype=torch.long)  # junk under the padding
+        m = torch.zeros_like(ids)
+        w = min(width, f["input_ids"].shape[1])
+        ids[:, :w], m[:, :w] = f["input_ids"][:, :w], f["attention_mask"][:, :w]
+        return {"input_ids": ids * m + 7 * (1 - m), "attention_mask": m}
+    for wq, wd in ((8, 9), (11, 10), (16, 31)):
+        assert c.keys(repad(q, wq), repad(d, wd)) == keys, (wq, wd)
+    c.insert(c.keys(repad(q, 13), repad(d, 17)), scores)
+    assert c.rows == nq
+    # a sample whose last real token differs only by its length is a different sample
+    shorter = {"input_ids": d["input_ids"], "attention_mask": d["attention_mask"].clone()}
+    shorter["attention_mask"][0, 8] = 0
+    assert c.keys(q, shorter)[0] != keys[0]
+    # growth is geometric: inserting many rows re-allocates O(log N) times
+    c2, allocs = TeacherScoreCache(), set()
+    for i in range(40):
+        c2.insert(list(range(i * 100, i * 100 + 100)), torch.full((100, k), float(i)))
+        allocs.add(c2.table.data_ptr())
+    assert c2.rows == 4000 and len(allocs) <= 4 and float(c2.lookup([3950])[0, 0]) == 39.0
 
 
 def test_synthetic_dataset_and_collator_layout():
