@@ -449,25 +449,10 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd: H=%d must be a multiple of 64 (<= 1024)", H);
   SM_REQUIRE(dtype == SM_F32 || dtype == SM_BF16, "sm_sparse_head_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  // Fork / join: the two halves of the head backward are independent.  When dE falls back to the gather kernel
-  // (L2/MALL-bandwidth-bound) it runs on a side stream next to the MFMA-bound dt GEMM; events only (no host
-  // synchronisation), the side stream and events live for the process.  When both halves are the one-workgroup-
-  // per-CU MFMA kernels they cannot share a CU anyway and simply follow each other on the caller's stream.
-  static thread_local hipStream_t side = nullptr;
-  static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  constexpr int overlap_env = 1;
-  const bool overlap = overlap_env && dt != nullptr && dE != nullptr && !sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag);
+  // The two halves of the head backward are independent; both run on the caller's stream here.  A caller that wants them
+  // side by side passes dt == NULL / dE == NULL in two calls on two streams of its own (sparse_hip/encoder.py does): the
+  // library creates no streams or events and keeps no state (include/sparse_hip.h, Conventions).
   hipStream_t st_de = st;
-  if (overlap) {
-    if (side == nullptr) {
-      SM_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      SM_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      SM_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
-    SM_HIP_CHECK(hipEventRecord(ev_fork, st));
-    SM_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
-    st_de = side;
-  }
   // dt == NULL / dE == NULL: only the other half (the caller runs the halves on different streams)
   if (dE == nullptr) {
     SM_REQUIRE(dt != nullptr, "sm_sparse_head_bwd: dt and dE are both NULL");
@@ -499,10 +484,6 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
   if (dt != nullptr) {
     const int rc = sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
     if (rc != SM_OK) return rc;
-  }
-  if (overlap) {
-    SM_HIP_CHECK(hipEventRecord(ev_join, side));
-    SM_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
   }
   return SM_OK;
 }

@@ -167,6 +167,13 @@ class HipBertMLM(torch.nn.Module):
         self.residual_fp32 = (True if residual_fp32 is None else bool(residual_fp32)) and compute_dtype != torch.float32
         self.with_head = with_head
         H = cfg.hidden_size
+        # Fused feed-forward block (csrc/ffn_fused.hip: LayerNorm-1 + FFN-up + GELU + FFN-down + residual + LayerNorm-2 in one
+        # launch, its backward in another; the [T, I] intermediate stays on the chip between the two GEMMs): bf16 runs with the
+        # fp32 residual stream at hidden size 384.  ffn_f16: its FORWARD operands are fp16 instead of bf16 (same MFMA rate, three
+        # more mantissa bits; gradients stay bf16).  SM_FUSED_FFN=0 / SM_FFN_F16=0 select the unfused kernels / bf16 operands.
+        self.fused_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
+                          and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "1") != "0")
+        self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
         if H // cfg.num_attention_heads not in (32, 64):
@@ -331,6 +338,18 @@ class HipBertMLM(torch.nn.Module):
             self._cast_table = ops.CastTable(ent)  # raw pointers: rebuilt if the flat buffer or the staging set changes
             self._cast_key = (self.flat_param.data_ptr(), len(st))
         self._cast_table.run()
+        if self.fused_ffn and cfg.num_hidden_layers > 0:
+            nl = cfg.num_hidden_layers
+            op = torch.float16 if self.ffn_f16 else torch.bfloat16
+            if "ffn_w1h" not in st:
+                st["ffn_w1h"] = torch.empty((nl, I, H), dtype=op, device=dev)
+                st["ffn_w2p"] = torch.empty((nl, I // 32, H, 32), dtype=op, device=dev)
+                st["ffn_w1tp"] = torch.empty((nl, I // 32, H, 32), dtype=torch.bfloat16, device=dev)
+            n0 = "bert.encoder.layer.0."
+            stride = (self._offsets["bert.encoder.layer.1.intermediate.dense.weight"][0]
+                      - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
+            ops.ffn_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
+                          st["ffn_w1h"], st["ffn_w2p"], st["ffn_w1tp"])
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
@@ -388,6 +407,19 @@ class HipBertMLM(torch.nn.Module):
             ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at, rag)
             z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
                              residual_ln=res_ln)
+            if self.fused_ffn:  # LayerNorm 1 .. LayerNorm 2 in one launch; gelu(f1) is not stored (the fused backward re-creates it)
+                g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
+                g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
+                fused = ops.ffn_fwd(z1, g1, b1, eps, st["ffn_w1h"][l], v(p + "intermediate.dense.bias"), st["ffn_w2p"][l],
+                                    v(p + "output.dense.bias"), g2, b2, d_h2, save_f1=save)
+                if fused is None:
+                    raise L.SparseHipError("fused feed-forward kernel declined a shape it was enabled for")
+                x1, m1, r1, f1, z2, x2, m2, r2 = fused
+                x32, res_ln = z2, (m2, r2, g2, b2)
+                if save:
+                    saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
+                x = x2
+                continue
             if r32:
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
                 x1, _, m1, r1 = ops.layernorm_fwd_res32(z1, g1, b1, eps, x.dtype, want_y32=False)
@@ -621,14 +653,26 @@ class _EncodeFn(torch.autograd.Function):
                                               g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"),
                                               d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
-            wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-            df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
-            wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
-            # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
-            # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
-            fused = ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
-                                       g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
-                                       d_h1, want_drop=d_h1 is not None)
+            fused = None
+            if ga is None:  # the forward ran the fused block: its backward in one launch (dF1 and gelu(f1) come out for the weight gradients)
+                fb = ops.ffn_bwd(a2, dz2, f1, st[f"w2T{l}"], st["ffn_w1tp"][l], z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                 d_h1, g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
+                                 want_drop=d_h1 is not None)
+                if fb is None:
+                    raise L.SparseHipError("fused feed-forward backward declined a shape its forward took")
+                df1, ga, dz1, dz1d = fb
+                fused = (dz1, dz1d)
+                wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+                wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
+            else:
+                wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+                df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
+                wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
+                # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
+                # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
+                fused = ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                           g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
+                                           d_h1, want_drop=d_h1 is not None)
             if fused is not None:
                 dz1, dz1d = fused
             else:

@@ -56,6 +56,9 @@ SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
     "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
+    "sm_ffn_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
+    "sm_ffn_fwd": [_i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "sm_ffn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
     "sm_layernorm_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],

@@ -22,7 +22,7 @@ def golden_dir():
 
 
 # kernel / end-to-end parity first, multi-process cases last: a stalled rendezvous must not hide the parity results
-_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_kernels_gpu", "test_e2e_gpu", "test_baseline_configs_gpu",
+_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_kernels_gpu", "test_ffn_fused_gpu", "test_e2e_gpu", "test_baseline_configs_gpu",
           "test_fullsize_gpu", "test_bench_cli", "test_distributed")
 
 

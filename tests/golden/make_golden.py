@@ -20,6 +20,9 @@ Fixtures (names follow SURVEY.md section 8c):
   g8_adamw.npz    3 optimiser steps (AdamW wd on all params + linear warm-up)
   g9_postprocess.npz  SparsePostProcessor (sparse_encoders.py:130-150) on a small sparse matrix:
                   per row the (token id, weight) pairs it emits      [python make_golden.py g9]
+  g10_hfstd.npz   the G1 / G6 outputs again for a model at the HF initialisation scale (weights N(0, 0.02), as
+                  BertConfig.initializer_range; G1-G8's model is at 4x that so that more activations are positive): what
+                  the bf16 tests assert the north star's 1e-2 on                 [python make_golden.py g10]
 """
 import importlib.machinery
 import json
@@ -65,7 +68,7 @@ def vocab_tokens():
     return toks
 
 
-def build_model_dir(path, seed=0):
+def build_model_dir(path, seed=0, std=0.08, bias_std=0.05, ln_std=0.1):
     import transformers
 
     cfg = transformers.BertConfig(
@@ -80,11 +83,11 @@ def build_model_dir(path, seed=0):
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "LayerNorm.weight" in n:
-                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                p.copy_(1.0 + ln_std * torch.randn(p.shape, generator=g))
             elif n.endswith("bias"):
-                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                p.copy_(bias_std * torch.randn(p.shape, generator=g))
             else:
-                p.copy_(0.08 * torch.randn(p.shape, generator=g))
+                p.copy_(std * torch.randn(p.shape, generator=g))
     model.save_pretrained(path)
     toks = vocab_tokens()
     tok = transformers.BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=True)
@@ -507,6 +510,59 @@ def g9():
     np.savez_compressed(os.path.join(HERE, "g9_postprocess.npz"), x=x, nnz=nnz, cols=cols, vals=vals)
     print("g9_postprocess.npz", nnz.tolist())
 
+
+def g10():
+    """SparseModel._encode (sparse_encoders.py:107-119) and SparseModelTrainer.compute_loss (trainer.py:81-143) of the
+    reference on a model initialised at the HF scale"""
+    sys.path.insert(0, REF)
+    install_stubs()
+    os.chdir(REF)
+    from scripts.model.sparse_encoders import SparseModel
+    tmp = tempfile.mkdtemp(prefix="golden_g10_")
+    out = {}
+    try:
+        hf_model = build_model_dir(tmp, seed=10, std=0.02, bias_std=0.02, ln_std=0.05)
+        idf_vec = np.load(os.path.join(HERE, "g2_inf_free.npz"))["idf_vector"]
+        idf = {t: float(v) for t, v in zip(vocab_tokens(), idf_vec)}
+        rng = np.random.default_rng(1010)
+        out.update({"sd/" + k: v for k, v in sd_np(hf_model).items()})
+        B, S = 8, 32
+        ids, mask = ragged_batch(rng, B, S)
+        up = rng.standard_normal((B, V)).astype(np.float32)
+        out.update(input_ids=ids, attention_mask=mask, upstream=up)
+        for use_l0 in (False, True):
+            m = SparseModel(tmp, idf=idf, tokenizer_id=tmp, use_l0=use_l0)
+            m.train()
+            rep = m(inf_free=False, input_ids=torch.tensor(ids), attention_mask=torch.tensor(mask))
+            out[f"rep_l0{int(use_l0)}"] = rep.detach().numpy()
+            if not use_l0:
+                m.zero_grad()
+                (rep * torch.tensor(up)).sum().backward()
+                for n, p in m.backbone.named_parameters():
+                    if p.grad is not None and not n.startswith("cls.predictions.decoder"):
+                        out["grad/" + n] = p.grad.numpy().copy()
+        trainer, model, _, _ = make_trainer(tmp, idf, dict(inf_free=True), dict(use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10),
+                                            ["infonce"])
+        trainer.model.train()
+        inp, raw = batch_inputs(rng, 4, 4, 8, 32, False)
+        for key, val in raw.items():
+            out["cl/" + key] = val
+        trainer.state.global_step = 5
+        trainer.ranking_loss_moving_avg = 0
+        loss, outputs = trainer.compute_loss(trainer.model, inp, return_outputs=True)
+        out["cl/loss"] = loss.detach().numpy()
+        out["cl/q_rep"], out["cl/d_rep"] = outputs["q_rep"].detach().numpy(), outputs["d_rep"].detach().numpy()
+        pos = float((out["rep_l00"] > 0).mean())
+        print(f"g10: {100 * pos:.1f} % of the sparse activations positive, max {out['rep_l00'].max():.3f}, loss {float(loss):.5f}")
+        np.savez_compressed(os.path.join(HERE, "g10_hfstd.npz"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("g10_hfstd.npz", os.path.getsize(os.path.join(HERE, "g10_hfstd.npz")))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g10":
+    g10()
+    sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "g7":
     g7()

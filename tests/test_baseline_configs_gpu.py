@@ -11,8 +11,12 @@ against oracle.compute_loss on the same seeded inputs.
       (bert-base MLM) and a dense (BERT-large shaped stand-in for gte-large) frozen teacher
 
 Tolerances (north star): fp32 storage 1e-3 elementwise; bf16 1e-2 -- ELEMENTWISE, |err| <= 1e-2 (1 + |ref|) on every sparse
-activation (default: bf16 GEMM operands, fp32 residual stream), plus relative Frobenius error 1e-2; the measured worst element and
-the fraction inside the bound are printed."""
+activation (default: bf16 GEMM operands, fp32 residual stream), plus relative Frobenius error 1e-2.  The bf16 runs are compared
+with TWO oracles and both figures are printed and asserted:
+  * "identical inputs": the oracle multiplies the UNROUNDED fp32 weights -- what the reference's CPU path computes from the same
+    checkpoint (north star: "match the reference CPU path on identical inputs within 1e-2 bf16");
+  * "kernel error": the oracle multiplies the weights the device staged (rounded to bf16 once per optimiser step): isolates what
+    the kernels add on top of the operand rounding any bf16 path has."""
 import time
 
 import pytest
@@ -49,9 +53,10 @@ def _elementwise(got, want, what):
     return float(err.max()), inside
 
 
-def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTION_INSIDE, elementwise=None):
+def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTION_INSIDE, elementwise=None, od_identical=None,
+                   oloss_identical=None):
     d = out["d_rep"].detach().float().cpu()
-    worst, inside = _elementwise(d, od, what + " d_rep")
+    worst, inside = _elementwise(d, od, what + " d_rep" + (" [kernel error: oracle on the staged (bf16-rounded) weights]" if od_identical is not None else ""))
     if dtype == torch.float32:
         assert worst <= 1e-3, f"{what}: d_rep worst element {worst:.3e} > 1e-3 (1+|ref|)"
         assert abs(float(loss.detach()) - float(oloss)) <= 1e-3 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
@@ -62,25 +67,47 @@ def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTI
         assert worst <= bound, f"{what}: d_rep worst element {worst:.3e} > {bound} (1+|ref|)"
         assert inside >= fraction_inside, f"{what}: only {inside:.5f} of d_rep inside 1e-2 (1+|ref|)"
         assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
+        if od_identical is not None:  # the north-star comparison: same fp32 checkpoint in, reference CPU arithmetic
+            worst_i, inside_i = _elementwise(d, od_identical, what + " d_rep [IDENTICAL INPUTS: oracle on the unrounded fp32 weights]")
+            assert worst_i <= bound, f"{what}: d_rep worst element {worst_i:.3e} > {bound} (1+|ref|) against the unrounded fp32 oracle"
+            assert inside_i >= fraction_inside
+            dl = abs(float(loss.detach()) - float(oloss_identical))
+            print(f"[{what}] loss {float(loss.detach()):.6f}, oracle (unrounded weights) {float(oloss_identical):.6f}, oracle (staged weights) {float(oloss):.6f}")
+            assert dl <= 1e-2 * (1 + abs(float(oloss_identical))), (float(loss.detach()), float(oloss_identical))
     if oq is not None:
         assert torch.equal(out["q_rep"].detach().cpu(), oq.detach()), "inference-free query encoding must be bit-exact"
 
 
-def _check_grads(dtype, bb, pr, what):
-    for n in GRAD_NAMES:
+def _grad_report(bb, pr, names=GRAD_NAMES):
+    out = {}
+    for n in names:
         got = bb.view(n, grad=True).detach().float().cpu()
         want = pr[n].grad if pr[n].grad is not None else torch.zeros_like(pr[n])
+        out[n] = (float((got - want).norm() / max(1e-12, float(want.norm()))), float((got - want).abs().max()), float(want.abs().max()))
+    return out
+
+
+BF16_GRAD_REL = 1.5e-1  # relative Frobenius error of a parameter gradient, bf16 storage, maxima routed as on the device
+
+
+def _check_grads(dtype, bb, pr, what, pr_unrouted=None):
+    rep = _grad_report(bb, pr)
+    unrouted = _grad_report(bb, pr_unrouted) if pr_unrouted is not None else None
+    for n in GRAD_NAMES:
+        rel, err, scale = rep[n]
         if dtype == torch.float32:
-            scale = max(1e-6, float(want.abs().max()))
-            err = float((got - want).abs().max())
+            scale = max(1e-6, scale)
             assert err <= 2e-3 * scale, f"{what} grad {n}: max err {err:.3e} > 2e-3 * {scale:.3e}"
         else:
-            rel = float((got - want).norm() / max(1e-12, float(want.norm())))
-            assert rel <= 1.5e-1, f"{what} grad {n}: relative Frobenius error {rel:.3e}"
+            extra = f", oracle's own arg-max routing {unrouted[n][0]:.3e}" if unrouted is not None else ""
+            print(f"[{what}] grad {n}: rel Frobenius {rel:.3e} (maxima routed as on the device){extra}")
+            assert rel <= BF16_GRAD_REL, f"{what} grad {n}: relative Frobenius error {rel:.3e} > {BF16_GRAD_REL}"
+            if unrouted is not None:  # near-tied maxima that bf16 rounding resolves the other way move whole gradient rows
+                assert unrouted[n][0] <= 1.5e-1, f"{what} grad {n}: relative Frobenius error {unrouted[n][0]:.3e} against the un-routed oracle"
 
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
-                  residual_fp32=None, elementwise=None, grad_cache_chunk=0):
+                  residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
@@ -143,17 +170,33 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     with torch.no_grad():  # what the outputs are compared with: the oracle's own maxima
         od_free = O.sparse_activation(logits, d["attention_mask"], use_l0)
         oloss = O.total_loss(oq, od_free, batch.get("scores"), lc, step, 1)[0]
+    pr_unrouted = None
     if check_grads:
         # for the GRADIENTS the oracle takes each (doc, vocab) maximum at the position the kernel's came from: a near-tie
         # that rounding resolved the other way would otherwise move whole gradient rows between token positions
         od = O.sparse_activation(logits, d["attention_mask"], use_l0, route=route)
         O.total_loss(oq, od, batch.get("scores"), lc, step, 1)[0].backward()
+        if dtype != torch.float32 and unrouted_grads:  # ... and, reported beside it, with the oracle's own routing
+            del logits, od
+            pr_unrouted = _round_like_staged(p, dtype)
+            lg = O.bert_mlm_logits(pr_unrouted, d["input_ids"], d["attention_mask"], oc)
+            O.total_loss(oq, O.sparse_activation(lg, d["attention_mask"], use_l0), batch.get("scores"), lc, step, 1)[0].backward()
+            logits = lg
+            del lg
     del logits
+    od_identical = oloss_identical = None
+    if dtype != torch.float32:  # IDENTICAL INPUTS: the same fp32 checkpoint, multiplied unrounded (the reference's CPU path)
+        with torch.no_grad():
+            lg = O.bert_mlm_logits(p, d["input_ids"], d["attention_mask"], oc)
+            od_identical = O.sparse_activation(lg, d["attention_mask"], use_l0)
+            del lg
+            oloss_identical = O.total_loss(oq, od_identical, batch.get("scores"), lc, step, 1)[0]
     rows = inp["docs"][0]["packed"].rag.rows if inp["docs"][0].get("packed") is not None else nq * k * S
     print(f"[{what}] oracle {time.time() - t0:.1f} s, {rows} token rows on the device")
-    _check_outputs(dtype, loss, oloss, out, oq, od_free, what, elementwise=elementwise)
+    _check_outputs(dtype, loss, oloss, out, oq, od_free, what, elementwise=elementwise, od_identical=od_identical,
+                   oloss_identical=oloss_identical)
     if check_grads:
-        _check_grads(dtype, bb, pr, what)
+        _check_grads(dtype, bb, pr, what, pr_unrouted)
     return trainer, bb
 
 
@@ -244,9 +287,12 @@ def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
     trainer.model.train()
     inp = trainer._prepare_inputs(batch)
     trainer.zero_grad()
+    bbs[0]._argmax_log = []
     loss, out = trainer.compute_loss(trainer.model, inp, return_outputs=True)
     loss.backward()
     torch.cuda.synchronize()
+    route = bbs[0]._argmax_log[0].cpu().long() & 0xFFFF
+    bbs[0]._argmax_log = None
     q, d = batch["query"][0], batch["docs"][0]
     t0 = time.time()
     with torch.no_grad():
@@ -282,7 +328,16 @@ def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
         lc = O.LossConfig(loss_types=("kldiv",), use_in_batch_negatives=True, flops_d_lambda=0.002, flops_d_T=200)
         oloss, _, _, oq, od = O.compute_loss(prs[0], ocs[0], idf, SPECIAL, q["input_ids"], q["attention_mask"], d["input_ids"],
                                              d["attention_mask"], got_t, lc, 100)
+        # IDENTICAL INPUTS: the student's fp32 checkpoint multiplied unrounded (the reference's CPU path)
+        oloss_i, _, _, _, od_i = O.compute_loss(params[0], ocs[0], idf, SPECIAL, q["input_ids"], q["attention_mask"], d["input_ids"],
+                                                d["attention_mask"], got_t, lc, 100)
+    # student gradients: the oracle takes every (doc, vocab) maximum at the position the kernel's came from
+    pr_s = _round_like_staged(params[0], dtype)
+    logits = O.bert_mlm_logits(pr_s, d["input_ids"], d["attention_mask"], ocs[0])
+    od_r = O.sparse_activation(logits, d["attention_mask"], False, route=route)
+    O.total_loss(oq, od_r, got_t, lc, 100, 1)[0].backward()
+    del logits
     print(f"[c4] oracle {time.time() - t0:.1f} s")
     # 12 layers: worst element 8.7e-3 (1 + |ref|) with the fp32 residual stream (2.1e-2 with all-bf16 storage)
-    _check_outputs(dtype, loss, oloss, out, oq, od, "c4")
-    assert torch.isfinite(bbs[0].flat_grad).all() and float(bbs[0].flat_grad.abs().max()) > 0
+    _check_outputs(dtype, loss, oloss, out, oq, od, "c4", od_identical=od_i, oloss_identical=oloss_i)
+    _check_grads(dtype, bbs[0], pr_s, "c4")

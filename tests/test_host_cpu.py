@@ -20,7 +20,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def test_library_loads_and_exports_every_declared_symbol():
     from sparse_hip import lib
     so = lib.load()
-    assert so.sm_abi_version() == 2
+    assert so.sm_abi_version() == 3
     header = open(os.path.join(ROOT, "include", "sparse_hip.h")).read()
     declared = set(re.findall(r"\b(sm_[a-z0-9_]+)\s*\(", header))
     declared -= {"sm_dropout", "sm_epilogue"}
@@ -49,6 +49,25 @@ def test_entry_points_reject_bad_arguments_with_a_message_before_touching_the_gp
         assert rc < 0 and name.split("_fwd")[0].split("_bwd")[0] in msg and needle in msg, (name, rc, msg)
     with pytest.raises(L.SparseHipError, match="no CPU fallback"):
         L.ptr(torch.zeros(4))
+
+
+def test_library_creates_no_hip_objects_of_its_own():
+    """include/sparse_hip.h: "the library allocates nothing and keeps no state except a thread-local error string" -- no
+    stream / event / memory creation call in any translation unit, and the built object imports none of them"""
+    import subprocess
+    banned = ("hipStreamCreate", "hipEventCreate", "hipMalloc", "hipHostMalloc", "hipMallocAsync", "hipMemPoolCreate", "hipGraphCreate")
+    csrc = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            for b in banned:
+                assert b not in src, f"{f} calls {b}"
+            if f != "api.cpp":
+                assert "thread_local" not in src, f"{f} keeps thread-local state"
+    so = os.path.join(PKG, "sparse_hip", "libsparse_hip.so")
+    nm = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    for b in banned:
+        assert b not in nm, f"libsparse_hip.so imports {b}"
 
 
 def test_product_path_has_no_cpu_fallback_and_never_imports_the_oracle():

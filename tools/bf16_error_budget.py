@@ -53,7 +53,9 @@ def encode(p, ids, mask, cfg, act_round, resid_fp32, z_fp32=None):
 
 def main():
     nd = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    cfg = O.BertShape()
+    shape = sys.argv[2] if len(sys.argv) > 2 else "mini"      # mini | base (bert-base, 12 layers: BASELINE configs[3] / [4])
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    cfg = O.BertShape() if shape == "mini" else O.BertShape(30522, 768, 12, 12, 3072, 512)
     p = O.init_params(cfg, seed=2)
     g = torch.Generator().manual_seed(102)
     for n in p:
@@ -62,8 +64,9 @@ def main():
         elif n.endswith("LayerNorm.weight"):
             p[n] = 1 + 0.05 * torch.randn(p[n].shape, generator=g)
     pw = {n: (r(v) if v.dim() == 2 and "position" not in n and "token_type" not in n else v) for n, v in p.items()}
-    ds = SyntheticTriplesDataset(nd // 16, 16, 128, 32, cfg.vocab_size, seed=9)
-    d = PreTokenizedCollator()([ds[i] for i in range(nd // 16)])["docs"][0]
+    k = min(nd, 16)
+    ds = SyntheticTriplesDataset(nd // k, k, S, 32, cfg.vocab_size, seed=9, len_mean=S * 0.625, len_std=S * 0.234)
+    d = PreTokenizedCollator()([ds[i] for i in range(nd // k)])["docs"][0]
     with torch.no_grad():
         ref = O.sparse_activation(O.bert_mlm_logits(p, d["input_ids"], d["attention_mask"], cfg), d["attention_mask"])
         for name, (params, act, res, zf) in {"C weights only": (pw, False, True, True), "B fp32 residual stream": (pw, True, True, True),
