@@ -20,6 +20,15 @@
 // Every weight byte is read from L2 once per 128 tokens (128 FLOP per LDS-DMA byte; the CU's load path moves ~33-40 B/clk, the
 // 128 x 128 GEMM tile this replaces runs at 64), and once from LDS per 16 tokens.  One s_barrier per chunk (48 MFMAs per wave).
 //
+// MEASURED (round 3, profiles/r3_ffn_fused.txt): the 16-token wave makes every v_mfma_f32_16x16x32 (16 cycles) consume one
+// 1-KiB ds_read_b128 fragment -- 8 waves x 1 KiB per 32 cycles = the LDS array's 256 B/clk at 100 % MFMA rate.  The bare
+// read + MFMA stream of one workgroup therefore runs at ~57 % of the matrix pipe, the whole kernel (GELU, LDS-DMA issue by the
+// compute waves, barrier, LayerNorm prologue / epilogue bursts) at ~30 %: 147 us per round of 256 workgroups forward, i.e. no
+// faster than the four unfused launches at the bench's 43.9 k rows (two rounds), 25 % faster at 65.5 k.  A 32-token wave
+// (32x32x16 MFMA, half the LDS bytes per FLOP) needs 96 + 192 accumulator / operand registers and does not fit two waves per
+// SIMD.  The kernels are kept for what they do deliver: fp16 forward operands at no cost in rate and one launch instead of
+// four; sparse_hip/encoder.py enables them with SM_FUSED_FFN=1 (default off).
+//
 // Operand precision: the forward takes its GEMM operands (x1, W1, g, W2) in fp16 rather than bf16 -- same MFMA rate, three more
 // mantissa bits: the forward rounding of these four tensors was 44 % of the error variance of the 12-layer sparse activations
 // against the fp32 reference (tools/bf16_error_budget.py).  Gradients (backward) stay bf16 (range).
@@ -134,7 +143,72 @@ struct FfLoader {
   }
 };
 
-// X0 / X1 (+)= the 32 rows of ring-1 address a1 (k-step-major image) . xb: 2 tiles x 12 k-steps, fragments double-buffered
+// ---- one chunk iteration as ONE software-pipelined stream of 48 fragment reads and 48 MFMAs -----------------------------------
+// Iteration i computes GEMM 1 of chunk i + 1 (X^T: 2 tiles x 12 k-steps, ring-1 slot of chunk i + 1) and GEMM 2 of chunk i (24
+// tiles, ring-2 slot of chunk i, B fragment `gb` from the previous iteration's GELU).  Order: for s = 0 .. 11
+// { X0 k-step s, X1 k-step s, acc[s] }, then acc[12 .. 23]; read k feeds MFMA k and lands in frag[k % 12]; FF_D reads are always in
+// flight -- the last FF_D of an iteration already belong to the NEXT one (addresses a1n / a2n), so the LDS pipe never drains.
+// beta() runs after MFMA 35 (GEMM 1 complete): the wave's counted vmcnt wait, the iteration's only s_barrier and the next
+// LDS-DMA batch; it makes the data of iteration i + 1 visible before the first read of it is issued (read 39 + FF_D - 48 >= 0 comes
+// later in program order) and comes after every wave's last read of iteration i - 1's slots, which the batch overwrites.
+// finish(X0, X1, b0, b1) follows: VALU work that is free to float in between the remaining twelve MFMAs.
+constexpr int FF_D = 9, FF_RING = 12;
+template <typename V, int J> __device__ __forceinline__ void ff_issue_read(uint32_t a1, uint32_t a2, V (&frag)[FF_RING]) {
+  if constexpr (J < 36) {
+    constexpr int s = J / 3, r = J % 3;
+    if constexpr (r < 2) frag[J % FF_RING] = ff_lds_read<V, s * 2048 + r * 1024>(a1);
+    else frag[J % FF_RING] = ff_lds_read<V, s * 1024>(a2);
+  } else {
+    frag[J % FF_RING] = ff_lds_read<V, (J - 24) * 1024>(a2);
+  }
+}
+template <int N, typename V> __device__ __forceinline__ void ff_wait_frag(V& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory"); }
+template <int N, typename V> __device__ __forceinline__ void ff_wait_frag_bias(V& f, f32x4& b0, f32x4& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f), "+v"(b0), "+v"(b1) : "n"(N) : "memory");
+}
+// LAST: nothing follows (no look-ahead reads, no finish); its GEMM-1 part runs on whatever slot a1 names and is discarded
+template <typename OP, bool LAST, bool BIAS, typename Beta, typename Finish>
+__device__ __forceinline__ void ff_iter(uint32_t a1, uint32_t a2, uint32_t a1n, uint32_t a2n, uint32_t bias_addr,
+                                        const typename OP::V (&xb)[FF_KS], f32x4 (&acc)[FF_NT], typename OP::V (&frag)[FF_RING],
+                                        typename OP::V& gb, Beta&& beta, Finish&& finish) {
+  using V = typename OP::V;
+  f32x4 X0 = f32x4{0.f, 0.f, 0.f, 0.f}, X1 = f32x4{0.f, 0.f, 0.f, 0.f}, b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  V gnext = gb;
+  ff_static_for<0, 48>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, j = k + FF_D;
+    if constexpr (j < 48) ff_issue_read<V, j>(a1, a2, frag);
+    else if constexpr (!LAST) ff_issue_read<V, j - 48>(a1n, a2n, frag);
+    constexpr bool bias_now = BIAS && !LAST;
+    if constexpr (bias_now && k == 12) {
+      b0 = ff_lds_read_f4(bias_addr);
+      b1 = ff_lds_read_f4(bias_addr + 64);
+    }
+    // LDS operations issued after read k: the look-ahead reads (+ the two bias reads while they are younger than read k)
+    constexpr int ahead = LAST ? (47 - k < FF_D ? 47 - k : FF_D) : FF_D;
+    constexpr int after = ahead + ((bias_now && k >= 13 && k <= 12 + FF_D) ? 2 : 0);
+    if constexpr (bias_now && k == 13 + FF_D) ff_wait_frag_bias<after>(frag[k % FF_RING], b0, b1);
+    else ff_wait_frag<after>(frag[k % FF_RING]);
+    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);  // VALU / SALU may float across; MFMA and LDS stay behind the wait
+    if constexpr (k < 36) {
+      constexpr int st = k / 3, r = k % 3;
+      if constexpr (r == 0) X0 = OP::mma(frag[k % FF_RING], xb[st], X0);
+      else if constexpr (r == 1) X1 = OP::mma(frag[k % FF_RING], xb[st], X1);
+      else acc[st] = OP::mma(frag[k % FF_RING], gb, acc[st]);
+    } else {
+      acc[k - 24] = OP::mma(frag[k % FF_RING], gb, acc[k - 24]);
+    }
+    if constexpr (k == 35) {
+      beta();
+      if constexpr (!LAST) gnext = finish(X0, X1, b0, b1);
+    }
+  });
+  gb = gnext;
+}
+// the FF_D look-ahead reads of the first iteration
+template <typename V> __device__ __forceinline__ void ff_prime(uint32_t a1, uint32_t a2, V (&frag)[FF_RING]) {
+  ff_static_for<0, FF_D>([&](auto jc) { ff_issue_read<V, decltype(jc)::value>(a1, a2, frag); });
+}
+// GEMM 1 of chunk 0 (prologue; simple two-deep pipeline)
 template <typename OP>
 __device__ __forceinline__ void ff_gemm1(uint32_t a1, const typename OP::V (&xb)[FF_KS], f32x4& X0, f32x4& X1) {
   using V = typename OP::V;
@@ -150,31 +224,9 @@ __device__ __forceinline__ void ff_gemm1(uint32_t a1, const typename OP::V (&xb)
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]) : : "memory");
     }
-    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);  // VALU / SALU may float across; MFMA and LDS stay behind the wait
+    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);
     X0 = OP::mma(fa[cur][0], xb[ks], X0);
     X1 = OP::mma(fa[cur][1], xb[ks], X1);
-  });
-}
-
-// acc[n] += W2-slab rows (ring-2 address a2) . gb, 24 tiles, 2 fragments in flight
-template <typename OP>
-__device__ __forceinline__ void ff_gemm2(uint32_t a2, typename OP::V gb, f32x4 (&acc)[FF_NT]) {
-  using V = typename OP::V;
-  V fa[3];
-  fa[0] = ff_lds_read<V, 0>(a2);
-  fa[1] = ff_lds_read<V, 1024>(a2);
-  ff_static_for<0, FF_NT>([&](auto nc) {
-    constexpr int n = decltype(nc)::value;
-    if constexpr (n + 2 < FF_NT) {
-      fa[(n + 2) % 3] = ff_lds_read<V, (n + 2) * 1024>(a2);
-      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[n % 3]) : : "memory");
-    } else if constexpr (n + 1 < FF_NT) {
-      asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[n % 3]) : : "memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[n % 3]) : : "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);
-    acc[n] = OP::mma(fa[n % 3], gb, acc[n]);
   });
 }
 
@@ -199,10 +251,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(FfnFwdArgs a) {
 
   FfLoader ld;
   ld.init(w, lane);
-  // batches: B(-1) = W1 chunk 0; B(b) = {W1 chunk b + 1, W2 chunk b}; B(0), B(1) before the loop, B(i + 2) in iteration i
+  // prologue batches: W1 chunks 0, 1, 2 and W2 chunks 0, 1 (the third pair re-loads W2 chunk 1: the loader moves pairs)
   ld.issue(ff_smem, w1, 0, 0, w2p, 0, 0);
-  ld.issue(ff_smem, w1, min(1, NC - 1), 1, w2p, min(1, NC - 1), 1);
-  ld.issue(ff_smem, w1, min(2, NC - 1), 2, w2p, min(2, NC - 1), 2);
+  ld.issue(ff_smem, w1, 1, 1, w2p, 1, 1);
+  ld.issue(ff_smem, w1, 2, 2, w2p, 1, 1);
 
   // ---- LayerNorm 1 of this lane's token: columns 32 ks + 8 g .. + 7 for every k-step (the B fragments of GEMM 1).  Three
   //      passes over the row (L1 / L2 hits after the first) instead of 96 fp32 values held in registers ----
@@ -269,9 +321,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(FfnFwdArgs a) {
   const bool stores = active && a.f1 != nullptr;  // wave-uniform: this wave issues two f1 stores per chunk
   const uint32_t f1lane = (uint32_t)(((size_t)row * a.I + 4 * g) * 2);  // byte offset of this lane's first f1 element (T * I * 2 < 4 GiB)
   // bias + f1 store + GELU of one chunk's X^T tiles -> the B fragment of GEMM 2 (k order: rows 4g..4g+3 of tile 0, then of tile 1)
-  auto finish = [&](int c, f32x4 X0, f32x4 X1) -> V {
-    f32x4 b0 = ff_lds_read_f4(biasaddr + (uint32_t)(c * FF_IC * 4)), b1 = ff_lds_read_f4(biasaddr + (uint32_t)(c * FF_IC * 4) + 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");
+  auto finish = [&](int c, f32x4 X0, f32x4 X1, f32x4 b0, f32x4 b1) -> V {
     float o[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { o[k] = X0[k] + b0[k]; o[4 + k] = X1[k] + b1[k]; }
@@ -287,38 +337,42 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(FfnFwdArgs a) {
     for (int k = 0; k < 8; ++k) o[k] = gelu_fast(o[k]);
     return OP::pack(o);
   };
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // chunk 0's GEMM 1 (ring-1 slot 0)
+  // chunk 0's GEMM 1 (ring-1 slot 0) and GELU
   V gb;
   {
-    f32x4 X0 = zero4, X1 = zero4;
+    f32x4 b0 = ff_lds_read_f4(biasaddr), b1 = ff_lds_read_f4(biasaddr + 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");
+    f32x4 X0 = f32x4{0.f, 0.f, 0.f, 0.f}, X1 = X0;
     ff_gemm1<OP>(a1lane, xb, X0, X1);
-    gb = finish(0, X0, X1);
+    gb = finish(0, X0, X1, b0, b1);
   }
-  // Vector-memory operations of a wave, in issue order: ... B(i) [6 LDS-DMA]  S(i-1) [2 stores]  B(i+1) [6]  S(i) [2] -- at the
-  // top of iteration i everything up to B(i) must have retired, so exactly the ops younger than it may be outstanding: 10 for
-  // a wave that stores f1, 6 for one that does not (a LARGER count than the ops really issued would let B(i) slip through)
+  // Batches.  The prologue loaded W1 chunks 0, 1, 2 and W2 chunks 0, 1.  Q(i), issued behind the barrier of iteration i, is
+  // { W1 chunk i + 3 -> ring-1 slot i % 3 (read last by GEMM 1 of chunk i, in iteration i - 1),
+  //   W2 chunk i + 2 -> ring-2 slot (i + 2) % 3 (read last by GEMM 2 of chunk i - 1, in iteration i - 1) };
+  // the barrier of iteration i waits for Q(i - 1) = the operands of iteration i + 1.  Vector-memory operations of a wave in issue
+  // order: Q(i-1) [6]  S(i) [2 f1 stores]  | barrier of iteration i: exactly the 2 stores may still be outstanding (0 without them)
+  V frag[FF_RING];
+  ff_prime<V>(a1lane + (uint32_t)(1 * FF_STAGE), a2lane, frag);
   for (int i = 0; i + 1 < NC; ++i) {
-    if (stores) ff_wait_vm<10>();
-    else ff_wait_vm<6>();
-    __builtin_amdgcn_s_barrier();  // B(i) has landed for every wave; every wave has finished iteration i - 1 (slots free)
-    asm volatile("" ::: "memory");
-    ld.issue(ff_smem, w1, min(i + 3, NC - 1), (i + 3) % FF_NST, w2p, min(i + 2, NC - 1), (i + 2) % FF_NST);
-    const uint32_t s2 = (uint32_t)((i % FF_NST) * FF_STAGE), s1 = (uint32_t)(((i + 1) % FF_NST) * FF_STAGE);
-    f32x4 X0 = zero4, X1 = zero4;
-    ff_gemm1<OP>(a1lane + s1, xb, X0, X1);
-    const V gnext = finish(i + 1, X0, X1);  // (its VALU part may float in between the MFMAs of GEMM 2 below)
-    ff_gemm2<OP>(a2lane + s2, gb, acc);
-    gb = gnext;
+    const uint32_t a1 = a1lane + (uint32_t)(((i + 1) % FF_NST) * FF_STAGE), a2 = a2lane + (uint32_t)((i % FF_NST) * FF_STAGE);
+    const uint32_t a1n = a1lane + (uint32_t)(((i + 2) % FF_NST) * FF_STAGE), a2n = a2lane + (uint32_t)(((i + 1) % FF_NST) * FF_STAGE);
+    ff_iter<OP, false, true>(
+        a1, a2, a1n, a2n, biasaddr + (uint32_t)((i + 1) * FF_IC * 4), xb, acc, frag, gb,
+        [&]() {
+          if (stores) ff_wait_vm<2>();
+          else ff_wait_vm<0>();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          ld.issue(ff_smem, w1, min(i + 3, NC - 1), i % FF_NST, w2p, min(i + 2, NC - 1), (i + 2) % FF_NST);
+        },
+        [&](f32x4 X0, f32x4 X1, f32x4 b0, f32x4 b1) -> V { return finish(i + 1, X0, X1, b0, b1); });
   }
-  {  // last chunk: only its GEMM 2 is left (the redundant tail batches target slots nobody reads any more)
-    if (stores) ff_wait_vm<10>();
-    else ff_wait_vm<6>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ff_gemm2<OP>(a2lane + (uint32_t)(((NC - 1) % FF_NST) * FF_STAGE), gb, acc);
+  {  // last chunk: only its GEMM 2 matters (the stream's GEMM-1 part re-reads a landed slot and is discarded)
+    const uint32_t a1 = a1lane + (uint32_t)((NC % FF_NST) * FF_STAGE), a2 = a2lane + (uint32_t)(((NC - 1) % FF_NST) * FF_STAGE);
+    ff_iter<OP, true, true>(a1, a2, a1, a2, biasaddr, xb, acc, frag, gb, [&]() {}, [&](f32x4, f32x4, f32x4, f32x4) -> V { return gb; });
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the redundant tail batches)
 
   // ---- epilogue: z2 = dropout(acc + b2) + LN1(z1) (the fp32 residual, recomputed), LayerNorm 2 -> x2; all in-lane ----
   {
@@ -446,8 +500,8 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(FfnBwdArgs a) {
   FfLoader ld;
   ld.init(w, lane);
   ld.issue(ff_smem, w2t, 0, 0, w1tp, 0, 0);
-  ld.issue(ff_smem, w2t, min(1, NC - 1), 1, w1tp, min(1, NC - 1), 1);
-  ld.issue(ff_smem, w2t, min(2, NC - 1), 2, w1tp, min(2, NC - 1), 2);
+  ld.issue(ff_smem, w2t, 1, 1, w1tp, 1, 1);
+  ld.issue(ff_smem, w2t, 2, 2, w1tp, 1, 1);
 
   const uint32_t ilane = (uint32_t)(((size_t)row * a.I + 4 * g) * 2);  // this lane's first element of an [T, I] row, bytes
   // f1 of chunk c travels in F[c & 1]: two 8-byte words (tile 0 rows 4g..4g+3, tile 1 rows 16+4g..)
@@ -507,28 +561,28 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(FfnBwdArgs a) {
     ff_gemm1<OP>(a1lane, dyb, D0, D1);
     gb = finish(0, D0, D1, F0a, F0b);
   }
-  // Vector-memory operations of a wave in issue order: ... B(i) [6]  L(i) [2]  S(i-1) [4] | B(i+1) L(i+1) S(i) | B(i+2) L(i+2) ...
-  //   top of iteration i: B(i) retired  -> 18 younger ops may be outstanding (10 without stores)
-  //   before finish(i+1): L(i+1) retired -> S(i) B(i+2) L(i+2) = 12 younger (8 without stores)
+  // Batches as in the forward: Q(i) behind the barrier of iteration i, together with L(i + 2), the two f1 words of chunk i + 2
+  // (into the pair that finish(i) consumed in iteration i - 1).  Vector-memory operations of a wave in issue order:
+  //   Q(i-1) [6]  L(i+1) [2]  S(i) [4 stores]  | barrier of iteration i needs Q(i-1) (operands of iteration i + 1) and, right
+  //   after it, finish(i + 1) needs L(i+1): only the 4 stores may be outstanding (nothing for a wave that does not store)
+  V frag[FF_RING];
+  ff_prime<V>(a1lane + (uint32_t)(1 * FF_STAGE), a2lane, frag);
   auto body = [&](int i, unsigned long long& Lda, unsigned long long& Ldb, unsigned long long& Usa, unsigned long long& Usb) {
-    if (stores) ff_wait_vm<18>();
-    else ff_wait_vm<10>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ld.issue(ff_smem, w2t, min(i + 3, NC - 1), (i + 3) % FF_NST, w1tp, min(i + 2, NC - 1), (i + 2) % FF_NST);
-    {
-      const bf16* pf = a.f1 + min(i + 2, NC - 1) * FF_IC;
-      Lda = ff_load_b64(pf, ilane);
-      Ldb = ff_load_b64(pf + 16, ilane);
-    }
-    const uint32_t s2 = (uint32_t)((i % FF_NST) * FF_STAGE), s1 = (uint32_t)(((i + 1) % FF_NST) * FF_STAGE);
-    f32x4 D0 = zero4, D1 = zero4;
-    ff_gemm1<OP>(a1lane + s1, dyb, D0, D1);
-    if (stores) asm volatile("s_waitcnt vmcnt(12)" : "+v"(Usa), "+v"(Usb) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" : "+v"(Usa), "+v"(Usb) : : "memory");
-    const V gnext = finish(i + 1, D0, D1, Usa, Usb);
-    ff_gemm2<OP>(a2lane + s2, gb, acc);
-    gb = gnext;
+    const uint32_t a1 = a1lane + (uint32_t)(((i + 1) % FF_NST) * FF_STAGE), a2 = a2lane + (uint32_t)((i % FF_NST) * FF_STAGE);
+    const uint32_t a1n = a1lane + (uint32_t)(((i + 2) % FF_NST) * FF_STAGE), a2n = a2lane + (uint32_t)(((i + 1) % FF_NST) * FF_STAGE);
+    ff_iter<OP, false, false>(
+        a1, a2, a1n, a2n, 0u, dyb, acc, frag, gb,
+        [&]() {
+          if (stores) asm volatile("s_waitcnt vmcnt(4)" : "+v"(Usa), "+v"(Usb) : : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Usa), "+v"(Usb) : : "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          ld.issue(ff_smem, w2t, min(i + 3, NC - 1), i % FF_NST, w1tp, min(i + 2, NC - 1), (i + 2) % FF_NST);
+          const bf16* pf = a.f1 + min(i + 2, NC - 1) * FF_IC;
+          Lda = ff_load_b64(pf, ilane);
+          Ldb = ff_load_b64(pf + 16, ilane);
+        },
+        [&](f32x4 D0, f32x4 D1, f32x4, f32x4) -> V { return finish(i + 1, D0, D1, Usa, Usb); });
   };
   {
     int i = 0;
@@ -539,11 +593,10 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(FfnBwdArgs a) {
     if (i + 1 < NC) body(i, F0a, F0b, F1a, F1b);
   }
   {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(F0a), "+v"(F0b), "+v"(F1a), "+v"(F1b) : : "memory");  // (also the redundant tail prefetches)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    ff_gemm2<OP>(a2lane + (uint32_t)(((NC - 1) % FF_NST) * FF_STAGE), gb, acc);
+    const uint32_t a1 = a1lane + (uint32_t)((NC % FF_NST) * FF_STAGE), a2 = a2lane + (uint32_t)(((NC - 1) % FF_NST) * FF_STAGE);
+    ff_iter<OP, true, false>(a1, a2, a1, a2, 0u, dyb, acc, frag, gb, [&]() {}, [&](f32x4, f32x4, f32x4, f32x4) -> V { return gb; });
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(F0a), "+v"(F0b), "+v"(F1a), "+v"(F1b) : : "memory");  // (redundant tail batches and prefetches)
 
   // ---- epilogue: dx1 = acc + dres; LayerNorm-1 backward of this lane's token row ----
   const float mu = a.m1[row], rs = a.r1[row];

@@ -170,9 +170,10 @@ class HipBertMLM(torch.nn.Module):
         # Fused feed-forward block (csrc/ffn_fused.hip: LayerNorm-1 + FFN-up + GELU + FFN-down + residual + LayerNorm-2 in one
         # launch, its backward in another; the [T, I] intermediate stays on the chip between the two GEMMs): bf16 runs with the
         # fp32 residual stream at hidden size 384.  ffn_f16: its FORWARD operands are fp16 instead of bf16 (same MFMA rate, three
-        # more mantissa bits; gradients stay bf16).  SM_FUSED_FFN=0 / SM_FFN_F16=0 select the unfused kernels / bf16 operands.
+        # more mantissa bits; gradients stay bf16).  OPT-IN (SM_FUSED_FFN=1): measured LDS-read bound, not faster than the unfused
+        # launches at the bench shape (csrc/ffn_fused.hip header); SM_FFN_F16=0 selects bf16 operands.
         self.fused_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
-                          and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "1") != "0")
+                          and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "0") == "1")
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
