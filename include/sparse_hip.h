@@ -34,6 +34,9 @@ extern "C" {
 #define SM_ABI_VERSION 3
 #define SM_F32 0
 #define SM_BF16 1
+/* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
+ * sm_gemm_nt (A, B, C fp16; `preact` stays bf16, it is read by the backward), sm_sparse_head_fwd (t, E), sm_cast_weight*. */
+#define SM_F16 2
 
 #define SM_OK 0
 #define SM_ERR_INVALID (-1)
@@ -71,7 +74,8 @@ typedef struct sm_ragged {
  * input-gradient GEMM of their backward.  Epilogue order:
  *   v = acc + bias[n]; if (preact) preact[m,n] = v; if (act==1) v = gelu_erf(v);
  *   v = dropout(v); if (residual) v += residual[m,n];
- *   if (gelu_grad_of) v *= gelu'(gelu_grad_of[m,n]);  C[m,n] = v                     */
+ *   if (gelu_grad_of) v *= gelu'(gelu_grad_of[m,n]);  C[m,n] = v
+ * dtype SM_F16: A, B (and C unless out_f32) are fp16, `preact` is still written as bf16; forward only.          */
 typedef struct sm_epilogue {
   const float* bias;        /* [N] fp32 or NULL */
   int act;                  /* 0 none, 1 exact-erf GELU (hf:336) */
@@ -87,6 +91,8 @@ typedef struct sm_epilogue {
   const float* res_ln_rstd;
   const float* res_ln_gamma;
   const float* res_ln_beta;
+  void* gelu_out;           /* with gelu_grad_of: gelu(gelu_grad_of[m,n]) is written here as well ([M,N] (ldc) dtype, or NULL): the
+                               post-GELU operand of the FFN-down weight gradient when the forward did not keep it in this dtype */
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -168,7 +174,8 @@ int sm_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, long n, void
 /* fp32 residual stream (bf16 GEMM operands, fp32 pre-LayerNorm sums and LayerNorm outputs on the residual path):
  * x32 [rows,H] fp32 in; y (dtype) for the next GEMM and, when y32 != NULL, its fp32 copy for the next residual add */
 int sm_layernorm_fwd_res32(int dtype, const float* x32, const float* gamma, const float* beta, void* y, float* y32,
-                           float* mean, float* rstd, int rows, int H, float eps, void* stream);
+                           float* mean, float* rstd, int rows, int H, float eps,
+                           void* y_f16 /* NULL, or an fp16 copy of y: the operand of a forward GEMM that runs on SM_F16 */, void* stream);
 int sm_embed_fwd_res32(int dtype, const int64_t* ids, const void* word, const float* pos, const float* type0, const float* gamma,
                        const float* beta, void* z, void* y, float* y32, float* mean, float* rstd, int B, int S, int H, float eps,
                        const sm_dropout* drop, const sm_ragged* rag, void* stream);
@@ -212,7 +219,7 @@ int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const
 int sm_sparse_head_bwd_dt_ln(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E,
                              void* dft, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x,
                              const float* gamma, const float* mean, const float* rstd, const void* gelu_of,
-                             float* dgamma, float* dbeta, void* stream);
+                             float* dgamma, float* dbeta, int x_f32 /* 1: x (the LayerNorm input) is fp32 */, void* stream);
 
 /* ---- inference-free query encoder (scripts/model/sparse_encoders.py:121-127) ----------- */
 int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,

@@ -13,6 +13,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+// fp16: the FORWARD operand type of the precision-critical GEMMs of bf16 runs (SM_F16: same MFMA rate as bf16, 11 significant
+// bits instead of 8; gradients and everything the backward reads stay bf16 for the exponent range)
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // ---- error plumbing (host) -------------------------------------------------
 void sm_set_error(const char* fmt, ...);
@@ -39,9 +44,11 @@ static inline int sm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 x) { return (float)x; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float x) { return (f16)x; }
 
 // ---- wave (64-lane) reductions ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -8,6 +8,7 @@
 // LDS stage rows are 128 bytes of K (64 bf16 / 32 fp32), XOR-swizzled in 16-byte chunks
 // (chunk ^= row & 7) so ds_read_b128 fragment reads are bank-conflict free; two stages.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -24,6 +25,17 @@ template <> struct Mma<bf16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
   // NT operand fragment: 8 consecutive k of row `row` (k = 32*ks + 8*g + j)
+  __device__ static __forceinline__ Frag load_nt(const char* tile, int row, int ks, int g) {
+    const int chunk = ks * 4 + g;
+    return *reinterpret_cast<const Frag*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+  }
+};
+template <> struct Mma<f16> {
+  static constexpr int KSTEP = 32, BK = 64;
+  using Frag = f16x8;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
   __device__ static __forceinline__ Frag load_nt(const char* tile, int row, int ks, int g) {
     const int chunk = ks * 4 + g;
     return *reinterpret_cast<const Frag*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
@@ -148,6 +160,12 @@ template <> struct GlFrag<bf16> {
     return *reinterpret_cast<const bf16x8*>(st + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
   }
 };
+template <> struct GlFrag<f16> {
+  static constexpr int BK = 32, NS = 1;
+  __device__ static __forceinline__ f16x8 load(const char* st, int row, int ks, int g) {
+    return *reinterpret_cast<const f16x8*>(st + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
+  }
+};
 template <> struct GlFrag<float> {
   static constexpr int BK = 16, NS = 4;
   __device__ static __forceinline__ float load(const char* st, int row, int ks, int g) {
@@ -235,6 +253,16 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v
     for (int k = 0; k < 8; ++k) v[k] = k < nvalid ? (float)p[k] : 0.f;
   }
 }
+template <> __device__ __forceinline__ void load8<f16>(const f16* p, float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    const f16x8 x = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nvalid ? (float)p[k] : 0.f;
+  }
+}
 template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8], bool full, int nvalid) {
   if (full) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -257,6 +285,17 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&
     for (int k = 0; k < 8; ++k) if (k < nvalid) p[k] = (bf16)v[k];
   }
 }
+template <> __device__ __forceinline__ void store8<f16>(f16* p, const float (&v)[8], bool full, int nvalid) {
+  if (full) {
+    f16x8 x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (f16)v[k];
+    *reinterpret_cast<f16x8*>(p) = x;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < nvalid) p[k] = (f16)v[k];
+  }
+}
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], bool full, int nvalid) {
   if (full) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
@@ -276,6 +315,7 @@ struct EpiArgs {
   DropCfg drop;
   const void* residual;
   const void* gelu_grad_of;
+  void* gelu_out;    // with gelu_grad_of: gelu(gelu_grad_of) is written here too (the post-GELU tensor a weight gradient needs)
   int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
   const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // res32: residual = LayerNorm(residual) recomputed from its fp32 input
 };
@@ -307,9 +347,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
   float* sC = reinterpret_cast<float*>(smem);
-  T* preact = reinterpret_cast<T*>(e.preact);
+  // fp16 operands (SM_F16) are a forward-only format: what the backward reads back (the pre-activation copy) stays bf16
+  using TP = typename std::conditional<std::is_same<T, f16>::value, bf16, T>::type;
+  TP* preact = reinterpret_cast<TP*>(e.preact);
   const T* residual = reinterpret_cast<const T*>(e.residual);
   const T* ggo = reinterpret_cast<const T*>(e.gelu_grad_of);
+  T* gout = reinterpret_cast<T*>(e.gelu_out);
   const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
   const int col = n0 + c * 8;
   const bool full = e.vec_ok && col + 8 <= N;
@@ -339,7 +382,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
         const f32x4 hi = *reinterpret_cast<const f32x4*>(sC + rt * CS + c * 8 + 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = lo[k] + bv[k]; v[4 + k] = hi[k] + bv[4 + k]; }
-        if (preact) store8<T>(preact + off, v, full, N - col);
+        if (preact) store8<TP>(preact + off, v, full, N - col);
         if (e.act == 1) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = gelu_t<T>(v[k]);
@@ -373,6 +416,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
           load8<T>(ggo + off, xv, full, N - col);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
+          if (gout) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = gelu_t<T>(xv[k]);
+            store8<T>(gout + off, xv, full, N - col);
+          }
         }
         if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);
         else store8<T>(C + off, v, full, N - col);
@@ -1222,7 +1270,8 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
   }
 }
 
-template <bool LNB, int LMODE = 0>
+// F16: A and B hold fp16 (SM_F16; launched only with an fp32 C and no 16-bit epilogue tensor: the FFN-down forward)
+template <bool LNB, int LMODE = 0, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                          bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, LnBwdArgs ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1298,7 +1347,10 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 6; ++i) {
+        if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
     __builtin_amdgcn_sched_barrier(0);
     if (w >= 4) issue(k + 3);
   }
@@ -1371,6 +1423,11 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
           load8<bf16>(ggo + off, xv, true, 8);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_t<bf16>(xv[q]);
+          if (e.gelu_out) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = gelu_t<bf16>(xv[q]);
+            store8<bf16>(reinterpret_cast<bf16*>(e.gelu_out) + off, xv, true, 8);
+          }
         }
         if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, true, 8);
         else store8<bf16>(C + off, v, true, 8);
@@ -1389,6 +1446,8 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.drop = make_drop(epi ? &epi->drop : nullptr);
   e.residual = epi ? epi->residual : nullptr;
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
+  e.gelu_out = epi ? epi->gelu_out : nullptr;
+  SM_REQUIRE(!e.gelu_out || e.gelu_grad_of, "sm_gemm_nt: gelu_out needs gelu_grad_of");
   e.res32 = epi ? epi->residual_f32 : 0;
   e.out32 = epi ? epi->out_f32 : 0;
   e.rl_mean = epi ? epi->res_ln_mean : nullptr;
@@ -1402,17 +1461,21 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.xcd = xcd_on;
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
-             ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0);
+             ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
   constexpr int nt192 = 1;
+  constexpr bool is_f16 = std::is_same<T, f16>::value;
+  // fp16 operands: the 192 x 384 kernel's epilogue types its 16-bit tensors bf16, so it takes fp16 only when there is none
+  const bool nt192_types_ok = !is_f16 || (e.out32 && !e.preact && !e.gelu_grad_of && (!e.residual || e.res32));
   if constexpr (sizeof(T) == 2) {
     constexpr int nt192_mink = 1024;
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
-    if (nt192 && nt192_shape && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+    if (nt192 && nt192_shape && nt192_types_ok && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
-      (void)hipFuncSetAttribute((const void*)gemm_nt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
-      hipLaunchKernelGGL(gemm_nt192_kernel<false>, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+      auto kern = is_f16 ? gemm_nt192_kernel<false, 0, true> : gemm_nt192_kernel<false, 0, false>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
+      hipLaunchKernelGGL(kern, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                          M, N, K, e, LnBwdArgs{});
       return 0;
     }
@@ -1473,13 +1536,18 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
                           int K, const sm_epilogue* epi, void* stream) {
   SM_REQUIRE(M > 0 && N > 0 && K > 0, "sm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   SM_REQUIRE(K % 64 == 0, "sm_gemm_nt: K=%d must be a multiple of 64", K);
-  const int esz = dtype == SM_BF16 ? 2 : 4;
+  const int esz = (dtype == SM_BF16 || dtype == SM_F16) ? 2 : 4;
   SM_REQUIRE((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "sm_gemm_nt: lda/ldb rows must be 16-byte aligned");
   SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_nt: A/B must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SM_BF16) launch_gemm_nt<bf16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
-  else if (dtype == SM_F32) launch_gemm_nt<float>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
-  else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
+  int rc = 0;
+  if (dtype == SM_BF16) rc = launch_gemm_nt<bf16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else if (dtype == SM_F32) rc = launch_gemm_nt<float>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else if (dtype == SM_F16) {
+    SM_REQUIRE(!epi || (!epi->gelu_grad_of && (!epi->residual || epi->residual_f32)), "sm_gemm_nt: fp16 operands are a forward format (no gelu_grad_of, residual only as fp32)");
+    rc = launch_gemm_nt<f16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  } else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
+  if (rc != 0) return rc;
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -1562,7 +1630,7 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_fwd: empty problem");
   SM_REQUIRE(H % 64 == 0, "sm_sparse_head_fwd: H=%d must be a multiple of 64", H);
   SM_REQUIRE(S <= 65535, "sm_sparse_head_fwd: S too large for u16 argmax");
-  SM_REQUIRE(dtype == SM_BF16 || dtype == SM_F32, "sm_sparse_head_fwd: bad dtype %d", dtype);
+  SM_REQUIRE(dtype == SM_BF16 || dtype == SM_F32 || dtype == SM_F16, "sm_sparse_head_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   {
     int r = sm_head_fwd_vs_try(dtype, t, E, bias, mask, rep, argmax, B, S, H, V, use_l0, rag, scratch, st);
@@ -1582,6 +1650,9 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
     if (dtype == SM_BF16)
       hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax,
                          B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
+    else if (dtype == SM_F16)
+      hipLaunchKernelGGL(sparse_head_fwd_kernel<f16>, grid, dim3(NTHREADS), 0, st, (const f16*)t, (const f16*)E, bias, mask, rep, argmax,
+                         B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
     else
       hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax,
                          B, 128, H, V, use_l0, xcd_on, rag->doc_off, rag->blk_doc, rag->rows, pk);
@@ -1598,6 +1669,9 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
   dim3 grid(sm_cdiv(V, BN), (mtiles + 8 * HEAD_MG - 1) / (8 * HEAD_MG) * (8 * HEAD_MG));
   if (dtype == SM_BF16)
     hipLaunchKernelGGL(sparse_head_fwd_kernel<bf16>, grid, dim3(NTHREADS), 0, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, B, S, H, V,
+                       use_l0, xcd_on, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, (unsigned long long*)nullptr);
+  else if (dtype == SM_F16)
+    hipLaunchKernelGGL(sparse_head_fwd_kernel<f16>, grid, dim3(NTHREADS), 0, st, (const f16*)t, (const f16*)E, bias, mask, rep, argmax, B, S, H, V,
                        use_l0, xcd_on, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, (unsigned long long*)nullptr);
   else
     hipLaunchKernelGGL(sparse_head_fwd_kernel<float>, grid, dim3(NTHREADS), 0, st, (const float*)t, (const float*)E, bias, mask, rep, argmax, B, S, H, V,
@@ -2033,13 +2107,13 @@ int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const 
 // the fused form of the dt half: LayerNorm' and GELU' of the head transform in the epilogue (1 = shape not eligible)
 int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dft,
                          int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x, const float* gamma,
-                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, hipStream_t st) {
+                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, int x_f32, hipStream_t st) {
   const long T = rag ? rag->rows : (long)B * S;
   if (dtype != SM_BF16 || H != DT_C || V % 2 != 0 || ((uintptr_t)E % 16) != 0 || !(rag || S % 16 == 0)) return 1;
   if ((((uintptr_t)x | (uintptr_t)gelu_of | (uintptr_t)dft | (uintptr_t)gamma) % 16) != 0) return 1;
   LnBwdArgs ln{};
   ln.x = (const bf16*)x;
-  ln.x32 = 0;
+  ln.x32 = x_f32;
   ln.gamma = gamma;
   ln.mean = mean;
   ln.rstd = rstd;

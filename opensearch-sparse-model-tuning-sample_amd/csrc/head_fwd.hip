@@ -128,7 +128,13 @@ __device__ unsigned long long vs_stamps[8 * 2048];
 #define VS_STAMP(S, K)
 #endif
 
-template <int H>
+// F16: t and E hold fp16 instead of bf16 (SM_F16: same rate, 3 more mantissa bits; every other byte of the kernel moves 16-bit words untyped)
+template <bool F16> __device__ __forceinline__ f32x16 vs_mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int H, bool F16>
 __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
     const bf16* __restrict__ Tn, const bf16* __restrict__ E, const float* __restrict__ bias, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ info, float* __restrict__ rep, uint16_t* __restrict__ argmax, int V, int use_l0, int rows,
@@ -420,9 +426,9 @@ __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
         f32x16 zero;
 #pragma unroll
         for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[0], zero, 0, 0, 0);
+        acc = vs_mma<F16>(a[0], fb[0], zero);
       } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], fb[ks], acc, 0, 0, 0);
+        acc = vs_mma<F16>(a[ks % D], fb[ks], acc);
       }
       if constexpr (ks == BAR_KS && !FIRST) {
         // barrier(s): every read of stage s - 1 has returned (its MFMAs were issued in the previous step); afterwards stage
@@ -494,10 +500,10 @@ __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
 // S <= 256: the position of a maximum takes the low 8 mantissa bits of its value (near-ties inside 2^-15 go to the lower
 // position); longer documents take the generic kernel of gemm.hip, which compares exactly
 bool vs_eligible(int dtype, int H, int S, const void* t, const void* E) {
-  return dtype == SM_BF16 && (H == 128 || H == 256 || H == 384) && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
+  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 128 || H == 256 || H == 384) && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
 }
 
-template <int H>
+template <int H, bool F16>
 int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* mask, float* rep, uint16_t* argmax, int B, int S, int V,
               int use_l0, const sm_ragged* rag, uint32_t* info, hipStream_t st) {
   using C = VsCfg<H>;
@@ -507,7 +513,7 @@ int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* ma
   while ((int)idx_mask < S - 1) idx_mask = idx_mask * 2 + 1;
   hipLaunchKernelGGL(vs_blkinfo_kernel, dim3(sm_cdiv(nblk, 256)), dim3(256), 0, st, rag ? rag->blk_doc : nullptr, rag ? rag->pos_ids : nullptr,
                      mask, S, nblk, info);
-  auto kern = sparse_head_fwd_vs_kernel<H>;
+  auto kern = sparse_head_fwd_vs_kernel<H, F16>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
   hipLaunchKernelGGL(kern, dim3(sm_cdiv(V, 128)), dim3(512), C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, (const uint32_t*)info, rep,
                      argmax, V, use_l0, rows, idx_mask);
@@ -526,11 +532,14 @@ int sm_head_fwd_vs_try(int dtype, const void* t, const void* E, const float* bia
   else SM_REQUIRE(S % 16 == 0, "sm_sparse_head_fwd: S=%d must be a multiple of 16", S);
   SM_REQUIRE(scratch != nullptr && B < (1 << 20), "sm_sparse_head_fwd: scratch (sm_sparse_head_fwd_scratch_bytes) required, B < 2^20");
   uint32_t* info = reinterpret_cast<uint32_t*>(scratch);
+#define VS_GO(HH) (dtype == SM_F16 ? vs_launch<HH, true>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, info, st) \
+                                  : vs_launch<HH, false>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, info, st))
   switch (H) {
-    case 128: return vs_launch<128>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, info, st);
-    case 256: return vs_launch<256>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, info, st);
-    default: return vs_launch<384>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, info, st);
+    case 128: return VS_GO(128);
+    case 256: return VS_GO(256);
+    default: return VS_GO(384);
   }
+#undef VS_GO
 }
 #ifdef VS_EXP_STAMP
 extern "C" int sm_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vs_stamps), sizeof(vs_stamps)); }

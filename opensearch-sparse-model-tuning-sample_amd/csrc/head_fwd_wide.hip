@@ -101,7 +101,13 @@ struct VsMeta {
 };
 
 
-template <int H, bool RAG>
+template <bool F16> __device__ __forceinline__ f32x16 vs_mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// F16: t and E hold fp16 instead of bf16 (SM_F16)
+template <int H, bool RAG, bool F16>
 __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_kernel(
     const bf16* __restrict__ Tn, const bf16* __restrict__ E, const float* __restrict__ bias, const uint8_t* __restrict__ mask,
     float* __restrict__ rep, uint16_t* __restrict__ argmax, int S, int V, int use_l0, const int32_t* __restrict__ blk_doc,
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
     vs_static_for<0, KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
       vs_wait_frag<D - 1>(a[ks % D]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], fb[ks], acc, 0, 0, 0);
+      acc = vs_mma<F16>(a[ks % D], fb[ks], acc);
       if constexpr (ks == BAR_KS && !FIRST) {
         // barrier(s): every read of stage s - 1 has returned (its MFMAs were issued in the previous step); afterwards stage
         // s + 1 is in LDS and the loaders refill the slot of stage s - 1
@@ -445,11 +451,11 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
 
 // scratch bytes the (dtype, shape, layout) combination needs from the caller: the vocabulary-stationary bf16 kernel needs none
 bool vs_eligible(int dtype, int H, int S, const void* t, const void* E) {
-  return dtype == SM_BF16 && (H == 512 || H == 768) && S <= 256 &&
+  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 512 || H == 768) && S <= 256 &&
          ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
 }
 
-template <int H>
+template <int H, bool F16>
 int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* mask, float* rep, uint16_t* argmax, int B, int S, int V,
               int use_l0, const sm_ragged* rag, hipStream_t st) {
   using C = VsCfg<H>;
@@ -459,12 +465,12 @@ int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* ma
   uint32_t idx_mask = 15u;
   while ((int)idx_mask < S - 1) idx_mask = idx_mask * 2 + 1;
   if (rag) {
-    auto kern = sparse_head_fwd_vs_kernel<H, true>;
+    auto kern = sparse_head_fwd_vs_kernel<H, true, F16>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     hipLaunchKernelGGL(kern, grid, block, C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, S, V, use_l0, rag->blk_doc,
                        rag->pos_ids, rows, idx_mask);
   } else {
-    auto kern = sparse_head_fwd_vs_kernel<H, false>;
+    auto kern = sparse_head_fwd_vs_kernel<H, false, F16>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     hipLaunchKernelGGL(kern, grid, block, C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, S, V, use_l0,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, rows, idx_mask);
@@ -481,9 +487,12 @@ int sm_head_fwd_wide_try(int dtype, const void* t, const void* E, const float* b
   if (!vs_eligible(dtype, H, S, t, E)) return 1;
   if (rag) SM_REQUIRE(rag->rows > 0 && rag->rows % 16 == 0, "sm_sparse_head_fwd: ragged layout needs rows %% 16 == 0");
   else SM_REQUIRE(S % 16 == 0, "sm_sparse_head_fwd: S=%d must be a multiple of 16", S);
+#define VS_GO(HH) (dtype == SM_F16 ? vs_launch<HH, true>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, st) \
+                                  : vs_launch<HH, false>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, st))
   switch (H) {
-    case 512: return vs_launch<512>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, st);
-    default: return vs_launch<768>(t, E, bias, mask, rep, argmax, B, S, V, use_l0, rag, st);
+    case 512: return VS_GO(512);
+    default: return VS_GO(768);
   }
+#undef VS_GO
 }
 bool sm_head_fwd_wide_takes(int dtype, int H, int S) { return vs_eligible(dtype, H, S, nullptr, nullptr); }

@@ -44,7 +44,7 @@ template <typename T, int NCH, typename TX = T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int H, float eps,
-                                                     float* __restrict__ y32 = nullptr) {
+                                                     float* __restrict__ y32 = nullptr, f16* __restrict__ y16 = nullptr) {
   const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4;
   const int nch = H >> 3;
   for (int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub; row < rows; row += gridDim.x * 16) {
@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * ga[k] + be[k];
         st8<T>(y + (size_t)row * H + c0, o);
         if (y32) st8<float>(y32 + (size_t)row * H + c0, o);
+        if (y16) {  // fp16 copy: the operand of a forward GEMM that runs on fp16 (SM_F16)
+          f16x8 h;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) h[k] = (f16)o[k];
+          *reinterpret_cast<f16x8*>(y16 + (size_t)row * H + c0) = h;
+        }
       }
     if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
   }
@@ -382,12 +388,12 @@ extern "C" int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, co
 }
 
 extern "C" int sm_layernorm_fwd_res32(int dtype, const float* x32, const float* gamma, const float* beta, void* y, float* y32,
-                                      float* mean, float* rstd, int rows, int H, float eps, void* stream) {
+                                      float* mean, float* rstd, int rows, int H, float eps, void* y_f16, void* stream) {
   SM_REQUIRE(rows > 0 && H % 64 == 0 && H <= 1024, "sm_layernorm_fwd_res32: rows=%d H=%d (H must be a multiple of 64, <= 1024)", rows, H);
   hipStream_t st = (hipStream_t)stream;
   SM_DISPATCH(dtype, "sm_layernorm_fwd_res32",
               LN_NCH(H, hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, float>), dim3(row_grid16(rows)), dim3(256), 0, st, x32, gamma, beta, (T*)y, mean, rstd,
-                                           rows, H, eps, y32)));
+                                           rows, H, eps, y32, (f16*)y_f16)));
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

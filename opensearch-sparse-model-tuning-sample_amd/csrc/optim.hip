@@ -180,6 +180,8 @@ extern "C" int sm_cast_weight(int dtype, const float* w, int rows, int cols, voi
     hipLaunchKernelGGL(cast_weight_kernel<bf16>, grid, dim3(256), 0, st, w, rows, cols, (bf16*)out, ld_out, (bf16*)out_t, ld_out_t);
   else if (dtype == SM_F32)
     hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, st, w, rows, cols, (float*)out, ld_out, (float*)out_t, ld_out_t);
+  else if (dtype == SM_F16)
+    hipLaunchKernelGGL(cast_weight_kernel<f16>, grid, dim3(256), 0, st, w, rows, cols, (f16*)out, ld_out, (f16*)out_t, ld_out_t);
   else SM_REQUIRE(false, "sm_cast_weight: bad dtype %d", dtype);
   SM_LAUNCH_CHECK();
   return SM_OK;
@@ -190,6 +192,7 @@ extern "C" int sm_cast_weights_multi(int dtype, const sm_cast_desc* descs_dev, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SM_BF16) hipLaunchKernelGGL(cast_weights_multi_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n);
   else if (dtype == SM_F32) hipLaunchKernelGGL(cast_weights_multi_kernel<float>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n);
+  else if (dtype == SM_F16) hipLaunchKernelGGL(cast_weights_multi_kernel<f16>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n);
   else SM_REQUIRE(false, "sm_cast_weights_multi: bad dtype %d", dtype);
   SM_LAUNCH_CHECK();
   return SM_OK;

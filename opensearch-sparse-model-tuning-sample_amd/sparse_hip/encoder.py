@@ -175,6 +175,16 @@ class HipBertMLM(torch.nn.Module):
         self.fused_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
                           and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "0") == "1")
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
+        # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
+        # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
+        # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
+        # feed-forward operands.  fwd_f16: head transform + decoder (every model; costs one fp16 copy of the [T, H] decoder input);
+        # ffn_fwd_f16: also the feed-forward GEMMs -- by default for deep models only (>= 10 layers: 12-layer bert-base is outside
+        # 1e-2 without it, the 6-layer model is inside), because the backward then has to re-create gelu(f1) in bf16 (one more
+        # [T, I] write).  SM_FWD_F16=0 / SM_FFN_FWD_F16=0|1 override.
+        self.fwd_f16 = compute_dtype == torch.bfloat16 and self.residual_fp32 and os.environ.get("SM_FWD_F16", "1") != "0"
+        deep = cfg.num_hidden_layers >= 10
+        self.ffn_fwd_f16 = self.fwd_f16 and not self.fused_ffn and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1"
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
         if H // cfg.num_attention_heads not in (32, 64):
@@ -339,6 +349,24 @@ class HipBertMLM(torch.nn.Module):
             self._cast_table = ops.CastTable(ent)  # raw pointers: rebuilt if the flat buffer or the staging set changes
             self._cast_key = (self.flat_param.data_ptr(), len(st))
         self._cast_table.run()
+        if self.fwd_f16:  # fp16 copies of the forward operands (a second table: one launch per storage type)
+            key16 = (self.flat_param.data_ptr(), self.ffn_fwd_f16)
+            if self._cast_table16 is None or self._cast_key16 != key16:
+                def buf16(k, shape):
+                    if k not in st:
+                        st[k] = torch.zeros(shape, dtype=torch.float16, device=dev)
+                    return st[k]
+                vpad = (V + 127) // 128 * 128
+                ent = [(self.view("bert.embeddings.word_embeddings.weight"), buf16("E16", (vpad, H)), None),
+                       (self.view("cls.predictions.transform.dense.weight"), buf16("t16", (H, H)), None)]
+                if self.ffn_fwd_f16:
+                    for l in range(cfg.num_hidden_layers):
+                        p = f"bert.encoder.layer.{l}."
+                        ent.append((self.view(p + "intermediate.dense.weight"), buf16(f"w1h{l}", (I, H)), None))
+                        ent.append((self.view(p + "output.dense.weight"), buf16(f"w2h{l}", (H, I)), None))
+                self._cast_table16 = ops.CastTable(ent)
+                self._cast_key16 = key16
+            self._cast_table16.run()
         if self.fused_ffn and cfg.num_hidden_layers > 0:
             nl = cfg.num_hidden_layers
             op = torch.float16 if self.ffn_f16 else torch.bfloat16
@@ -397,6 +425,7 @@ class HipBertMLM(torch.nn.Module):
         # input and statistics (res_ln), so the [T, H] fp32 LayerNorm outputs are never written
         x32 = emb[4] if r32 else None
         res_ln = None  # (mean, rstd, gamma, beta) of the LayerNorm whose fp32 input x32 currently holds
+        xh_last = None  # fp16 copy of the last layer's output (fwd_f16: operand of the head transform)
         if save:
             saved["emb"] = (z0, m0, r0)
         for l in range(cfg.num_hidden_layers):
@@ -421,26 +450,40 @@ class HipBertMLM(torch.nn.Module):
                     saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
                 x = x2
                 continue
+            f16_ffn = self.ffn_fwd_f16
+            x1h = None
             if r32:
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
-                x1, _, m1, r1 = ops.layernorm_fwd_res32(z1, g1, b1, eps, x.dtype, want_y32=False)
+                ln1 = ops.layernorm_fwd_res32(z1, g1, b1, eps, x.dtype, want_y32=False, want_y16=f16_ffn)
+                x1, _, m1, r1 = ln1[:4]
+                x1h = ln1[4] if f16_ffn else None
                 res1, res1_ln = z1, (m1, r1, g1, b1)
             else:
                 x1, m1, r1 = ops.layernorm_fwd(z1, v(p + "attention.output.LayerNorm.weight"),
                                                v(p + "attention.output.LayerNorm.bias"), eps)
                 res1, res1_ln = x1, None
             f1 = torch.empty((x1.shape[0], cfg.intermediate_size), dtype=x1.dtype, device=x1.device) if save else None
-            ga = ops.gemm_nt(x1, st[f"w1{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
-            z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
+            if f16_ffn:  # fp16 operands (x1, W1, gelu(f1), W2); f1 is kept in bf16 for the backward, which re-creates gelu(f1) in bf16
+                gah = ops.gemm_nt(x1h, st[f"w1h{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
+                z2 = ops.gemm_nt(gah, st[f"w2h{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=True, residual_ln=res1_ln)
+                ga = None
+            else:
+                ga = ops.gemm_nt(x1, st[f"w1{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
+                z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
             if r32:
                 g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
-                x2, _, m2, r2 = ops.layernorm_fwd_res32(z2, g2, b2, eps, x.dtype, want_y32=False)
+                last16 = self.fwd_f16 and l == cfg.num_hidden_layers - 1  # the head transform's fp16 operand
+                ln2 = ops.layernorm_fwd_res32(z2, g2, b2, eps, x.dtype, want_y32=False, want_y16=last16)
+                x2, _, m2, r2 = ln2[:4]
+                if last16:
+                    xh_last = ln2[4]
                 x32, res_ln = z2, (m2, r2, g2, b2)
             else:
                 x2, m2, r2 = ops.layernorm_fwd(z2, v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias"), eps)
             if save:
                 saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2))
             x = x2
+        self._x_last_f16 = xh_last
         return x, saved
 
     def hidden_states(self, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
@@ -581,10 +624,21 @@ class _EncodeFn(torch.autograd.Function):
         v, st = model.view, model._staged
         c = "cls.predictions."
         ft = torch.empty_like(x) if need_grad else None
-        gt = ops.gemm_nt(x, st["t"], bias=v(c + "transform.dense.bias"), act=1, preact=ft)
-        tn, mt, rt = ops.layernorm_fwd(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
-                                       cfg.layer_norm_eps)
-        rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
+        if model.fwd_f16:
+            # fp16 operands for the transform GEMM (when the last layer left an fp16 copy of its output) and for the decoder GEMM
+            # of the fused head; gelu(transform) stays fp32 between the GEMM epilogue and its LayerNorm
+            xh = model._x_last_f16
+            gt = ops.gemm_nt(xh if xh is not None else x, st["t16"] if xh is not None else st["t"], bias=v(c + "transform.dense.bias"),
+                             act=1, preact=ft, out_f32=True)
+            tn, _, mt, rt, tn16 = ops.layernorm_fwd_res32(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
+                                                          cfg.layer_norm_eps, x.dtype, want_y32=False, want_y16=True)
+            rep, argmax = ops.sparse_head_fwd(tn16, st["E16"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
+            del tn16
+        else:
+            gt = ops.gemm_nt(x, st["t"], bias=v(c + "transform.dense.bias"), act=1, preact=ft)
+            tn, mt, rt = ops.layernorm_fwd(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
+                                           cfg.layer_norm_eps)
+            rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
         if prune_ratio is not None:
             ops.prune_rows(rep, prune_ratio)
         if model._argmax_log is not None:  # test hook: which position each (doc, vocab) max came from
@@ -655,7 +709,7 @@ class _EncodeFn(torch.autograd.Function):
                                               d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
             fused = None
-            if ga is None:  # the forward ran the fused block: its backward in one launch (dF1 and gelu(f1) come out for the weight gradients)
+            if ga is None and model.fused_ffn:  # the forward ran the fused block: its backward in one launch (dF1 and gelu(f1) come out for the weight gradients)
                 fb = ops.ffn_bwd(a2, dz2, f1, st[f"w2T{l}"], st["ffn_w1tp"][l], z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                  d_h1, g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
                                  want_drop=d_h1 is not None)
@@ -666,8 +720,13 @@ class _EncodeFn(torch.autograd.Function):
                 wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
                 wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
             else:
-                wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
+                if ga is not None:
+                    wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
+                else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
+                    ga = torch.empty_like(f1)
+                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga)
+                    wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
                 wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
                 # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
                 # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
@@ -726,5 +785,8 @@ HipBertMLM._layer_hook = None
 HipBertMLM._dropout_without_grad = False
 HipBertMLM._cast_table = None
 HipBertMLM._cast_key = None
+HipBertMLM._cast_table16 = None
+HipBertMLM._cast_key16 = None
+HipBertMLM._x_last_f16 = None
 HipBertMLM._wgrad = None
 HipBertMLM._argmax_log = None

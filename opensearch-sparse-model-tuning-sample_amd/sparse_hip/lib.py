@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
-SM_F32, SM_BF16 = 0, 1
+SM_F32, SM_BF16, SM_F16 = 0, 1, 2
 
 
 class SmDropout(C.Structure):
@@ -36,6 +36,7 @@ class SmEpilogue(C.Structure):
         ("res_ln_rstd", C.c_void_p),
         ("res_ln_gamma", C.c_void_p),
         ("res_ln_beta", C.c_void_p),
+        ("gelu_out", C.c_void_p),  # with gelu_grad_of: gelu(gelu_grad_of) written here too
     ]
 
 
@@ -61,7 +62,7 @@ SIGNATURES = {
     "sm_ffn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
-    "sm_layernorm_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "sm_layernorm_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p],
     "sm_layernorm_bwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
     "sm_embed_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
     "sm_embed_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, C.POINTER(SmDropout), _rag, _p],
@@ -75,7 +76,7 @@ SIGNATURES = {
     "sm_sparse_head_fwd_scratch_bytes": [_i, _i, _i, _i, _i, _i],
     "sm_prune_rows": [_p, _i, _i, _f, _p],
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
-    "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],
     "sm_flops_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -138,6 +139,8 @@ def dtype_code(dt: torch.dtype) -> int:
         return SM_F32
     if dt == torch.bfloat16:
         return SM_BF16
+    if dt == torch.float16:  # forward operand format of bf16 runs where an entry point accepts it (include/sparse_hip.h)
+        return SM_F16
     raise SparseHipError(f"unsupported compute dtype {dt}")
 
 

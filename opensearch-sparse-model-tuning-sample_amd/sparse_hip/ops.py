@@ -40,10 +40,11 @@ def _rag_ref(rag):
 def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
             gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None,
-            out_f32: bool = False, residual_ln=None) -> Tensor:
+            out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables).  fp32 residual stream of a
     bf16 run: an fp32 `residual` is added in fp32 and `out_f32` writes the sum as fp32; residual_ln = (mean, rstd, gamma, beta):
-    `residual` is the fp32 INPUT of that LayerNorm and its output is recomputed on the fly."""
+    `residual` is the fp32 INPUT of that LayerNorm and its output is recomputed on the fly.  fp16 A / B (SM_F16: forward operands
+    of a bf16 run): `preact` must be bf16, `out` is fp16 unless out_f32.  gelu_out (with gelu_grad_of): receives gelu(gelu_grad_of)."""
     M, K = A.shape
     N = B.shape[0] if n is None else n
     assert B.shape[1] == K and A.dtype == B.dtype
@@ -52,7 +53,7 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
     res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
                        L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32),
-                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4))
+                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out))
     assert residual_ln is None or res32, "residual_ln needs an fp32 residual under a bf16 GEMM"
     L.call("sm_gemm_nt", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
            out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())
@@ -156,17 +157,19 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     return dx, dx_drop
 
 
-def layernorm_fwd_res32(x32: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype, want_y32: bool = True):
+def layernorm_fwd_res32(x32: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype, want_y32: bool = True,
+                        want_y16: bool = False):
     """fp32 residual stream: LayerNorm of fp32 rows -> y (compute dtype, the next GEMM's operand) and its fp32 copy (the next
-    residual add)"""
+    residual add); want_y16: additionally an fp16 copy (operand of a forward GEMM that runs on fp16), returned as a fifth value"""
     rows, H = x32.shape
     y = _new((rows, H), out_dtype, x32)
     y32 = _new((rows, H), torch.float32, x32) if want_y32 else None
+    y16 = _new((rows, H), torch.float16, x32) if want_y16 else None
     mean = _new((rows,), torch.float32, x32)
     rstd = _new((rows,), torch.float32, x32)
     L.call("sm_layernorm_fwd_res32", L.dtype_code(out_dtype), L.ptr(x32), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(y32),
-           L.ptr(mean), L.ptr(rstd), rows, H, float(eps), L.stream_ptr())
-    return y, y32, mean, rstd
+           L.ptr(mean), L.ptr(rstd), rows, H, float(eps), L.ptr(y16), L.stream_ptr())
+    return (y, y32, mean, rstd, y16) if want_y16 else (y, y32, mean, rstd)
 
 
 def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tensor, beta: Tensor, eps: float,
@@ -277,12 +280,13 @@ def sparse_head_bwd_dt_ln(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tens
     """dt half of the head backward fused with the backward of the transform's LayerNorm (input x) and GELU (input gelu_of):
     the gradient w.r.t. the transform's dense output, or None when the fused kernel does not take the shape"""
     H = x.shape[1]
-    if not (x.is_contiguous() and gelu_of.is_contiguous() and x.dtype == gelu_of.dtype == E.dtype):
+    x32 = x.dtype == torch.float32 and E.dtype != torch.float32  # the LayerNorm input kept in fp32 (fp16-forward mode)
+    if not (x.is_contiguous() and gelu_of.is_contiguous() and gelu_of.dtype == E.dtype and (x32 or x.dtype == E.dtype)):
         return None
-    dft = torch.empty_like(x)
-    ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(x.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
+    dft = torch.empty_like(gelu_of)
+    ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(E.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
                          L.ptr(dft), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), int(x32), L.stream_ptr())
     return dft if ok else None
 
 

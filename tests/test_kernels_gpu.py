@@ -633,3 +633,68 @@ def test_attention_ragged_layout(ops, dtype):
     (want * dctx).sum().backward()
     dqkv = ops.attention_bwd(dev(qkv, dtype), dev(mask), ctx, dev(dctx * vm[:, None], dtype), lse, B, S, A, None, rag)
     close(dqkv.float().cpu()[vm], xr.grad[vm], tol * 2, "dqkv")
+
+
+# ------------------------------------------------------------------ fp16 forward operands of a bf16 run (SM_F16)
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (6151, 1152, 384), (4100, 384, 1536), (49200, 768, 1024), (6200, 384, 1024)])
+def test_gemm_nt_fp16_operands(ops, M, N, K):
+    """fp16 A / B: C fp16 (or fp32 with out_f32), the pre-activation copy stays bf16; against the fp32 product of the fp16-rounded
+    operands: 2e-3 of the scale (the bf16 form of the same test asserts 2e-2)"""
+    h = torch.float16
+    A, B = q(rnd(M, K, seed=1, scale=0.5), h), q(rnd(N, K, seed=2, scale=0.5), h)
+    bias = rnd(N, seed=3)
+    ref = A @ B.t() + bias
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm_nt(dev(A, h), dev(B, h), bias=dev(bias), act=1, preact=pre)
+    assert out.dtype == h
+    close(pre, ref, 1e-2, "pre-activation (bf16 storage)")
+    close(out, O._gelu(ref), 2e-3, "gelu (fp16)")
+    res = rnd(M, N, seed=4)
+    out32 = ops.gemm_nt(dev(A, h), dev(B, h), bias=dev(bias), residual=dev(res), out_f32=True)
+    assert out32.dtype == torch.float32
+    close(out32, ref + res, 2e-3, "fp32 out + fp32 residual")
+
+
+def test_gemm_nt_gelu_out(ops):
+    """backward of FFN-down with the post-GELU tensor re-created in the same epilogue (hf:336 backward)"""
+    M, N, K = 4100, 1536, 384
+    bf = torch.bfloat16
+    A, B, x = q(rnd(M, K, seed=1, scale=0.3), bf), q(rnd(N, K, seed=2, scale=0.3), bf), q(rnd(M, N, seed=3), bf)
+    ga = torch.empty(M, N, dtype=bf, device="cuda")
+    out = ops.gemm_nt(dev(A, bf), dev(B, bf), gelu_grad_of=dev(x, bf), gelu_out=ga)
+    plain = ops.gemm_nt(dev(A, bf), dev(B, bf), gelu_grad_of=dev(x, bf))
+    assert torch.equal(out, plain)
+    close(ga, O._gelu(x), 1e-2, "gelu_out")
+
+
+@pytest.mark.parametrize("B,S,H,V,rag_mode", [(6, 64, 384, 3000, "dense"), (5, 128, 768, 2500, "dense"), (3, 512, 128, 1500, "dense")])
+def test_sparse_head_fwd_fp16_operands(ops, B, S, H, V, rag_mode):
+    """t, E in fp16 (vocabulary-stationary kernels at H = 384 / 768, the generic kernel at S = 512): against fp32 on the same
+    fp16-rounded operands 2e-3 of the scale, and bit-identical arg-max semantics (a position that attains the maximum)"""
+    h = torch.float16
+    t = q(rnd(B * S, H, seed=1), h)
+    E = q(rnd(V, H, seed=2, scale=0.3), h)
+    bias = rnd(V, seed=3, scale=0.5)
+    mask = torch.ones(B, S, dtype=torch.uint8)
+    for b in range(1, B):
+        mask[b, S - 3 * b - 2:] = 0
+    Epad = torch.zeros((V + 127) // 128 * 128, H)
+    Epad[:V] = E
+    rep, am = ops.sparse_head_fwd(dev(t, h), dev(Epad, h), dev(bias), dev(mask), B, S, V, False)
+    logits = (t @ E.t() + bias).view(B, S, V)
+    ref = O.sparse_activation(logits, mask.long(), False)
+    close(rep, ref, 2e-3, "rep (fp16 operands)")
+    pos = am.cpu().long() & 0xFFFF
+    masked = logits.masked_fill(mask[:, :, None] == 0, -float("inf"))
+    picked = torch.gather(masked, 1, pos[:, None, :]).squeeze(1)
+    live = ref > 0
+    assert (picked[live] >= masked.max(1).values[live] - 1e-2).all()
+
+
+def test_layernorm_res32_fp16_copy(ops):
+    rows, H = 1000, 768
+    x = rnd(rows, H, seed=1) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    y, y32, mean, rstd, y16 = ops.layernorm_fwd_res32(dev(x), dev(gamma), dev(beta), 1e-12, torch.bfloat16, want_y32=True, want_y16=True)
+    assert y16.dtype == torch.float16 and torch.equal(y16, y32.to(torch.float16)) and torch.equal(y, y32.to(torch.bfloat16))
+    close(y32, O._ln(x, gamma, beta, 1e-12), 1e-5, "fp32 output")
