@@ -28,8 +28,10 @@ from oracle import sparse_oracle as O  # noqa: E402
 
 SPECIAL = [0, 100, 101, 102, 103]
 V = 30522
-ELEMENTWISE_BF16 = 1e-2   # worst element, in units of (1 + |ref|): the north star's bf16 bound, met ELEMENTWISE with the default fp32
-                          # residual stream (measured 5.9e-3 at the c2 slice); all-bf16 storage: 1.4e-2 (own test below)
+ELEMENTWISE_BF16 = 1e-2   # worst element, in units of (1 + |ref|): the north star's bf16 bound, met ELEMENTWISE against the UNROUNDED
+                          # fp32 oracle with the defaults (fp32 residual stream, fp16 forward operands in the head and, for deep
+                          # models, the feed-forward): measured c1 3.5e-3, c2 4.0e-3, c3 4.0e-3, c4 6.5e-3, c5 6.3e-3;
+                          # all-bf16 storage: 1.5e-2 (own test below)
 FRACTION_INSIDE = 0.999   # of the elements are inside 1e-2 * (1 + |ref|)
 
 GRAD_NAMES = ("bert.embeddings.word_embeddings.weight", "bert.embeddings.LayerNorm.weight",
@@ -87,7 +89,8 @@ def _grad_report(bb, pr, names=GRAD_NAMES):
     return out
 
 
-BF16_GRAD_REL = 1.5e-1  # relative Frobenius error of a parameter gradient, bf16 storage, maxima routed as on the device
+BF16_GRAD_REL = 4e-2    # relative Frobenius error of a parameter gradient, bf16 storage, maxima routed as on the device (measured <= 1.6e-2)
+BF16_GRAD_REL_UNROUTED = 8e-2  # ... against the oracle's OWN arg-max routing (measured <= 3.8e-2; near-tied maxima that rounding resolves the other way move whole gradient rows)
 
 
 def _check_grads(dtype, bb, pr, what, pr_unrouted=None):
@@ -103,7 +106,7 @@ def _check_grads(dtype, bb, pr, what, pr_unrouted=None):
             print(f"[{what}] grad {n}: rel Frobenius {rel:.3e} (maxima routed as on the device){extra}")
             assert rel <= BF16_GRAD_REL, f"{what} grad {n}: relative Frobenius error {rel:.3e} > {BF16_GRAD_REL}"
             if unrouted is not None:  # near-tied maxima that bf16 rounding resolves the other way move whole gradient rows
-                assert unrouted[n][0] <= 1.5e-1, f"{what} grad {n}: relative Frobenius error {unrouted[n][0]:.3e} against the un-routed oracle"
+                assert unrouted[n][0] <= BF16_GRAD_REL_UNROUTED, f"{what} grad {n}: relative Frobenius error {unrouted[n][0]:.3e} against the un-routed oracle"
 
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",

@@ -51,10 +51,10 @@ def close(got, want, tol, what=""):
 
 def close_out(got, want, tol, what=""):
     """outputs the north star bounds (sparse activations, losses), ELEMENTWISE: |err| <= bound * (1 + |ref|).
-    fp32 storage: bound 1e-3.  bf16 (bf16 GEMM operands, fp32 residual stream): the models of THIS file are toys initialised
-    at 4x the HF standard deviation (std 0.08, so that a good share of the activations is positive), which amplifies rounding:
-    the tightest bound that holds for all of them is 2e-2 (worst measured 1.6e-2); at the BASELINE.json model shapes and
-    HF initialisation the bound 1e-2 itself is asserted on every element (tests/test_baseline_configs_gpu.py)."""
+    fp32 storage: bound 1e-3.  bf16: goldens G1-G8 come from a model initialised at 4x the HF standard deviation (std 0.08: a
+    STRESS case, it amplifies rounding) and are held to 2e-2; the north star's 1e-2 itself is asserted elementwise on golden G10
+    (the same reference functions on a model at the HF scale, test_g10_* below) and at the BASELINE.json model shapes against the
+    unrounded fp32 oracle (tests/test_baseline_configs_gpu.py)."""
     got, want = _prep(got, want, what)
     if tol >= 1e-2:
         tol = 2e-2
@@ -106,6 +106,62 @@ def test_g1_encode_matches_reference(dtype):
                 if n.endswith("attention.self.key.bias"):
                     continue  # mathematically zero gradient, pure rounding noise
                 close(m.backbone.view(n, grad=True), g[pre + n], TOL[dtype] * 2, "routed grad " + n)
+
+
+def hf_std_backbone(dtype):
+    from sparse_hip.encoder import HipBertMLM
+    g = load("g10_hfstd.npz")
+    bb = HipBertMLM(tiny_cfg(), compute_dtype=dtype, device="cuda", init_seed=None)
+    bb.load_hf_state_dict({k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith("sd/")})
+    return bb
+
+
+def close_out_strict(got, want, tol, what=""):
+    """|err| <= tol * (1 + |ref|) on every element: 1e-3 fp32 / 1e-2 bf16, the north star's numbers with nothing added"""
+    got, want = _prep(got, want, what)
+    excess = ((got - want).abs() - tol * (1 + want.abs())).max()
+    worst = float(((got - want).abs() / (1 + want.abs())).max())
+    assert float(excess) <= 0, f"{what}: worst |err| {worst:.3e} x (1+|ref|) > {tol}"
+    return worst
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_g10_hf_std_model_matches_reference_at_the_north_star_tolerance(dtype):
+    """golden G10: the reference's SparseModel._encode (sparse_encoders.py:107-119) and SparseModelTrainer.compute_loss
+    (trainer.py:81-143) on a model at the HF initialisation scale -- 1e-3 fp32 / 1e-2 bf16 ELEMENTWISE against the reference's
+    own fp32 CPU output (identical inputs: the unrounded fp32 checkpoint)"""
+    from scripts.model.sparse_encoders import SparseModel
+    g = load("g10_hfstd.npz")
+    idf = torch.tensor(load("g2_inf_free.npz")["idf_vector"])
+    ids, mask = torch.tensor(g["input_ids"]).cuda(), torch.tensor(g["attention_mask"]).cuda()
+    tol = TOL[dtype]
+    for l0 in (0, 1):
+        m = SparseModel(hf_std_backbone(dtype), idf=idf, use_l0=bool(l0))
+        m.train()
+        rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
+        worst = close_out_strict(rep, g[f"rep_l0{l0}"], tol, f"rep l0={l0}")
+        print(f"[g10 {dtype} l0={l0}] worst element {worst:.2e} x (1+|ref|) [bound {tol}]")
+        if l0 == 0:
+            m.backbone.zero_grad()
+            (rep * torch.tensor(g["upstream"]).cuda()).sum().backward()
+            for k in [k for k in g.files if k.startswith("grad/")]:
+                if k.endswith("attention.self.key.bias"):
+                    continue  # mathematically zero gradient, pure rounding noise
+                close(m.backbone.view(k[5:], grad=True), g[k], tol * 2, "routed grad " + k[5:])
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    model = SparseModel(hf_std_backbone(dtype), idf=idf, use_l0=False)
+    trainer = SparseModelTrainer(model_args=ModelArguments(model_name_or_path="unused", inf_free=True),
+                                 data_args=DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=10),
+                                 model=model, args=TrainingArguments(output_dir="/tmp/sm_test_out", logging_steps=1000),
+                                 loss_functions=[LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1, temperature=1.0)])
+    trainer.model.train()
+    trainer.state.global_step = 5
+    loss, out = trainer.compute_loss(trainer.model, _inputs(g, "cl"), return_outputs=True)
+    close_out_strict(loss, g["cl/loss"], tol, "loss")
+    close_out_strict(out["d_rep"], g["cl/d_rep"], tol, "d_rep")
+    assert torch.equal(out["q_rep"].cpu(), torch.tensor(g["cl/q_rep"]))
 
 
 def _make_trainer(dtype, case):
