@@ -143,6 +143,20 @@ int sm_ffn_bwd(const void* dy, const void* dres, const void* f1, const void* w2t
                const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
                void* dz1d, float* dgamma, float* dbeta, int T, int H, int I, void* stream);
 
+/* ---- the same block in PRODUCER / CONSUMER form (csrc/ffn_pc.hip: a pair of waves per 32 tokens, 32x32x16 MFMAs, weights
+ * staged fragment-major so that every LDS-DMA piece is one linear KiB).  Same contract as sm_ffn_fwd; its operands come from
+ * sm_ffn_pc_stage (e = ((c * 24 + piece) * 64 + lane) * 8 + j, lane = (kg, r) = (lane >> 5, lane & 31)):
+ *   w1f  [L][I/32][24][64][8]  W1[32c + r][16 piece + 8 kg + j]                                   forward GEMM 1, operand type
+ *   w2f  [L][I/32][24][64][8]  W2[32 (piece >> 1) + r][32c + kp(piece & 1, kg, j)]                forward GEMM 2, operand type
+ *   w2tf [L][I/32][24][64][8]  W2[16 piece + 8 kg + j][32c + r]                                    backward GEMM A, bf16
+ *   w1tf [L][I/32][24][64][8]  W1[32c + kp(piece & 1, kg, j)][32 (piece >> 1) + r]                backward GEMM B, bf16
+ *   kp(s, kg, j) = 16 s + (j & 3) + 8 (j >> 2) + 4 kg   (any output may be NULL) */
+int sm_ffn_pc_stage(int op_f16, const float* w1, const float* w2, long layer_stride, int layers, int H, int I, void* w1f, void* w2f,
+                    void* w2tf, void* w1tf, void* stream);
+int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, const float* ln1_b, float eps, const void* w1f, const float* bias1,
+                  const void* w2f, const float* bias2, const float* ln2_g, const float* ln2_b, const sm_dropout* drop, void* x1,
+                  float* m1, float* r1, void* f1, float* z2, void* x2, float* m2, float* r2, int T, int H, int I, void* stream);
+
 /* ---- LayerNorm (hf:106, :293, :351, :479) ---------------------------------------- */
 int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                      float* mean, float* rstd, int rows, int H, float eps, void* stream);

@@ -134,6 +134,34 @@ def ffn_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2t: Tensor, w1tp: T
     return (df1, ga, dz1, dz1d) if ok else None
 
 
+def ffn_pc_stage(w1_layer0: Tensor, w2_layer0: Tensor, layer_stride: int, layers: int, w1f: Optional[Tensor], w2f: Optional[Tensor],
+                 w2tf: Optional[Tensor], w1tf: Optional[Tensor]):
+    """fragment-major operand copies of every layer's FFN weights for the producer / consumer kernels (csrc/ffn_pc.hip), one launch"""
+    I, H = w1_layer0.shape
+    ref = w1f if w1f is not None else w2f
+    f16 = int(ref is not None and ref.dtype == torch.float16)
+    L.call("sm_ffn_pc_stage", f16, L.ptr(w1_layer0), L.ptr(w2_layer0), int(layer_stride), int(layers), H, I, L.ptr(w1f), L.ptr(w2f),
+           L.ptr(w2tf), L.ptr(w1tf), L.stream_ptr())
+
+
+def ffn_pc_fwd(z1: Tensor, ln1_g: Tensor, ln1_b: Tensor, eps: float, w1f: Tensor, bias1: Tensor, w2f: Tensor, bias2: Tensor,
+               ln2_g: Tensor, ln2_b: Tensor, drop: Optional[L.SmDropout], save_f1: bool):
+    """(x1, m1, r1, f1, z2, x2, m2, r2) of the fused block (producer / consumer kernel), or None when it does not take the shape"""
+    T, H = z1.shape
+    I = bias1.shape[0]
+    if z1.dtype != torch.float32 or not z1.is_contiguous() or H != 384 or I % 64 or T % 16:
+        return None
+    bf = torch.bfloat16
+    x1, x2 = _new((T, H), bf, z1), _new((T, H), bf, z1)
+    z2 = _new((T, H), torch.float32, z1)
+    m1, r1, m2, r2 = (_new((T,), torch.float32, z1) for _ in range(4))
+    f1 = _new((T, I), bf, z1) if save_f1 else None
+    ok = L.call_optional("sm_ffn_pc_fwd", int(w1f.dtype == torch.float16), L.ptr(z1), L.ptr(ln1_g), L.ptr(ln1_b), float(eps), L.ptr(w1f),
+                         L.ptr(bias1), L.ptr(w2f), L.ptr(bias2), L.ptr(ln2_g), L.ptr(ln2_b), _drop_ref(drop), L.ptr(x1), L.ptr(m1),
+                         L.ptr(r1), L.ptr(f1), L.ptr(z2), L.ptr(x2), L.ptr(m2), L.ptr(r2), T, H, I, L.stream_ptr())
+    return (x1, m1, r1, f1, z2, x2, m2, r2) if ok else None
+
+
 # ---------------------------------------------------------------- LayerNorm / embeddings
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
     rows, H = x.shape

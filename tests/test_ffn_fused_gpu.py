@@ -227,3 +227,68 @@ def test_encoder_layer_fused_matches_unfused(monkeypatch):
     # two bf16 paths against each other: rounding re-routes near-tied arg-max positions of the head, which moves whole rows of the
     # tied embedding gradient (the bound of the un-routed oracle comparison); the kernels themselves are held to 1e-2 above
     assert err <= 5e-3 and rel <= 1.2e-1
+
+
+# ------------------------------------------------------------------ producer / consumer form (csrc/ffn_pc.hip)
+def _kp(s, kg, j):
+    return 16 * s + (j & 3) + 8 * (j >> 2) + 4 * kg
+
+
+def _stage_pc(ops, w1, w2, op_dtype):
+    L, inter, _ = w1.shape
+    per = inter * H
+    stride = 2 * per + 64
+    flat = torch.empty(L * stride, device="cuda")
+    for l in range(L):
+        flat[l * stride: l * stride + per] = w1[l].reshape(-1)
+        flat[l * stride + per: l * stride + 2 * per] = w2[l].reshape(-1)
+    shape = (L, inter // 32, 24, 64, 8)
+    w1f, w2f = torch.empty(shape, dtype=op_dtype, device="cuda"), torch.empty(shape, dtype=op_dtype, device="cuda")
+    w2tf, w1tf = torch.empty(shape, dtype=torch.bfloat16, device="cuda"), torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+    ops.ffn_pc_stage(flat[:per].view(inter, H), flat[per:2 * per].view(H, inter), stride, L, w1f, w2f, w2tf, w1tf)
+    return w1f, w2f, w2tf, w1tf
+
+
+@pytest.mark.parametrize("op_dtype", [torch.float16, torch.bfloat16])
+def test_pc_stage_layouts(ops, op_dtype):
+    w1, w2 = _weights(L=2, seed=5, inter=128)
+    w1f, w2f, w2tf, w1tf = _stage_pc(ops, w1, w2, op_dtype)
+    torch.cuda.synchronize()
+    bf = torch.bfloat16
+    lane = torch.arange(64, device="cuda")
+    r, kg = lane & 31, lane >> 5
+    j = torch.arange(8, device="cuda")
+    for l in range(2):
+        for c in (0, 3):
+            for piece in (0, 5, 23):
+                k = 16 * piece + 8 * kg[:, None] + j[None, :]                              # [64, 8]
+                assert torch.equal(w1f[l, c, piece], w1[l][(32 * c + r)[:, None], k].to(op_dtype))
+                assert torch.equal(w2tf[l, c, piece], w2[l][k, (32 * c + r)[:, None]].to(bf))
+                n, s_ = piece >> 1, piece & 1
+                kp = 32 * c + 16 * s_ + (j[None, :] & 3) + 8 * (j[None, :] >> 2) + 4 * kg[:, None]
+                assert torch.equal(w2f[l, c, piece], w2[l][(32 * n + r)[:, None], kp].to(op_dtype))
+                assert torch.equal(w1tf[l, c, piece], w1[l][kp, (32 * n + r)[:, None]].to(bf))
+
+
+@pytest.mark.parametrize("op_dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("T", [16, 112, 128, 1008, 4096 + 48])
+def test_ffn_pc_forward_matches_torch(ops, op_dtype, tol, T):
+    w1, w2 = _weights(seed=T)
+    w1f, w2f, _, _ = _stage_pc(ops, w1, w2, op_dtype)
+    z1 = _rnd(T, H, seed=11, scale=1.5) + 0.3
+    g1, b1 = 1 + _rnd(H, seed=12, scale=0.1), _rnd(H, seed=13, scale=0.1)
+    g2, b2 = 1 + _rnd(H, seed=14, scale=0.1), _rnd(H, seed=15, scale=0.1)
+    bias1, bias2 = _rnd(I, seed=16, scale=0.1), _rnd(H, seed=17, scale=0.1)
+    out = ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, None, save_f1=True)
+    assert out is not None
+    torch.cuda.synchronize()
+    want = _reference_forward(z1, g1, b1, w1[0].to(op_dtype).float(), bias1, w2[0].to(op_dtype).float(), bias2, g2, b2)
+    names = ("x1", "m1", "r1", "f1", "z2", "x2", "m2", "r2")
+    errs = {n: _close(g_, w_, 1e-2 if n in ("x1", "f1", "x2") else tol, n) for n, g_, w_ in zip(names, out, want)}
+    print(f"[ffn pc fwd {op_dtype} T={T}] " + " ".join(f"{n} {e:.1e}" for n, e in errs.items()))
+    out2 = ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, None, save_f1=False)
+    assert out2[3] is None and torch.equal(out2[4], out[4]) and torch.equal(out2[5], out[5])
+    # repeated launches agree bit for bit (hand-over / ring races would show up here)
+    for _ in range(3):
+        again = ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, None, save_f1=True)
+        assert all(torch.equal(x, y) for x, y in zip(out, again))

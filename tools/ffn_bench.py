@@ -50,9 +50,14 @@ def main():
                 ga = ops.gemm_nt(x1, w1b, bias=bias1, act=1, preact=f1buf)
                 z2 = ops.gemm_nt(ga, w2b, bias=bias2, drop=drop, residual=z1, out_f32=True, residual_ln=(m1, r1, g1, b1))
                 return ops.layernorm_fwd_res32(z2, g2, b2, 1e-12, bf, want_y32=False)
-            tf, tu = timeit(fused), timeit(unfused)
+            shape = (1, I // 32, 24, 64, 8)
+            w1f, w2f = torch.empty(shape, dtype=op, device="cuda"), torch.empty(shape, dtype=op, device="cuda")
+            ops.ffn_pc_stage(flat[:I * H].view(I, H), flat[I * H:].view(H, I), 0, 1, w1f, w2f, None, None)
+            pc = lambda: ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, drop, save_f1=True)
+            tf, tu, tp = timeit(fused), timeit(unfused), timeit(pc)
             flop = 4.0 * T * H * I
-            print(f"forward  {'f16' if f16 else 'bf16'} operands, {T} rows: fused {tf:7.1f} us ({flop / tf / 1e6:5.0f} TFLOP/s)   "
+            print(f"forward  {'f16' if f16 else 'bf16'} operands, {T} rows: producer/consumer {tp:7.1f} us ({flop / tp / 1e6:5.0f} TFLOP/s)   "
+                  f"16-token fused {tf:7.1f} us ({flop / tf / 1e6:5.0f} TFLOP/s)   "
                   f"unfused sequence {tu:7.1f} us ({flop / tu / 1e6:5.0f} TFLOP/s)", flush=True)
             if not f16:
                 continue
