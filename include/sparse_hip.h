@@ -150,7 +150,10 @@ int sm_ffn_bwd(const void* dy, const void* dres, const void* f1, const void* w2t
  *   w2f  [L][I/32][24][64][8]  W2[32 (piece >> 1) + r][32c + kp(piece & 1, kg, j)]                forward GEMM 2, operand type
  *   w2tf [L][I/32][24][64][8]  W2[16 piece + 8 kg + j][32c + r]                                    backward GEMM A, bf16
  *   w1tf [L][I/32][24][64][8]  W1[32c + kp(piece & 1, kg, j)][32 (piece >> 1) + r]                backward GEMM B, bf16
- *   kp(s, kg, j) = 16 s + (j & 3) + 8 (j >> 2) + 4 kg   (any output may be NULL) */
+ *   kp(s, kg, j) = 16 s + (j & 3) + 8 (j >> 2) + 4 kg   (any output may be NULL)
+ * f1 (the GELU input, bf16) comes back tile-major, [4 ceil(T / 128)][I/32][64 lanes][16]: lane (kg, r) of tile (tt, c) holds
+ * token 32 tt + r, columns 32c + 8q + 4kg + k at element 4q + k.  The buffer must hold WHOLE 128-row blocks: the kernel stores
+ * the rows past T as well. */
 int sm_ffn_pc_stage(int op_f16, const float* w1, const float* w2, long layer_stride, int layers, int H, int I, void* w1f, void* w2f,
                     void* w2tf, void* w1tf, void* stream);
 int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, const float* ln1_b, float eps, const void* w1f, const float* bias1,

@@ -36,8 +36,10 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int PC_H = 384, PC_KS = PC_H / 16, PC_NT = PC_H / 32, PC_IC = 32, PC_TOK = 128;
 constexpr int PC_CHUNK = PC_IC * PC_H * 2;  // bytes of one chunk of either weight: 24 pieces of 1 KiB
-constexpr int PC_W1_OFF = 0, PC_W2_OFF = 3 * PC_CHUNK, PC_G_OFF = PC_W2_OFF + 2 * PC_CHUNK, PC_STAT_OFF = PC_G_OFF + 2 * 4 * 2048;
-constexpr int PC_BIAS_OFF = PC_STAT_OFF + PC_TOK * 8;
+constexpr int PC_W1_OFF = 0, PC_W2_OFF = 3 * PC_CHUNK, PC_G_OFF = PC_W2_OFF + 3 * PC_CHUNK;
+constexpr int PC_STAT_OFF = PC_G_OFF;                 // LayerNorm-1 statistics: written before P0, read right behind it (then the hand-over buffers own the bytes)
+constexpr int PC_VEC_OFF = PC_W1_OFF;                 // epilogue: bias2 | ln1_g | ln1_b | ln2_g | ln2_b (5 x 384 fp32) in the idle ring 1
+constexpr int PC_LDS = PC_G_OFF + 2 * 4 * 2048;       // 160 KiB exactly
 constexpr int PC_RING = 8, PC_D = 6;  // fragment registers / reads in flight of either role
 
 template <bool F16> struct PcOp;
@@ -72,6 +74,7 @@ __device__ __forceinline__ f32x4 pc_lds_read_f4(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+template <typename A, typename F> __device__ __forceinline__ void pc_touch(A& a, const F& f) { asm volatile("" : "+v"(a) : "v"(f)); }
 template <typename V> __device__ __forceinline__ void pc_lds_write(uint32_t addr, V v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -83,21 +86,29 @@ template <int I, int N, typename F> __device__ __forceinline__ void pc_static_fo
   }
 }
 
-// 24 MFMAs of one chunk: fragment k (1 KiB at `base` + 1024 k) against bfrag(k), PC_D reads in flight, `apply(k, frag)` issues the MFMA
-template <typename V, typename Apply>
-__device__ __forceinline__ void pc_stream24(uint32_t base, Apply&& apply) {
+// 24 MFMAs of one chunk: fragment k (1 KiB at `base` + 1024 k), PC_D reads in flight; `apply(k, frag)` issues the MFMA,
+// `hook(k)` runs behind it (the consumer puts one LDS-DMA piece behind every second MFMA: an LDS-DMA instruction blocks its wave
+// for ~80 cycles, during which the MFMA just issued and the partner wave keep the matrix pipe busy)
+template <typename V, typename Apply, typename Hook>
+__device__ __forceinline__ void pc_stream24(uint32_t base, Apply&& apply, Hook&& hook) {
   V frag[PC_RING];
-  pc_static_for<0, PC_D>([&](auto jc) {
+  pc_static_for<0, PC_D>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     frag[j % PC_RING] = pc_lds_read<V, j * 1024>(base);
   });
-  pc_static_for<0, 24>([&](auto kc) {
+  pc_static_for<0, 24>([&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value, j = k + PC_D;
+#ifdef PC_X_NOLDS  // timing experiments (tools/ffn_pc_stamps.py): results are wrong with any PC_X_* switch
+    if constexpr (j < 24) asm volatile("" : "=v"(frag[j % PC_RING]));
+#else
     if constexpr (j < 24) frag[j % PC_RING] = pc_lds_read<V, j * 1024>(base);
+#endif
     constexpr int ahead = 23 - k < PC_D ? 23 - k : PC_D;
     pc_wait_frag<ahead>(frag[k % PC_RING]);
     __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);  // VALU / SALU may float across; MFMA and LDS stay behind the wait
     apply(kc, frag[k % PC_RING]);
+    hook(kc);
+    __builtin_amdgcn_sched_barrier(0);  // what the hook put behind this MFMA stays there
   });
 }
 
@@ -120,6 +131,21 @@ struct FfnPcFwdArgs {
   int T, I;
 };
 
+// -DPC_STAMPS: shader-clock stamps of one pair of waves (tools/ffn_pc_stamps.py builds and reads them); nothing in a normal build
+#ifdef PC_STAMPS
+__device__ unsigned long long pc_stamps[2][128];
+#define PC_STAMP(ROLE, IDX) do { if (blockIdx.x == 3 && t == 1 && lane == 0 && (IDX) < 128) pc_stamps[ROLE][IDX] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PC_STAMP(ROLE, IDX)
+#endif
+
+template <int N> __device__ __forceinline__ float pc_lanes_sum(float v) {  // sum over N consecutive lanes (N = 8 or 16)
+#pragma unroll
+  for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+constexpr int PC_EROW = 192 * 4 + 16;  // epilogue staging: row stride of a [128 rows][192 columns] fp32 half tile (bank-spreading pad)
+
 template <bool F16>
 __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   using OP = PcOp<F16>;
@@ -128,15 +154,153 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tok = lane & 31, hh = lane >> 5;
   const int T = a.T, NC = a.I / PC_IC;
-  const int t = w & 3;                         // token group of this wave
-  const int m0 = blockIdx.x * PC_TOK + t * 32;
-  const bool rv = m0 + tok < T;                // this lane's token row exists (T % 16 == 0: a group may be half empty)
-  const int row = min(m0 + tok, T - 1);
+  const int t = w & 3;                         // token group of this wave (producer t and consumer t + 4 serve the same 32 tokens)
+  const int blk_row0 = blockIdx.x * PC_TOK;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)pc_smem;
+  const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
+  PC_STAMP(w >> 2, 0);
 
-  // bias1 -> LDS (plain stores, before any LDS-DMA is in flight)
-  for (int i = tid; i < a.I; i += 512) reinterpret_cast<float*>(pc_smem + PC_BIAS_OFF)[i] = a.bias1[i];
-  __syncthreads();
+  // ---------------------------------------------------------------- prologue: LayerNorm 1 by all eight waves, row-major and
+  // coalesced (16 lanes per row, 3 chunks of 8 columns per lane); x1 goes to memory in bf16 (operand of the W1 weight gradient)
+  // and, in the operand type, into LDS in the producers' B-fragment order ((group, k-step, lane) -> 16 bytes)
+  {
+    const int sl = lane & 15, sub = lane >> 4;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 32 + w * 4 + sub, grow = blk_row0 + rl;
+      const bool live = grow < T;
+      const float* zr = a.z1 + (size_t)min(grow, T - 1) * PC_H;
+      float v[3][8];
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8), hi = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[i][k] = lo[k]; v[i][4 + k] = hi[k]; s1 += lo[k] + hi[k]; }
+      }
+      const float mu = pc_lanes_sum<16>(s1) * (1.f / PC_H);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+      const float rs = rsqrtf(pc_lanes_sum<16>(q) * (1.f / PC_H) + a.eps);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ch = sl + 16 * i, c0 = ch * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = (v[i][k] - mu) * rs * g0[k] + e0[k];
+          o[4 + k] = (v[i][4 + k] - mu) * rs * g1[k] + e1[k];
+        }
+        if (live) {
+          bf16x8 xo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xo[k] = (bf16)o[k];
+          *reinterpret_cast<bf16x8*>(a.x1 + (size_t)grow * PC_H + c0) = xo;
+        }
+        // chunk ch = k-step ch >> 1, lane half ch & 1 of token rl & 31 of group rl >> 5
+        const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
+        pc_lds_write<V>(fa, OP::pack(o));
+      }
+      if (live && sl == 0) { a.m1[grow] = mu; a.r1[grow] = rs; }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // A: the B fragments of all four groups are in LDS
+  asm volatile("" ::: "memory");
+  PC_STAMP(w >> 2, 1);
+
+  // ---------------------------------------------------------------- epilogue row code, shared by the roles (defined here, run last)
+  // Row-major and coalesced like the prologue: 8 lanes per row, 3 chunks of 8 columns per lane and half; every wave owns rows
+  // w * 8 + sub of each of the two 64-row blocks.  z2 = dropout(acc + b2) + LN1(z1) (the fp32 residual, recomputed from z1 and the
+  // statistics the prologue stored) is written at once and kept in registers for LayerNorm 2.
+  float keep[2][2][3][8];
+  auto rows_half = [&](int half, auto halfc) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(halfc)::value;
+    (void)half;
+    const int sl = lane & 7, sub = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rl = it * 64 + w * 8 + sub, grow = blk_row0 + rl;
+      const bool live = grow < T;
+      const int gr = min(grow, T - 1);
+      const float mu1 = a.m1[gr], rs1 = a.r1[gr];
+      const uint32_t ra = lds0 + (uint32_t)(rl * PC_EROW);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ci = sl + 8 * i, c0 = HALF * 192 + ci * 8;
+        f32x4 lo = pc_lds_read_f4(ra + (uint32_t)(ci * 32)), hi = pc_lds_read_f4(ra + (uint32_t)(ci * 32 + 16));
+        const float* zr = a.z1 + (size_t)gr * PC_H + c0;
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(zr), z1v = *reinterpret_cast<const f32x4*>(zr + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias2 + c0), b1 = *reinterpret_cast<const f32x4*>(a.bias2 + c0 + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = lo[k] + b0[k]; v[4 + k] = hi[k] + b1[k]; }
+        if (a.drop.thresh16) drop_apply8(a.drop, (uint64_t)gr * PC_H + c0, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] += (z0[k] - mu1) * rs1 * g0[k] + e0[k];
+          v[4 + k] += (z1v[k] - mu1) * rs1 * g1[k] + e1[k];
+        }
+        if (live) {
+          float* zo = a.z2 + (size_t)grow * PC_H + c0;
+          *reinterpret_cast<f32x4*>(zo) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(zo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) keep[it][HALF][i][k] = v[k];
+      }
+    }
+  };
+  auto rows_ln2 = [&]() __attribute__((always_inline)) {
+    const int sl = lane & 7, sub = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rl = it * 64 + w * 8 + sub, grow = blk_row0 + rl;
+      const bool live = grow < T;
+      float s1 = 0.f;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s1 += keep[it][h2][i][k];
+      const float mu2 = pc_lanes_sum<8>(s1) * (1.f / PC_H);
+      float q = 0.f;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float d = keep[it][h2][i][k] - mu2; q += d * d; }
+      const float rs2 = rsqrtf(pc_lanes_sum<8>(q) * (1.f / PC_H) + a.eps);
+      if (live) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int c0 = h2 * 192 + (sl + 8 * i) * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0 + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              o[k] = (bf16)((keep[it][h2][i][k] - mu2) * rs2 * g0[k] + e0[k]);
+              o[4 + k] = (bf16)((keep[it][h2][i][4 + k] - mu2) * rs2 * g1[k] + e1[k]);
+            }
+            *reinterpret_cast<bf16x8*>(a.x2 + (size_t)grow * PC_H + c0) = o;
+          }
+        if (sl == 0) { a.m2[grow] = mu2; a.r2[grow] = rs2; }
+      }
+    }
+  };
 
   if (w >= 4) {
     // =================================================================== consumer
@@ -145,184 +309,146 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
     const char* w2f = reinterpret_cast<const char*>(a.w2f) + cw * 6 * 1024 + lane * 16;
     char* d1 = pc_smem + PC_W1_OFF + cw * 6 * 1024;
     char* d2 = pc_smem + PC_W2_OFF + cw * 6 * 1024;
-    auto issue6 = [&](const char* src, char* dst) {
+    auto dma = [&](const char* src, char* dst) __attribute__((always_inline)) { __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0); };
+    __builtin_amdgcn_s_barrier();  // B: the producers hold their fragments in registers, the rings may be filled
+    asm volatile("" ::: "memory");
+    // before the first step: W1 chunks 0, 1, 2 and W2 chunk 0 (this wave's six pieces of each)
 #pragma unroll
-      for (int u = 0; u < 6; ++u) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + u * 1024), (lds_void_t*)(dst + u * 1024), 16, 0, 0);
-    };
-    // W1 chunks 0, 1, 2 before the first step
-    issue6(w1f, d1);
-    issue6(w1f + (size_t)min(1, NC - 1) * PC_CHUNK, d1 + PC_CHUNK);
-    issue6(w1f + (size_t)min(2, NC - 1) * PC_CHUNK, d1 + 2 * PC_CHUNK);
+    for (int u = 0; u < 6; ++u) {
+      dma(w1f + u * 1024, d1 + u * 1024);
+      dma(w1f + (size_t)min(1, NC - 1) * PC_CHUNK + u * 1024, d1 + PC_CHUNK + u * 1024);
+      dma(w1f + (size_t)min(2, NC - 1) * PC_CHUNK + u * 1024, d1 + 2 * PC_CHUNK + u * 1024);
+      dma(w2f + u * 1024, d2 + u * 1024);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // P0: W1 chunks 0-2 are in LDS; the producers' LayerNorm statistics are in LDS
+    __builtin_amdgcn_s_barrier();  // P0: the prologue chunks are in LDS
     __builtin_amdgcn_s_barrier();  // P1: the producers have finished GEMM 1 of chunk 0 (ring-1 slot 0 may be refilled)
     asm volatile("" ::: "memory");
+    PC_STAMP(1, 2);
 
     f32x16 acc[PC_NT];
 #pragma unroll
     for (int n = 0; n < PC_NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
     // Step s (0 .. NC - 1): the producer computes GEMM 1 of chunk s + 1 (ring-1 slot (s + 1) % 3) and hands over g(s); this wave
-    // adds GEMM 2 of chunk s - 1 (ring-2 slot (s - 1) % 2, g(s - 1)) and refills ring-2 slot s % 2 with chunk s (read in step
-    // s + 1) and ring-1 slot s % 3 with chunk s + 3 (read in step s + 2).  Past the end the clamped index re-loads the last
-    // chunk into a slot nobody reads any more, so that every step has the same 12 vector-memory operations.
-    auto refill = [&](int st) {
-      issue6(w2f + (size_t)min(st, NC - 1) * PC_CHUNK, d2 + (st % 2) * PC_CHUNK);
-      issue6(w1f + (size_t)min(st + 3, NC - 1) * PC_CHUNK, d1 + (st % 3) * PC_CHUNK);
+    // adds GEMM 2 of chunk s - 1 (ring-2 slot (s - 1) % 3, g(s - 1)) and refills ring-2 slot (s + 1) % 3 with chunk s + 1 and
+    // ring-1 slot s % 3 with chunk s + 3 -- both read in step s + 2: two steps of lead.  An LDS-DMA instruction blocks its wave
+    // for 100-180 cycles here: nine of the pair's twelve pieces per step go out behind every second MFMA of this wave, three
+    // behind the producer's first MFMAs.  Past the end the clamped index re-loads the last chunk into a slot nobody reads any
+    // more, so that every step has the same vector-memory operations; at the end of step s everything issued BEFORE step s must
+    // have landed: vmcnt(9) here; the producer's three are older than the bias loads its next step begins with.
+    auto piece = [&](int st, int u) __attribute__((always_inline)) {  // u = 0 .. 11 of step st
+#ifdef PC_X_NODMA
+      return;
+#endif
+      if (u < 6) dma(w2f + (size_t)min(st + 1, NC - 1) * PC_CHUNK + u * 1024, d2 + ((st + 1) % 3) * PC_CHUNK + u * 1024);
+      else dma(w1f + (size_t)min(st + 3, NC - 1) * PC_CHUNK + (u - 6) * 1024, d1 + (st % 3) * PC_CHUNK + (u - 6) * 1024);
     };
-    auto gemm2 = [&](int c) {
+    auto gemm2 = [&](int c, int st) __attribute__((always_inline)) {  // st < 0: no refill
       const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
       V g0 = pc_lds_read<V, 0>(gb), g1 = pc_lds_read<V, 1024>(gb);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1) : : "memory");
-      pc_stream24<V>(lbase + PC_W2_OFF + (uint32_t)((c % 2) * PC_CHUNK), [&](auto kc, V fr) {
-        constexpr int k = decltype(kc)::value;
-        acc[k >> 1] = OP::mma(fr, (k & 1) ? g1 : g0, acc[k >> 1]);
-      });
+      pc_stream24<V>(lbase + PC_W2_OFF + (uint32_t)((c % 3) * PC_CHUNK),
+                     [&](auto kc, V fr) __attribute__((always_inline)) {
+                       constexpr int k = decltype(kc)::value;
+#ifdef PC_X_NOCMFMA
+                       pc_touch(acc[k >> 1], fr);
+#else
+                       acc[k >> 1] = OP::mma(fr, (k & 1) ? g1 : g0, acc[k >> 1]);
+#endif
+                     },
+                     [&](auto kc) __attribute__((always_inline)) {
+                       constexpr int k = decltype(kc)::value;
+                       if constexpr ((k & 1) && k < 18) {  // pieces 0 .. 8; the producer of the pair issues 9 .. 11
+                         if (st >= 0) piece(st, k >> 1);
+                       }
+                     });
     };
-    auto step_end = [&]() {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // everything but this step's ring-1 batch has landed
+    auto step_end = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // every batch of the previous steps has landed (nine pieces per step and consumer)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
-    refill(0);
+#pragma unroll
+    for (int u = 0; u < 9; ++u) piece(0, u);
     step_end();
     for (int st = 1; st < NC; ++st) {
-      refill(st);
-      gemm2(st - 1);
+      gemm2(st - 1, st);
+      PC_STAMP(1, 8 + 2 * st);
       step_end();
+      PC_STAMP(1, 9 + 2 * st);
     }
-    gemm2(NC - 1);
+    gemm2(NC - 1, -1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the redundant tail batches)
-
-    // ---- epilogue: z2 = dropout(acc + b2) + LN1(z1) (the fp32 residual, recomputed), LayerNorm 2 -> x2 ----
-    // lane (tok, hh) holds, of tile n, columns 32 n + 8 q + 4 hh + (0..3) in registers 4 q .. 4 q + 3
-    float mu1, rs1;
-    {
-      const float* st = reinterpret_cast<const float*>(pc_smem + PC_STAT_OFF) + (t * 32 + tok) * 2;
-      mu1 = st[0];
-      rs1 = st[1];
-    }
-    const float* zr = a.z1 + (size_t)row * PC_H + 4 * hh;
-    const uint32_t th8 = a.drop.thresh16 >> 8;
-    float ssum = 0.f;
+    PC_STAMP(1, 3);
+    // ---- hand the accumulators to the row-major epilogue, one half of the columns at a time: tile n, register 4 q + k of lane
+    //      (tok, hh) is column 32 n + 8 q + 4 hh + k of token 32 t + tok ----
+    const uint32_t rowa = lds0 + (uint32_t)((t * 32 + tok) * PC_EROW + 16 * hh);
+    pc_static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
+      constexpr int HALF = decltype(hc)::value;
+      __builtin_amdgcn_s_barrier();  // the staging area is free (rings idle / previous half consumed)
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int n = 0; n < PC_NT; ++n) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * n + 8 * q + 4 * hh;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias2 + c0);
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 32 * n + 8 * q);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), be = *reinterpret_cast<const f32x4*>(a.ln1_b + c0);
-        uint32_t h = 0xFFFFFFFFu;
-        if (th8) h = drop_hash4(a.drop, (uint32_t)(((uint64_t)row * PC_H + c0) >> 2));
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float x = acc[n][4 * q + k] + bb[k];
-          if (th8) x = ((h >> (8 * k)) & 0xFFu) >= th8 ? x * a.drop.scale : 0.f;
-          v[k] = x + ((zz[k] - mu1) * rs1 * ga[k] + be[k]);
-          ssum += v[k];
-          acc[n][4 * q + k] = v[k];
-        }
-        if (rv) *reinterpret_cast<f32x4*>(a.z2 + (size_t)row * PC_H + c0) = v;
-      }
-      if (n & 1) __builtin_amdgcn_sched_barrier(0);  // a few tiles' loads in flight at a time: the accumulators fill the register file
-    }
-    ssum += __shfl_xor(ssum, 32, 64);
-    const float mu2 = ssum * (1.f / PC_H);
-    float qs = 0.f;
-#pragma unroll
-    for (int n = 0; n < PC_NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float d = acc[n][r] - mu2; qs += d * d; }
-    qs += __shfl_xor(qs, 32, 64);
-    const float rs2 = rsqrtf(qs * (1.f / PC_H) + a.eps);
-    if (rv) {
-#pragma unroll
-      for (int n = 0; n < PC_NT; ++n) {
+      for (int n6 = 0; n6 < 6; ++n6)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c0 = 32 * n + 8 * q + 4 * hh;
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(a.ln2_g + c0), be = *reinterpret_cast<const f32x4*>(a.ln2_b + c0);
-          bf16x4 o;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = (bf16)((acc[n][4 * q + k] - mu2) * rs2 * ga[k] + be[k]);
-          *reinterpret_cast<bf16x4*>(a.x2 + (size_t)row * PC_H + c0) = o;
+          const f32x16& A = acc[HALF * 6 + n6];
+          pc_lds_write<f32x4>(rowa + (uint32_t)((32 * n6 + 8 * q) * 4), f32x4{A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]});
         }
-        if (n & 1) __builtin_amdgcn_sched_barrier(0);
-      }
-      if (hh == 0) { a.m2[row] = mu2; a.r2[row] = rs2; }
-    }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the half tile is staged
+      asm volatile("" ::: "memory");
+      PC_STAMP(1, 4 + HALF);
+      rows_half(HALF, hc);
+    });
+    PC_STAMP(1, 6);
+    rows_ln2();
+    PC_STAMP(1, 7);
     return;
   }
 
   // ===================================================================== producer
-  // LayerNorm 1 of this lane's token: columns 16 ks + 8 hh .. + 7 for every k-step (the B fragments of GEMM 1); three passes
-  // over the row (L1 / L2 hits after the first) instead of 192 fp32 values held in registers
   V xb[PC_KS];
   {
-    const float* zr = a.z1 + (size_t)row * PC_H + 8 * hh;
-    float s = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < PC_KS; ++ks) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(zr + 16 * ks), hi = *reinterpret_cast<const f32x4*>(zr + 16 * ks + 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) s += lo[k] + hi[k];
-    }
-    s += __shfl_xor(s, 32, 64);
-    const float mu1 = s * (1.f / PC_H);
-    float q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < PC_KS; ++ks) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(zr + 16 * ks), hi = *reinterpret_cast<const f32x4*>(zr + 16 * ks + 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const float d0 = lo[k] - mu1, d1 = hi[k] - mu1; q += d0 * d0 + d1 * d1; }
-    }
-    q += __shfl_xor(q, 32, 64);
-    const float rs1 = rsqrtf(q * (1.f / PC_H) + a.eps);
-#pragma unroll
-    for (int ks = 0; ks < PC_KS; ++ks) {
-      const int c0 = 16 * ks + 8 * hh;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(zr + 16 * ks), hi = *reinterpret_cast<const f32x4*>(zr + 16 * ks + 4);
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
-      float o[8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        o[k] = (lo[k] - mu1) * rs1 * g0[k] + e0[k];
-        o[4 + k] = (hi[k] - mu1) * rs1 * g1[k] + e1[k];
-      }
-      xb[ks] = OP::pack(o);
-      if (rv) {
-        bf16x8 xo;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xo[k] = (bf16)o[k];
-        *reinterpret_cast<bf16x8*>(a.x1 + (size_t)row * PC_H + c0) = xo;
-      }
-    }
-    if (hh == 0) {
-      float* st = reinterpret_cast<float*>(pc_smem + PC_STAT_OFF) + (t * 32 + tok) * 2;
-      st[0] = mu1;
-      st[1] = rs1;
-      if (rv) { a.m1[row] = mu1; a.r1[row] = rs1; }
-    }
+    const uint32_t fb = lbase + (uint32_t)(t * PC_KS * 1024);
+    pc_static_for<0, PC_KS>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(kc)::value;
+      xb[ks] = pc_lds_read<V, ks * 1024>(fb);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]), "+v"(xb[7]), "+v"(xb[8]), "+v"(xb[9]),
+                   "+v"(xb[10]), "+v"(xb[11]), "+v"(xb[12]), "+v"(xb[13]), "+v"(xb[14]), "+v"(xb[15]), "+v"(xb[16]), "+v"(xb[17]), "+v"(xb[18]),
+                   "+v"(xb[19]), "+v"(xb[20]), "+v"(xb[21]), "+v"(xb[22]), "+v"(xb[23])
+                 :
+                 : "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // P0
+  __builtin_amdgcn_s_barrier();  // B: the fragments are in registers, the rings may be filled
+  __builtin_amdgcn_s_barrier();  // P0: the prologue chunks are in LDS
   asm volatile("" ::: "memory");
 
-  const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
-  const uint32_t biasaddr = lds0 + PC_BIAS_OFF + (uint32_t)(hh * 16);
-  const uint32_t f1lane = (uint32_t)(((size_t)row * a.I + 4 * hh) * 2);  // byte offset of this lane's first f1 element
-  const bool stores = a.f1 != nullptr;
-  // accumulator initialised with the bias: register 4 q + k <-> chunk row 8 q + 4 hh + k
-  auto bias_init = [&](int c) -> f32x16 {
-    f32x4 b[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b[q] = pc_lds_read_f4(biasaddr + (uint32_t)((c * PC_IC + 8 * q) * 4));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
+  // f1 in the kernels' private TILE-MAJOR layout: (group of 32 tokens, chunk, lane) -> 16 bf16 = the lane's 16 accumulator
+  // registers, 32 contiguous bytes (the fused backward reads it back the same way)
+  bf16* const f1lane = a.f1 ? a.f1 + ((size_t)(blockIdx.x * 4 + t) * NC * 64 + lane) * 16 : nullptr;
+  // Accumulator initialised with the bias: register 4 q + k <-> chunk row 8 q + 4 hh + k (four 16-byte loads that every lane of a
+  // half shares: L1 hits).  The loads are issued in assembly one step ahead and awaited with a COUNTED vmcnt: left to the compiler
+  // the wait is vmcnt(0), which, vmcnt being in order, also drains the f1 stores and LDS-DMA pieces the previous step issued last
+  // (measured: 2.66 of a step's 2.88 kilo-cycles).  Vector-memory operations of a producer step, in issue order: 4 bias loads at
+  // gap 0, then the tail: [2 f1 stores,] 3 LDS-DMA pieces.
+  const float* const bias_lane = a.bias1 + 4 * hh;
+  const bool has_f1 = a.f1 != nullptr;
+  auto bias_issue = [&](int c, f32x4(&b)[4]) __attribute__((always_inline)) {
+    const float* bp = bias_lane + c * PC_IC;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[0]) : "v"(bp));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(b[1]) : "v"(bp));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(b[2]) : "v"(bp));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(b[3]) : "v"(bp));
+  };
+  auto bias_take = [&](f32x4(&b)[4], bool all) __attribute__((always_inline)) -> f32x16 {
+    // everything but the tail of the previous step has landed
+    if (all) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else if (has_f1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
     f32x16 x;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -330,57 +456,127 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
       for (int k = 0; k < 4; ++k) x[4 * q + k] = b[q][k];
     return x;
   };
-  auto gemm1 = [&](int c, f32x16& X) {
-    pc_stream24<V>(lbase + PC_W1_OFF + (uint32_t)((c % 3) * PC_CHUNK), [&](auto kc, V fr) {
-      constexpr int k = decltype(kc)::value;
-      X = OP::mma(fr, xb[k], X);
-    });
+  // this wave's share of the pair's LDS-DMA: pieces 9 .. 11 of a step = pieces 3 .. 5 of consumer-wave t's six of W1 chunk st + 3
+  const char* w1f_p = reinterpret_cast<const char*>(a.w1f) + t * 6 * 1024 + lane * 16;
+  char* d1_p = pc_smem + PC_W1_OFF + t * 6 * 1024;
+  auto piece_p = [&](int st, int u) __attribute__((always_inline)) {  // u = 9 .. 11
+#ifdef PC_X_NODMA
+    return;
+#endif
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(w1f_p + (size_t)min(st + 3, NC - 1) * PC_CHUNK + (u - 6) * 1024),
+                                     (lds_void_t*)(d1_p + (st % 3) * PC_CHUNK + (u - 6) * 1024), 16, 0, 0);
   };
-  // f1 store + GELU of one chunk's X^T tile -> the two B fragments of GEMM 2 (pure VALU apart from the f1 stores: free to float
-  // in between the MFMAs of the next chunk's GEMM 1); hand_over() writes them to this group's buffer AFTER that GEMM
-  auto finish = [&](int c, const f32x16& X, V& glo, V& ghi) {
-    if (stores && rv) {
-      bf16* p = a.f1 + c * PC_IC;
+  // GELU of the previous chunk's X^T tile, cut into pieces that sit BEHIND the MFMAs of the next chunk's GEMM 1 (one element per
+  // MFMA gap: ~9 vector instructions), then the two B fragments of GEMM 2 and the f1 store
+  // Element e runs in FOUR stages spread over gaps e .. e + 3 (x^2 and the inner polynomial step; the outer step and the product;
+  // exp2 and 1 + e; rcp and the final product), so that every gap carries four independent chains of two or three instructions
+  // instead of one of nine: a dependent vector instruction waits ~8 cycles (a transcendental more) for its operand.
+  float o[16], a_x2 = 0.f, a_p = 0.f, b_u = 0.f, c_d = 1.f;
+  V glo, ghi;
+  auto fin_piece = [&](auto kc, const f32x16& X, int c) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+#ifdef PC_X_NOGELU
+    if constexpr (k < 16) o[k] = X[k];
+#else
+    // (an empty volatile statement per result: the optimiser would otherwise sink the whole GELU to its first use, behind the
+    //  last MFMA -- sched_barrier only binds the machine scheduler)
+    if constexpr (k >= 3 && k <= 18) {
+      o[k - 3] = X[k - 3] * __builtin_amdgcn_rcpf(c_d);
+      asm volatile("" : "+v"(o[k - 3]));
+    }
+    if constexpr (k >= 2 && k <= 17) {
+      c_d = 1.0f + __builtin_amdgcn_exp2f(b_u);
+      asm volatile("" : "+v"(c_d));
+    }
+    if constexpr (k >= 1 && k <= 16) {
+      b_u = X[k - 1] * fmaf(a_p, a_x2, -2.30112135f);  // -(x (c0 + c1 x^2 + c2 x^4)) log2(e): gelu_sig of common.h
+      asm volatile("" : "+v"(b_u));
+    }
+    if constexpr (k < 16) {
+      a_x2 = fminf(X[k] * X[k], 81.0f);
+      a_p = fmaf(a_x2, 1.01426436e-3f, -1.06775740e-1f);
+      asm volatile("" : "+v"(a_x2), "+v"(a_p));
+    }
+#endif
+    if constexpr (k == 19) {
+      float lo8[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bf16x4 o;
+      for (int j = 0; j < 8; ++j) lo8[j] = o[j];
+      glo = OP::pack(lo8);
+      asm volatile("" : "+v"(glo));
+    } else if constexpr (k == 20) {
+      float hi8[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (bf16)X[4 * q + k];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p) + f1lane + q * 16) = o;
+      for (int j = 0; j < 8; ++j) hi8[j] = o[8 + j];
+      ghi = OP::pack(hi8);
+      asm volatile("" : "+v"(ghi));
+    } else if constexpr (k == 21 || k == 22) {
+      if (has_f1) {  // rows past T included: the f1 buffer is whole 128-row blocks (counted vmcnt: the stores are unconditional)
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16)X[(k - 21) * 8 + j];
+        *reinterpret_cast<bf16x8*>(f1lane + (size_t)c * (64 * 16) + (k - 21) * 8) = f;
       }
     }
-    float lo[8], hi[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { lo[k] = gelu_fast(X[k]); hi[k] = gelu_fast(X[8 + k]); }
-    glo = OP::pack(lo);
-    ghi = OP::pack(hi);
   };
-  auto hand_over = [&](int c, V glo, V ghi) {
+  auto hand_over = [&](int c) __attribute__((always_inline)) {
     const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
     pc_lds_write<V>(gb, glo);
     pc_lds_write<V>(gb + 1024, ghi);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the LDS-DMA pieces of the step BEFORE this one have landed (younger: this step's 4 bias loads and its tail)
+    if (has_f1) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
-  f32x16 X = bias_init(0);
-  gemm1(0, X);
+  f32x4 bn[4];
+  bias_issue(0, bn);
+  f32x16 X = bias_take(bn, true);
+  pc_stream24<V>(lbase + PC_W1_OFF,
+                 [&](auto kc, V fr) __attribute__((always_inline)) {
+                   constexpr int k = decltype(kc)::value;
+                   X = OP::mma(fr, xb[k], X);
+                 },
+                 [&](auto) __attribute__((always_inline)) {});
+  bias_issue(1, bn);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]));
   __builtin_amdgcn_s_barrier();  // P1
   asm volatile("" ::: "memory");
+  PC_STAMP(0, 2);
   for (int s = 0; s + 1 < NC; ++s) {
-    f32x16 Xn = bias_init(s + 1);
-    V glo, ghi;
-    finish(s, X, glo, ghi);
-    gemm1(s + 1, Xn);
-    hand_over(s, glo, ghi);
+    f32x16 Xn = bias_take(bn, false);  // chunk s + 1's bias, issued at gap 0 of step s - 1
+    pc_stream24<V>(lbase + PC_W1_OFF + (uint32_t)(((s + 1) % 3) * PC_CHUNK),
+                   [&](auto kc, V fr) __attribute__((always_inline)) {
+                     constexpr int k = decltype(kc)::value;
+#ifdef PC_X_NOPMFMA
+                     pc_touch(Xn, fr);
+#else
+                     Xn = OP::mma(fr, xb[k], Xn);
+#endif
+                   },
+                   [&](auto kc) __attribute__((always_inline)) {
+                     constexpr int k = decltype(kc)::value;
+                     if constexpr (k == 0) bias_issue(min(s + 2, NC - 1), bn);
+                     fin_piece(kc, X, s);
+                     if constexpr (k >= 21) piece_p(s, k - 12);  // behind the last pieces of the GELU: pieces 9 .. 11 of this step
+                   });
+    PC_STAMP(0, 10 + 2 * s);
+    hand_over(s);
+    PC_STAMP(0, 11 + 2 * s);
     X = Xn;
   }
-  {
-    V glo, ghi;
-    finish(NC - 1, X, glo, ghi);
-    hand_over(NC - 1, glo, ghi);
-  }
+  pc_static_for<0, 23>([&](auto kc) __attribute__((always_inline)) { fin_piece(kc, X, NC - 1); });
+  hand_over(NC - 1);
+  // ---- epilogue: the consumers stage their accumulators, every wave runs the row code ----
+  pc_static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rows_half(decltype(hc)::value, hc);
+  });
+  rows_ln2();
+  PC_STAMP(0, 7);
 }
 
 // ---- fragment-major weight staging for the kernels above (one launch for all layers: the layers of the flat parameter buffer
@@ -445,8 +641,7 @@ extern "C" int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, co
   a.z1 = z1; a.ln1_g = ln1_g; a.ln1_b = ln1_b; a.eps = eps; a.w1f = w1f; a.bias1 = bias1; a.w2f = w2f; a.bias2 = bias2;
   a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.drop = make_drop(drop); a.x1 = (bf16*)x1; a.m1 = m1; a.r1 = r1; a.f1 = (bf16*)f1; a.z2 = z2;
   a.x2 = (bf16*)x2; a.m2 = m2; a.r2 = r2; a.T = T; a.I = I;
-  const int lds = PC_BIAS_OFF + I * 4;
-  SM_REQUIRE(lds <= 160 * 1024, "sm_ffn_pc_fwd: I=%d does not fit the bias table in LDS", I);
+  const int lds = PC_LDS;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = sm_cdiv(T, PC_TOK);
   if (op_f16) {
@@ -459,3 +654,8 @@ extern "C" int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, co
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
+
+
+#ifdef PC_STAMPS
+extern "C" int sm_pc_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pc_stamps), sizeof(pc_stamps)); }
+#endif

@@ -155,7 +155,9 @@ def ffn_pc_fwd(z1: Tensor, ln1_g: Tensor, ln1_b: Tensor, eps: float, w1f: Tensor
     x1, x2 = _new((T, H), bf, z1), _new((T, H), bf, z1)
     z2 = _new((T, H), torch.float32, z1)
     m1, r1, m2, r2 = (_new((T,), torch.float32, z1) for _ in range(4))
-    f1 = _new((T, I), bf, z1) if save_f1 else None
+    # f1 comes back in the kernels' private tile-major layout [4 ceil(T / 128)][I / 32][64 lanes][16] (csrc/ffn_pc.hip): whole
+    # 128-row workgroup blocks, the kernel stores the rows past T too (its stores are counted, not predicated)
+    f1 = _new((4 * ((T + 127) // 128), I // 32, 64, 16), bf, z1) if save_f1 else None
     ok = L.call_optional("sm_ffn_pc_fwd", int(w1f.dtype == torch.float16), L.ptr(z1), L.ptr(ln1_g), L.ptr(ln1_b), float(eps), L.ptr(w1f),
                          L.ptr(bias1), L.ptr(w2f), L.ptr(bias2), L.ptr(ln2_g), L.ptr(ln2_b), _drop_ref(drop), L.ptr(x1), L.ptr(m1),
                          L.ptr(r1), L.ptr(f1), L.ptr(z2), L.ptr(x2), L.ptr(m2), L.ptr(r2), T, H, I, L.stream_ptr())
