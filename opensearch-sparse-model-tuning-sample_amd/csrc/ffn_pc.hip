@@ -360,18 +360,18 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
                      },
                      [&](auto kc) __attribute__((always_inline)) {
                        constexpr int k = decltype(kc)::value;
-                       if constexpr ((k & 1) && k < 18) {  // pieces 0 .. 8; the producer of the pair issues 9 .. 11
-                         if (st >= 0) piece(st, k >> 1);
+                       if constexpr (k & 1) {  // a piece behind every second MFMA: all twelve of the step (the producer wave is
+                         if (st >= 0) piece(st, k >> 1);  // the issue-bound one of the pair)
                        }
                      });
     };
     auto step_end = [&]() __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // every batch of the previous steps has landed (nine pieces per step and consumer)
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // every batch of the previous steps has landed (twelve pieces per step and consumer)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
 #pragma unroll
-    for (int u = 0; u < 9; ++u) piece(0, u);
+    for (int u = 0; u < 12; ++u) piece(0, u);
     step_end();
     for (int st = 1; st < NC; ++st) {
       gemm2(st - 1, st);
@@ -432,9 +432,8 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   bf16* const f1lane = a.f1 ? a.f1 + ((size_t)(blockIdx.x * 4 + t) * NC * 64 + lane) * 16 : nullptr;
   // Accumulator initialised with the bias: register 4 q + k <-> chunk row 8 q + 4 hh + k (four 16-byte loads that every lane of a
   // half shares: L1 hits).  The loads are issued in assembly one step ahead and awaited with a COUNTED vmcnt: left to the compiler
-  // the wait is vmcnt(0), which, vmcnt being in order, also drains the f1 stores and LDS-DMA pieces the previous step issued last
-  // (measured: 2.66 of a step's 2.88 kilo-cycles).  Vector-memory operations of a producer step, in issue order: 4 bias loads at
-  // gap 0, then the tail: [2 f1 stores,] 3 LDS-DMA pieces.
+  // the wait is vmcnt(0), which, vmcnt being in order, also drains the f1 stores the previous step issued last.  Vector-memory operations of a producer step, in issue order: 4 bias loads at
+  // gap 0, then the two f1 stores (training only).
   const float* const bias_lane = a.bias1 + 4 * hh;
   const bool has_f1 = a.f1 != nullptr;
   auto bias_issue = [&](int c, f32x4(&b)[4]) __attribute__((always_inline)) {
@@ -447,24 +446,14 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   auto bias_take = [&](f32x4(&b)[4], bool all) __attribute__((always_inline)) -> f32x16 {
     // everything but the tail of the previous step has landed
     if (all) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    else if (has_f1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else if (has_f1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
     f32x16 x;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[4 * q + k] = b[q][k];
     return x;
-  };
-  // this wave's share of the pair's LDS-DMA: pieces 9 .. 11 of a step = pieces 3 .. 5 of consumer-wave t's six of W1 chunk st + 3
-  const char* w1f_p = reinterpret_cast<const char*>(a.w1f) + t * 6 * 1024 + lane * 16;
-  char* d1_p = pc_smem + PC_W1_OFF + t * 6 * 1024;
-  auto piece_p = [&](int st, int u) __attribute__((always_inline)) {  // u = 9 .. 11
-#ifdef PC_X_NODMA
-    return;
-#endif
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(w1f_p + (size_t)min(st + 3, NC - 1) * PC_CHUNK + (u - 6) * 1024),
-                                     (lds_void_t*)(d1_p + (st % 3) * PC_CHUNK + (u - 6) * 1024), 16, 0, 0);
   };
   // GELU of the previous chunk's X^T tile, cut into pieces that sit BEHIND the MFMAs of the next chunk's GEMM 1 (one element per
   // MFMA gap: ~9 vector instructions), then the two B fragments of GEMM 2 and the f1 store
@@ -523,9 +512,7 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
     const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
     pc_lds_write<V>(gb, glo);
     pc_lds_write<V>(gb + 1024, ghi);
-    // the LDS-DMA pieces of the step BEFORE this one have landed (younger: this step's 4 bias loads and its tail)
-    if (has_f1) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -559,7 +546,6 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
                      constexpr int k = decltype(kc)::value;
                      if constexpr (k == 0) bias_issue(min(s + 2, NC - 1), bn);
                      fin_piece(kc, X, s);
-                     if constexpr (k >= 21) piece_p(s, k - 12);  // behind the last pieces of the GELU: pieces 9 .. 11 of this step
                    });
     PC_STAMP(0, 10 + 2 * s);
     hand_over(s);
