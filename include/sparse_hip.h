@@ -93,6 +93,8 @@ typedef struct sm_epilogue {
   const float* res_ln_beta;
   void* gelu_out;           /* with gelu_grad_of: gelu(gelu_grad_of[m,n]) is written here as well ([M,N] (ldc) dtype, or NULL): the
                                post-GELU operand of the FFN-down weight gradient when the forward did not keep it in this dtype */
+  int gelu_grad_tiled;      /* 1: gelu_grad_of is the tile-major f1 that sm_ffn_pc_fwd leaves ([4 ceil(M/128)][N/32][64][16], 16-bit
+                               dtypes, N % 32 == 0) instead of a row-major [M,N] tensor */
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

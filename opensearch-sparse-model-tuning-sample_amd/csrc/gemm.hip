@@ -316,9 +316,30 @@ struct EpiArgs {
   const void* residual;
   const void* gelu_grad_of;
   void* gelu_out;    // with gelu_grad_of: gelu(gelu_grad_of) is written here too (the post-GELU tensor a weight gradient needs)
+  int ggo_tiled;     // gelu_grad_of is the fused feed-forward's tile-major f1 (load_ggo8)
   int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
   const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // res32: residual = LayerNorm(residual) recomputed from its fp32 input
 };
+
+// gelu_grad_of as the producer / consumer feed-forward kernel leaves it (csrc/ffn_pc.hip, include/sparse_hip.h): tiles of 32 rows x
+// 32 columns, [row / 32][N / 32][64 lanes][16]; lane (kg, r) holds row r, columns 8 q + 4 kg + k at element 4 q + k.  Eight
+// consecutive columns (col % 8 == 0) of one row are two 8-byte pieces 1 KiB apart.
+template <typename T>
+__device__ __forceinline__ void load_ggo8(const T* ggo, bool tiled, size_t off, int row, int col, int N, float (&xv)[8], bool full, int nvalid) {
+  if (!tiled) {
+    load8<T>(ggo + off, xv, full, nvalid);
+    return;
+  }
+  const size_t tile = (size_t)(row >> 5) * (size_t)(N >> 5) + (size_t)(col >> 5);
+  const T* p = ggo + (tile * 64 + (row & 31)) * 16 + ((col & 31) >> 3) * 4;
+  typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+  const u16x4 lo = *reinterpret_cast<const u16x4*>(p), hi = *reinterpret_cast<const u16x4*>(p + 32 * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    xv[k] = to_f32<T>(__builtin_bit_cast(T, (uint16_t)lo[k]));
+    xv[4 + k] = to_f32<T>(__builtin_bit_cast(T, (uint16_t)hi[k]));
+  }
+}
 
 template <typename T, bool GLDS>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
@@ -413,7 +434,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
         }
         if (ggo) {
           float xv[8];
-          load8<T>(ggo + off, xv, full, N - col);
+          if constexpr (sizeof(T) == 2) load_ggo8<T>(ggo, e.ggo_tiled, off, row, col, N, xv, full, N - col);
+          else load8<T>(ggo + off, xv, full, N - col);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
           if (gout) {
@@ -1420,7 +1442,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
         }
         if (ggo) {
           float xv[8];
-          load8<bf16>(ggo + off, xv, true, 8);
+          load_ggo8<bf16>(ggo, e.ggo_tiled, off, row, col, N, xv, true, 8);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_t<bf16>(xv[q]);
           if (e.gelu_out) {
@@ -1448,6 +1470,9 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
   e.gelu_out = epi ? epi->gelu_out : nullptr;
   SM_REQUIRE(!e.gelu_out || e.gelu_grad_of, "sm_gemm_nt: gelu_out needs gelu_grad_of");
+  e.ggo_tiled = epi ? epi->gelu_grad_tiled : 0;
+  SM_REQUIRE(!e.ggo_tiled || (e.gelu_grad_of && sizeof(T) == 2 && N % 32 == 0 && ldc % 8 == 0),
+             "sm_gemm_nt: gelu_grad_tiled needs a 16-bit gelu_grad_of, N %% 32 == 0");
   e.res32 = epi ? epi->residual_f32 : 0;
   e.out32 = epi ? epi->out_f32 : 0;
   e.rl_mean = epi ? epi->res_ln_mean : nullptr;

@@ -175,6 +175,10 @@ class HipBertMLM(torch.nn.Module):
         self.fused_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
                           and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "0") == "1")
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
+        # pc_ffn: the FORWARD of the same block in producer / consumer form (csrc/ffn_pc.hip: 195-215 us against 250-265 us of the
+        # unfused launches at 43.9 k rows); the backward stays unfused and reads the kernel's tile-major f1 in the dF1 epilogue.
+        self.pc_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
+                       and cfg.intermediate_size >= 128 and not self.fused_ffn and os.environ.get("SM_PC_FFN", "1") == "1")
         # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
         # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
         # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
@@ -184,7 +188,8 @@ class HipBertMLM(torch.nn.Module):
         # [T, I] write).  SM_FWD_F16=0 / SM_FFN_FWD_F16=0|1 override.
         self.fwd_f16 = compute_dtype == torch.bfloat16 and self.residual_fp32 and os.environ.get("SM_FWD_F16", "1") != "0"
         deep = cfg.num_hidden_layers >= 10
-        self.ffn_fwd_f16 = self.fwd_f16 and not self.fused_ffn and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1"
+        self.ffn_fwd_f16 = (self.fwd_f16 and not self.fused_ffn and not self.pc_ffn
+                            and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1")
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
         if H // cfg.num_attention_heads not in (32, 64):
@@ -379,6 +384,17 @@ class HipBertMLM(torch.nn.Module):
                       - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
             ops.ffn_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
                           st["ffn_w1h"], st["ffn_w2p"], st["ffn_w1tp"])
+        if self.pc_ffn and cfg.num_hidden_layers > 0:
+            nl = cfg.num_hidden_layers
+            op = torch.float16 if self.ffn_f16 else torch.bfloat16
+            if "pc_w1f" not in st:
+                st["pc_w1f"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=op, device=dev)
+                st["pc_w2f"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=op, device=dev)
+            n0 = "bert.encoder.layer.0."
+            stride = (self._offsets["bert.encoder.layer.1.intermediate.dense.weight"][0]
+                      - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
+            ops.ffn_pc_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
+                             st["pc_w1f"], st["pc_w2f"], None, None)
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
@@ -446,6 +462,21 @@ class HipBertMLM(torch.nn.Module):
                     raise L.SparseHipError("fused feed-forward kernel declined a shape it was enabled for")
                 x1, m1, r1, f1, z2, x2, m2, r2 = fused
                 x32, res_ln = z2, (m2, r2, g2, b2)
+                if save:
+                    saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
+                x = x2
+                continue
+            if self.pc_ffn and z1.shape[0] % 16 == 0:
+                g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
+                g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
+                fused = ops.ffn_pc_fwd(z1, g1, b1, eps, st["pc_w1f"][l], v(p + "intermediate.dense.bias"), st["pc_w2f"][l],
+                                       v(p + "output.dense.bias"), g2, b2, d_h2, save_f1=save)
+                if fused is None:
+                    raise L.SparseHipError("fused feed-forward kernel declined a shape it was enabled for")
+                x1, m1, r1, f1, z2, x2, m2, r2 = fused  # f1 tile-major (4 dims): the backward's dF1 epilogue reads it that way
+                x32, res_ln = z2, (m2, r2, g2, b2)
+                if self.fwd_f16 and l == cfg.num_hidden_layers - 1:  # the head transform's fp16 operand
+                    xh_last = ops.layernorm_fwd_res32(z2, g2, b2, eps, x.dtype, want_y32=False, want_y16=True)[4]
                 if save:
                     saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
                 x = x2
@@ -724,8 +755,8 @@ class _EncodeFn(torch.autograd.Function):
                     wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
                     df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
                 else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
-                    ga = torch.empty_like(f1)
-                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga)
+                    ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
+                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)
                     wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
                 wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
                 # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel

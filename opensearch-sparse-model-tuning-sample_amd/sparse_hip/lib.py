@@ -37,6 +37,7 @@ class SmEpilogue(C.Structure):
         ("res_ln_gamma", C.c_void_p),
         ("res_ln_beta", C.c_void_p),
         ("gelu_out", C.c_void_p),  # with gelu_grad_of: gelu(gelu_grad_of) written here too
+        ("gelu_grad_tiled", C.c_int),  # gelu_grad_of is the tile-major f1 of sm_ffn_pc_fwd
     ]
 
 

@@ -40,11 +40,12 @@ def _rag_ref(rag):
 def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
             gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None,
-            out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None) -> Tensor:
+            out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None, gelu_grad_tiled: bool = False) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables).  fp32 residual stream of a
     bf16 run: an fp32 `residual` is added in fp32 and `out_f32` writes the sum as fp32; residual_ln = (mean, rstd, gamma, beta):
     `residual` is the fp32 INPUT of that LayerNorm and its output is recomputed on the fly.  fp16 A / B (SM_F16: forward operands
-    of a bf16 run): `preact` must be bf16, `out` is fp16 unless out_f32.  gelu_out (with gelu_grad_of): receives gelu(gelu_grad_of)."""
+    of a bf16 run): `preact` must be bf16, `out` is fp16 unless out_f32.  gelu_out (with gelu_grad_of): receives gelu(gelu_grad_of);
+    gelu_grad_tiled: gelu_grad_of is the tile-major f1 of ffn_pc_fwd."""
     M, K = A.shape
     N = B.shape[0] if n is None else n
     assert B.shape[1] == K and A.dtype == B.dtype
@@ -53,7 +54,7 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
     res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
                        L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32),
-                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out))
+                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled))
     assert residual_ln is None or res32, "residual_ln needs an fp32 residual under a bf16 GEMM"
     L.call("sm_gemm_nt", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
            out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())

@@ -309,3 +309,36 @@ def test_ffn_pc_forward_matches_torch(ops, op_dtype, tol, T):
         again = list(ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, None, save_f1=True))
         again[3] = _f1_rows(again[3], T)
         assert all(torch.equal(x, y) for x, y in zip(out, again))
+
+
+def _f1_tiles(f1, I):
+    """row-major [T, I] -> the producer / consumer kernel's tile-major layout (inverse of _f1_rows), whole 128-row blocks"""
+    T = f1.shape[0]
+    G, NC = 4 * ((T + 127) // 128), I // 32
+    pad = torch.zeros(G * 32, I, dtype=f1.dtype, device=f1.device)
+    pad[:T] = f1
+    r = torch.arange(16, device=f1.device)
+    lane = torch.arange(64, device=f1.device)
+    col = (r[None, :] & 3) + 8 * (r[None, :] >> 2) + 4 * (lane[:, None] >> 5)
+    tok = (lane & 31)[:, None].expand(64, 16)
+    out = torch.empty(G, NC, 64, 16, dtype=f1.dtype, device=f1.device)
+    for c in range(NC):
+        for g in range(G):
+            out[g, c] = pad[g * 32 + tok, c * 32 + col]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,N,K", [(400, 256, 384), (1000, 1536, 384), (4200, 384, 1536)])
+def test_gemm_reads_tile_major_gelu_grad_of(ops, T, N, K):
+    """dF1 = (dy W2) * gelu'(f1) with f1 in the fused forward's tile-major layout == the same GEMM on the row-major tensor, bit for bit
+    (both epilogues: the 128 x 128 kernel and, at K >= 1024, the 192 x 384 one)"""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bf = torch.bfloat16
+    a = (torch.randn(T, K, device="cuda", generator=g) * 0.5).to(bf)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(bf)
+    f1 = torch.randn(T, N, device="cuda", generator=g).to(bf)
+    ga0, ga1 = torch.empty_like(f1), torch.empty_like(f1)
+    want = ops.gemm_nt(a, b, gelu_grad_of=f1, gelu_out=ga0)
+    got = ops.gemm_nt(a, b, gelu_grad_of=_f1_tiles(f1, N), gelu_out=ga1, gelu_grad_tiled=True)
+    assert torch.equal(want, got) and torch.equal(ga0, ga1)
