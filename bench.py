@@ -36,10 +36,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--layout", default="ragged", choices=["ragged", "dense"],
-                    help="layout `value` is measured on: ragged = padding tokens skipped on the device (product default), "
-                         "dense = every document computed at the full padded length (SURVEY 8d headline protocol); the "
-                         "other layout is timed too (after the timed region) and reported beside it")
+    ap.add_argument("--layout", default="dense", choices=["ragged", "dense"],
+                    help="layout `value` is measured on: dense = every document computed at the full padded length (SURVEY 8d "
+                         "headline protocol, the default), ragged = padding tokens skipped on the device (what the product's "
+                         "trainer does by default: identical outputs); the other layout is timed too (after the timed region) "
+                         "and reported beside it")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--negs", type=int, default=15)
@@ -48,8 +49,9 @@ def parse():
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the post-run per-GEMM timing steps")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="also time the oracle on configs[1] at FULL shape (32 x 16 docs, 2 steps; ~36 GB of host RAM, minutes)")
+    ap.add_argument("--cpu-baseline-bounded", action="store_true",
+                    help="time the oracle only on the bounded sample (2 queries per step) instead of configs[1] at FULL shape "
+                         "(32 x 16 docs, 2 steps, ~36 GB of host RAM, about a minute: the default)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--bf16-storage", action="store_true",
                     help="all-bf16 activation storage instead of the default fp32 residual stream (+4.5 %% throughput; the sparse "
@@ -149,6 +151,8 @@ class GemmRoofline:
         self._wrap("gemm_nt", lambda A, B, *a, n=None, **k: 2.0 * A.shape[0] * A.shape[1] * (B.shape[0] if n is None else n))
         self._wrap("gemm_nt_ln_bwd", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
         self._wrap("gemm_tn_acc", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+        # the fused feed-forward forward (LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2): its two GEMMs' FLOPs
+        self._wrap("ffn_pc_fwd", lambda z1, g1, b1, eps, w1f, bias1, *a, **k: 4.0 * z1.shape[0] * z1.shape[1] * bias1.shape[0])
         return self
 
     def __exit__(self, *exc):
@@ -191,20 +195,37 @@ def cpu_model() -> str:
 
 def cpu_baseline(args):
     """Run the CPU leg in a child process with a hard wall-clock bound so the GPU bench line is never
-    held hostage by a slow host (the child never touches the GPU)."""
+    held hostage by a slow host (the child never touches the GPU).  The child prints one JSON line per finished leg (each a
+    complete record): the last one that arrived counts, also when the full-shape leg ran out of time or memory."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--negs", str(args.negs), "--seq", str(args.seq),
-           "--bs", str(args.bs)] + (["--cpu-baseline-full"] if args.cpu_baseline_full else [])
+           "--bs", str(args.bs)] + (["--cpu-baseline-bounded"] if args.cpu_baseline_bounded else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-    timeout = args.cpu_baseline_timeout + (1200 if args.cpu_baseline_full else 0)
+    timeout = args.cpu_baseline_timeout + (0 if args.cpu_baseline_bounded else 600)
     fail = {"value": None, "unit": "samples/sec", "cores": usable_cores(), "kind": "port", "cpu_model": cpu_model()}
+
+    def last_record(stdout):
+        for line in reversed((stdout or "").splitlines()):
+            if line.startswith("{"):
+                try:
+                    return json.loads(line)
+                except ValueError:
+                    continue
+        return None
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-        for line in reversed(out.stdout.splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
+        rec = last_record(out.stdout)
+        if rec is not None:
+            if out.returncode != 0:
+                rec["note"] = f"the CPU child exited with code {out.returncode} after this leg"
+            return rec
         return dict(fail, sample="CPU leg failed: " + (out.stderr.strip().splitlines() or ["no output"])[-1][:200])
-    except subprocess.TimeoutExpired:
+    except subprocess.TimeoutExpired as ex:
+        so = ex.stdout.decode() if isinstance(ex.stdout, bytes) else ex.stdout
+        rec = last_record(so)
+        if rec is not None:
+            rec["note"] = f"the full-shape leg did not finish within {timeout:.0f} s"
+            return rec
         return dict(fail, sample=f"CPU oracle did not finish within {timeout:.0f} s")
 
 
@@ -242,11 +263,13 @@ def _oracle_steps(O, oc, nq, k, S, Sq, steps, seed, lr=2e-5):
 def cpu_baseline_child(args):
     """CPU oracle (the 'port'; oracle/sparse_oracle.py, validated against the reference through tests/golden) timed on
     this box's host cores:
-      * `value`: BASELINE configs[1]'s shape (same model, seq 128, 16 docs per query) on a BOUNDED sample -- 2 queries per
+      * `bounded`: BASELINE configs[1]'s shape (same model, seq 128, 16 docs per query) on a BOUNDED sample -- 2 queries per
         step instead of 32 (one step is a few seconds of host work), 3 steps, mean of steps 2-3;
       * `c1_full`: BASELINE configs[0] (the reference's own CPU-runnable case) IN FULL: 64 triples = 16 steps of bs 4 x
         (1 pos + 1 neg) x seq 64, mean of steps 2-16;
-      * `c2_full` (--cpu-baseline-full only): configs[1] at full shape, 2 steps (~36 GB of host RAM)."""
+      * `value`: configs[1] at FULL shape, 2 steps, the second one (~36 GB of host RAM); with --cpu-baseline-bounded, or if
+        the full-shape leg does not finish, the bounded sample's rate.
+    One JSON line per finished leg, each a complete record (the parent takes the last)."""
     from oracle import sparse_oracle as O  # baseline leg only
 
     cores = usable_cores()
@@ -256,17 +279,23 @@ def cpu_baseline_child(args):
     nq = 2
     t = _oracle_steps(O, oc, nq, k, args.seq, 32, 3, seed=1234)
     mean = sum(t[1:]) / len(t[1:])
-    out = {"value": nq / mean, "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
-           "sample": f"CPU oracle (torch fp32, dropout 0.1, AdamW), configs[1] model/seq/docs-per-query, {nq} queries x {k} docs per "
-                     f"step (1/{args.bs // nq} of the GPU batch), 3 steps, mean of steps 2-3 = {mean:.2f} s/step"}
+    bounded = {"value": nq / mean, "unit": "samples/sec", "s_per_step": mean,
+               "sample": f"configs[1] model/seq/docs-per-query, {nq} queries x {k} docs per step (1/{args.bs // nq} of the GPU batch), "
+                         f"3 steps, mean of steps 2-3"}
+    out = {"value": bounded["value"], "unit": "samples/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+           "sample": "CPU oracle (torch fp32, dropout 0.1, AdamW), " + bounded["sample"] + f" = {mean:.2f} s/step", "bounded": bounded}
+    print(json.dumps(out), flush=True)
     t1 = _oracle_steps(O, oc, 4, 2, 64, 16, 16, seed=4321)
     m1 = sum(t1[1:]) / len(t1[1:])
     out["c1_full"] = {"value": 4 / m1, "unit": "samples/sec", "s_per_step": m1,
                       "sample": "configs[0] in full: 64 triples = 16 steps of bs 4 x (1 pos + 1 neg) x seq 64, mean of steps 2-16"}
-    if args.cpu_baseline_full:
+    print(json.dumps(out), flush=True)
+    if not args.cpu_baseline_bounded:
         t2 = _oracle_steps(O, oc, args.bs, k, args.seq, 32, 2, seed=1234)
-        out["c2_full"] = {"value": args.bs / t2[-1], "unit": "samples/sec", "s_per_step": t2[-1],
-                          "sample": f"configs[1] at full shape: {args.bs} queries x {k} docs x seq {args.seq}, 2 steps, second step"}
+        out["value"] = args.bs / t2[-1]
+        out["sample"] = (f"CPU oracle (torch fp32, dropout 0.1, AdamW), configs[1] at FULL shape: {args.bs} queries x {k} docs x seq "
+                         f"{args.seq} per step (the GPU batch), 2 steps, the second one = {t2[-1]:.1f} s/step")
+        out["c2_full"] = {"value": out["value"], "unit": "samples/sec", "s_per_step": t2[-1]}
     return out
 
 
@@ -300,7 +329,7 @@ def measured_peaks(device):
             "how": "bare v_mfma_f32_16x16x32_bf16 loop, random operands in registers, 1024 WGs x 4 waves; float4 copy of 1 GiB (read + write bytes)"}
 
 
-def latest_traffic(kernel_names):
+def latest_traffic(kernel_names, layout):
     """HBM-side bytes per launch of the roofline kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same command, tools/pmc_summary.py); the git revision it was measured at is reported so a
     stale figure is visible.  PMC counters cannot be read from inside this process."""
@@ -308,10 +337,33 @@ def latest_traffic(kernel_names):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             pmc = json.load(open(path))
+            if pmc.get("layout", "ragged") != layout:  # (summaries older than round 3 were taken on the ragged layout)
+                continue
             for name in kernel_names:
                 if name in pmc["kernels"]:
                     return (pmc["kernels"][name]["bytes_per_launch"], f"{os.path.relpath(path, ROOT)}: {pmc['source']}",
                             pmc.get("git", "unknown (round 1)"), name)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None, None
+
+
+GEMM_KERNELS = ("gemm_nt_kernel", "gemm_nt192_kernel", "gemm_tn_pc_kernel", "gemm_tn_kernel", "ffn_pc_fwd_kernel")
+
+
+def latest_gemm_traffic(layout):
+    """HBM-side bytes per training step of all encoder GEMM launches, from the newest committed PMC summary that records the
+    number of steps it profiled and ran on `layout` (tools/profile_round.sh): sum over the GEMM kernels of launches x bytes per launch"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if not pmc.get("steps") or pmc.get("layout") != layout:
+                continue
+            ks = {n: v for n, v in pmc["kernels"].items() if any(n.startswith(g) for g in GEMM_KERNELS)}
+            if ks:
+                total = sum(v["launches"] * v["bytes_per_launch"] for v in ks.values()) / pmc["steps"]
+                return total, f"{os.path.relpath(path, ROOT)}: {pmc['source']}", pmc.get("git"), sorted(ks)
         except (OSError, KeyError, ValueError):
             continue
     return None, None, None, None
@@ -410,8 +462,8 @@ def main():
     achieved = head_flops / (head_ms * 1e-3)
     peak = MFMA_PEAK[args.dtype]
     traffic, traffic_src, traffic_git, traffic_kernel = None, None, None, None
-    if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16" and args.layout == "ragged":
-        traffic, traffic_src, traffic_git, traffic_kernel = latest_traffic(HEAD_KERNELS)
+    if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
+        traffic, traffic_src, traffic_git, traffic_kernel = latest_traffic(HEAD_KERNELS, args.layout)
     sps = lambda el: world * args.bs * args.steps / el
     result = {
         "metric": "training samples/sec (q+1pos+15neg, seq128)",
@@ -434,30 +486,43 @@ def main():
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
                    "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks: all-gather of the representations over "
                                                       "RCCL as in the reference; flat-gradient all-reduce in slices overlapped with backward)")},
-        "roofline": {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
-                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
-                     "traffic_measured_at_git": traffic_git, "traffic_kernel": traffic_kernel,
-                     "kernel_ms": head_ms, "rows_per_launch": T},
     }
+    head_line = {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
+                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                 "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
+                 "traffic_measured_at_git": traffic_git, "traffic_kernel": traffic_kernel,
+                 "kernel_ms": head_ms, "rows_per_launch": T}
     if gemm_lines is not None:
-        result["roofline_encoder_gemms"] = gemm_lines
+        # the step's dominant kernel class: every encoder GEMM launch of a step (forward, input gradients, weight gradients; the
+        # fused feed-forward forward counted by its two GEMMs), timed with HIP events on the stream each launch runs on, in the
+        # step as it runs (weight gradients on the side queue share the chip with the backward chain)
         fl = sum(g["gflop_per_step"] for g in gemm_lines)
         ms = sum(g["ms_per_step"] for g in gemm_lines)
-        result["roofline_encoder_gemms_aggregate"] = {"gflop_per_step": fl, "ms_per_step": ms, "achieved_tflops": fl / ms,
-                                                      "frac": fl / ms * 1e12 / peak}
+        result["roofline"] = {"kernel": "encoder GEMMs, in-step (all launches of sm_gemm_nt / sm_gemm_nt_ln_bwd / sm_gemm_tn_acc / "
+                                        "sm_ffn_pc_fwd of one training step)",
+                              "bound": "mfma", "achieved": fl / ms, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / ms * 1e12 / peak,
+                              "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines}
+        if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
+            tr, src, tgit, tk = latest_gemm_traffic(args.layout)
+            result["roofline"].update({"traffic": tr, "traffic_unit": "bytes/step over all encoder GEMM launches (HBM-side reads x2-corrected "
+                                                                     "+ writes)", "traffic_source": src, "traffic_measured_at_git": tgit,
+                                       "traffic_kernels": tk})
         if gemm_lines_serial:
             fl2 = sum(g["gflop_per_step"] for g in gemm_lines_serial)
             ms2 = sum(g["ms_per_step"] for g in gemm_lines_serial)
-            result["roofline_encoder_gemms_one_queue"] = {
+            result["roofline"]["one_queue"] = {
                 "how": "same ops, weight-gradient launches on the main queue (no kernel shares the chip with another)",
                 "per_op_tflops": {g["op"]: g["achieved_tflops"] for g in gemm_lines_serial},
-                "gflop_per_step": fl2, "ms_per_step": ms2, "achieved_tflops": fl2 / ms2, "frac": fl2 / ms2 * 1e12 / peak}
+                "gflop_per_step": fl2, "ms_per_step": ms2, "achieved": fl2 / ms2, "frac": fl2 / ms2 * 1e12 / peak}
+        result["roofline_head_fwd"] = head_line
+    else:  # N > 1 or --no-gemm-roofline: the largest single kernel of the step
+        result["roofline"] = head_line
     if rank == 0:
         if world == 1:
             pm = measured_peaks(device)
             result["roofline"]["peak_measured"] = pm
-            result["roofline"]["frac_of_measured_peak"] = achieved / 1e12 / pm["mfma_bf16_tflops"] if args.dtype == "bf16" else None
+            result["roofline"]["frac_of_measured_peak"] = (result["roofline"]["achieved"] / pm["mfma_bf16_tflops"]
+                                                           if args.dtype == "bf16" else None)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

@@ -5,10 +5,10 @@
 #   3. PMC passes (FETCH_SIZE, WRITE_SIZE, SQ set), each in its own run with --kernel-trace only
 #      -> gpurun_out/<tag>/pmc_traffic.json, pmc_mfma_util.txt
 # The caller copies what it wants judged into profiles/.
-tag=${1:-r2}; git=${2:-unknown}
+tag=${1:-r3}; git=${2:-unknown}
 out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-B="bench.py --steps 2 --warmup 1 --only-value-layout --no-cpu-baseline"
+B="bench.py --steps 2 --warmup 1 --only-value-layout --no-cpu-baseline --no-gemm-roofline"
 timeout 900 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --only-value-layout --no-cpu-baseline > $out/stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- python3 $B > $out/pmc_fetch.log 2>&1
@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_C
     -d $out/pmc_sq -o s --output-format csv -- python3 $B > $out/pmc_sq.log 2>&1
 f=$(find $out/pmc_fetch -name 'f_counter_collection.csv' | head -1); w=$(find $out/pmc_write -name 'w_counter_collection.csv' | head -1)
 s=$(find $out/pmc_sq -name 's_counter_collection.csv' | head -1)
-python3 tools/pmc_summary.py $f $w $out/pmc_traffic.json $git > $out/pmc_traffic.txt 2>&1
+python3 tools/pmc_summary.py $f $w $out/pmc_traffic.json $git 3 dense > $out/pmc_traffic.txt 2>&1
 python3 tools/sq_summary.py $s $git > $out/pmc_mfma_util.txt 2>&1
 cp $(find $out/stats -name 's_kernel_stats.csv' | head -1) $out/kernel_stats.csv
 python3 tools/step_timeline.py $(find $out/stats -name 's_kernel_trace.csv' | head -1) > $out/step_timeline.txt 2>&1
