@@ -484,8 +484,11 @@ def main():
                                   "identical outputs); value_dense_layout computes all of them" if args.layout == "ragged" else
                                   f"dense layout: all {T_padded} token rows computed; value_ragged_layout skips padding tokens"),
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
-                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks: all-gather of the representations over "
-                                                      "RCCL as in the reference; flat-gradient all-reduce in slices overlapped with backward)")},
+                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks over RCCL, exchange mode "
+                                                      + os.environ.get("SM_EXCHANGE", "scores") + ": scores = all-gather of the queries (under "
+                                                      "the document encoder) and of the score blocks + all-reduce of the FLOPS column means, "
+                                                      "gather = the reference's all-gather of the representations; flat-gradient all-reduce "
+                                                      "in slices overlapped with backward)")},
     }
     head_line = {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
                  "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,

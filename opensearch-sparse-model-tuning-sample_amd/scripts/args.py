@@ -35,7 +35,7 @@ class DataTrainingArguments:
     flops_threshold: Optional[int] = None
     # N > 1 only: "gather" = the reference's dense all-gather of the representations (scripts/utils.py:16-23,
     # default), "scores" = exchange queries / score blocks / FLOPS column means instead (opt-in); identical results
-    dist_exchange: str = "gather"
+    dist_exchange: str = "scores"
     # extension (no reference key): documents per chunk of the rep-level gradient caching (0 = off): forward without saved
     # activations, then per chunk re-forward + backward once d loss / d rep is known (sparse_hip.encoder.encode_cached)
     grad_cache_chunk: int = 0

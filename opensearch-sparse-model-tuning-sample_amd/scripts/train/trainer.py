@@ -35,12 +35,18 @@ class ModelWrapper(torch.nn.Module):
         super().__init__()
         self.sparse_model = sparse_model
         self.inf_free = inf_free
+        self.on_q_rep = None  # N > 1: called with q_rep BEFORE the document encoder runs (the trainer starts its all-gather there)
 
     def forward(self, inputs):
+        q_rep = None
+        if self.inf_free and self.on_q_rep is not None:  # inference-free queries do not touch the encoder: the order is free
+            q_rep = self.sparse_model(inf_free=True, input_ids=inputs["q_input_ids"], attention_mask=inputs["q_attention_mask"])
+            self.on_q_rep(q_rep)
         d_rep = self.sparse_model(inf_free=False, input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
                                   packed=inputs.get("packed"), grad_cache_chunks=inputs.get("grad_cache_chunks"))
-        q_rep = self.sparse_model(inf_free=self.inf_free, input_ids=inputs["q_input_ids"],
-                                  attention_mask=inputs["q_attention_mask"])
+        if q_rep is None:
+            q_rep = self.sparse_model(inf_free=self.inf_free, input_ids=inputs["q_input_ids"],
+                                      attention_mask=inputs["q_attention_mask"])
         return d_rep, q_rep
 
     def save(self, output_dir, **kwargs):
@@ -111,8 +117,11 @@ class SparseModelTrainer:
         self._adam = None
         self._comm_stream = None
         self._pending = []
+        self._q_prefetch = None
         if self.accelerator.num_processes > 1:
             self._setup_grad_overlap()
+            if sparse_model.backbone.device.type == "cuda":
+                self.model.on_q_rep = self._prefetch_q_gather
 
     # ------------------------------------------------------------------ reference surface
     @property
@@ -131,6 +140,24 @@ class SparseModelTrainer:
             return lambda_value
         step = self.state.global_step + 1
         return lambda_value * (step / lambda_T) ** 2
+
+    def _prefetch_q_gather(self, q_rep):
+        """N > 1: the all-gather of q_rep (reference trainer.py:101-104 gathers it after both encoders) is issued on the
+        communication stream as soon as q_rep exists, i.e. under the document encoder; the loss waits for it where it reads
+        the gathered queries.  Same collective, same place in every rank's collective order (the first of the step)."""
+        q = q_rep.detach().contiguous()
+        n = self.accelerator.num_processes
+        q_all = torch.empty((n * q.shape[0],) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            work = dist.all_gather_into_tensor(q_all, q, async_op=True)
+        self._q_prefetch = (q_all, work, q)  # q stays referenced until the wait: the side stream reads it
+
+    def _take_q_prefetch(self):
+        pre, self._q_prefetch = self._q_prefetch, None
+        return pre[:2] if pre is not None else None
 
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
         if hasattr(self, "bi_encoder_teacher"):
@@ -153,7 +180,7 @@ class SparseModelTrainer:
         if self._use_fused_loss():
             return self._compute_loss_fused(d_rep, q_rep, inputs, cap, return_outputs)
         d_rep = gather_rep(d_rep, self.accelerator)
-        q_rep = gather_rep(q_rep, self.accelerator)
+        q_rep = gather_rep(q_rep, self.accelerator, prefetched=self._take_q_prefetch())
         if "scores" in inputs:
             inputs["scores"] = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
         d_flops = self.flops_value(d_rep, d_rep.shape[0] // q_rep.shape[0])
@@ -187,12 +214,13 @@ class SparseModelTrainer:
         return [(ids[a:a + n], mask[a:a + n], None) for a in range(0, ids.shape[0], n)]
 
     def _use_score_exchange(self) -> bool:
-        """N > 1: the default is the reference's dense all-gather of the representations (utils.py:16-23).
-        SM_EXCHANGE=scores (or data_args.dist_exchange) opts into exchanging queries, score blocks and FLOPS
-        column means instead (same loss, same gradients, ~100x less traffic; sparse_hip.functional.distributed_loss)."""
+        """N > 1: the default (data_args.dist_exchange = "scores") exchanges queries, score blocks and FLOPS column means
+        (sparse_hip.functional.distributed_loss: same loss, same gradients as the reference's dense all-gather of the
+        representations, ~100x less traffic and every V-length loss kernel stays on the local documents).  SM_EXCHANGE=gather or
+        dist_exchange: gather selects the reference's own form (utils.py:16-23), kept as the parity mode."""
         if self.accelerator.num_processes <= 1:
             return False
-        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "gather"))
+        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "scores"))
         if mode not in ("scores", "gather"):
             raise KeyError(mode)
         return mode == "scores"
@@ -217,6 +245,7 @@ class SparseModelTrainer:
             teacher = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
         # (the moving average ma = 0.01 * ranking + 0.99 * ma of trainer.py:120-122 is updated by the same launch)
         cfg = {"losses": losses, "q_cap": cap, "flops_threshold": self.data_args.flops_threshold, "moving_avg": self._ma,
+               "q_all": self._take_q_prefetch(),
                "lambda_d": self.get_lambda(self.data_args.flops_d_lambda, self.data_args.flops_d_T),
                "lambda_q": None if self.model_args.inf_free else self.get_lambda(self.data_args.flops_q_lambda,
                                                                                  self.data_args.flops_q_T)}
@@ -338,8 +367,9 @@ class SparseModelTrainer:
         """Side-stream all-reduce of each layer's gradient slice as soon as backward has produced it."""
         bb = self.model.sparse_model.backbone
         self._comm_stream = torch.cuda.Stream(device=bb.device)
-        if not self.model_args.inf_free or int(getattr(self.data_args, "grad_cache_chunk", 0) or 0) > 0:
-            return  # the encoder's backward runs more than once per step (queries + docs / one pass per chunk): reduce once at the end
+        if not self.model_args.inf_free:
+            return  # the encoder's backward runs twice per step (queries and documents): reduce once at the end
+        # (gradient caching runs one backward per chunk: the encoder calls the hook in the LAST chunk's backward only)
         layout = bb._layout
         names = [n for n, _ in layout]
         self._slices = {}

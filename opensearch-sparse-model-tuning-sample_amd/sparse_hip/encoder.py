@@ -587,10 +587,11 @@ class _GradCacheFn(torch.autograd.Function):
         model: HipBertMLM = ctx.model
         use_l0, prune_ratio = ctx.args
         after = model._invocation
-        hook, model._layer_hook = model._layer_hook, None  # per-layer gradient slices are final only after the LAST chunk
-        off = 0
+        hook, model._layer_hook = model._layer_hook, None  # per-layer gradient slices are final only in the LAST chunk's backward:
+        off = 0                                             # that one runs with the hook (overlapped all-reduce of the slices)
         try:
-            for (ids, mask, packed), counter in zip(ctx.chunks, ctx.counters):
+            for i, ((ids, mask, packed), counter) in enumerate(zip(ctx.chunks, ctx.counters)):
+                model._layer_hook = hook if i == len(ctx.chunks) - 1 else None
                 with torch.enable_grad():
                     model._invocation = counter
                     rep = model.encode(ids, mask, use_l0, prune_ratio, packed)

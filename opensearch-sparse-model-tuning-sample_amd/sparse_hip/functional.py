@@ -135,22 +135,28 @@ def ensemble_scores(score_list: List[Tensor], score_scale: float) -> Tensor:
 # scripts/utils.py:16-23 gather_rep: all-gather, local slice keeps its autograd edge
 class _GatherFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rep: Tensor, rank: int, world: int, group):
+    def forward(ctx, rep: Tensor, rank: int, world: int, group, prefetched=None):
         rep = rep.contiguous()
-        out = torch.empty((world * rep.shape[0],) + tuple(rep.shape[1:]), dtype=rep.dtype, device=rep.device)
-        dist.all_gather_into_tensor(out, rep, group=group)
+        shape = (world * rep.shape[0],) + tuple(rep.shape[1:])
+        if prefetched is not None and tuple(prefetched[0].shape) == shape and prefetched[0].dtype == rep.dtype:
+            out, work = prefetched  # the all-gather was started earlier on a side stream: the current stream waits for it here
+            work.wait()
+        else:
+            out = torch.empty(shape, dtype=rep.dtype, device=rep.device)
+            dist.all_gather_into_tensor(out, rep, group=group)
         ctx.rank, ctx.n = rank, rep.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        return grad_out[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None, None, None
+        return grad_out[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None, None, None, None
 
 
-def gather_rep(rep: Tensor, accelerator=None, group=None) -> Tensor:
+def gather_rep(rep: Tensor, accelerator=None, group=None, prefetched=None) -> Tensor:
     """Mirror of scripts/utils.py:16-23.  ``accelerator`` may be anything exposing
     ``num_processes`` / ``local_process_index`` (kept for API compatibility) or None, in
-    which case torch.distributed's default group is used."""
+    which case torch.distributed's default group is used.  ``prefetched`` = (gathered tensor, work handle) of an all-gather
+    of this same tensor that is already in flight (SparseModelTrainer._prefetch_q_gather)."""
     if accelerator is not None:
         world, rank = int(accelerator.num_processes), int(accelerator.local_process_index)
     elif dist.is_available() and dist.is_initialized():
@@ -159,7 +165,7 @@ def gather_rep(rep: Tensor, accelerator=None, group=None) -> Tensor:
         world, rank = 1, 0
     if world == 1:
         return rep
-    return _GatherFn.apply(rep, rank, world, group)
+    return _GatherFn.apply(rep, rank, world, group, prefetched)
 
 
 # ---------------------------------------------------------------------------------------
@@ -193,7 +199,11 @@ class _DistLossFn(torch.autograd.Function):
             raise L.SparseHipError(f"d_rep rows {nd} must be a multiple of q_rep rows {nq}")
         k = nd // nq
         thr, cap = cfg.get("flops_threshold"), cfg.get("q_cap")
-        if N > 1:
+        pre = cfg.pop("q_all", None)
+        if N > 1 and pre is not None and tuple(pre[0].shape) == (N * nq, V) and pre[0].dtype == torch.float32:
+            q_all, work = pre  # started on the communication stream before the document encoder ran
+            work.wait()
+        elif N > 1:
             q_all = torch.empty((N * nq, V), dtype=torch.float32, device=q.device)
             dist.all_gather_into_tensor(q_all, q, group=group)
         else:

@@ -255,3 +255,96 @@ def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_
 def test_two_rank_step_over_rccl(tmp_path, case):
     """the same invariant with one GPU per rank over RCCL (backend "nccl"), when the box has two GPUs"""
     _two_rank_case(tmp_path, case, "nccl", (29571 + 4 * CASES.index(case), 29573 + 4 * CASES.index(case)))
+
+
+# ---- 4 and 8 ranks on the single test GPU (gloo): a synthetic global batch of 8 queries, rank r takes queries [r * 8 / N, (r + 1) * 8 / N)
+WORKER_N = r"""
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(100, exit=True)
+import numpy as np, torch, torch.distributed as dist
+root, pkg, out = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path[:0] = [root, pkg]
+torch.cuda.set_device(0)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+rank = dist.get_rank() if world > 1 else 0
+from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+from scripts.model.sparse_encoders import SparseModel
+from scripts.train.loss import LOSS_CLS_MAP
+from scripts.train.trainer import SparseModelTrainer
+from sparse_hip.encoder import BertConfigLite, HipBertMLM
+g1 = np.load(os.path.join(root, "tests", "golden", "g1_encode.npz"))
+g2 = np.load(os.path.join(root, "tests", "golden", "g2_inf_free.npz"))
+cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None)
+bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
+model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
+case = os.environ["SM_TEST_CASE"]
+K = 16 if case == "infonce_ibn_k16" else 3
+inf_free = case != "learned_queries"
+kd = case == "kd_scores"
+ibn = not kd
+kind = "kldiv" if kd else "infonce"
+gc = 8 if case == "infonce_ibn_k16" else 0   # k = 16 also runs rep-level gradient caching (8 documents per chunk): the slices are
+                                              # then all-reduced from inside the LAST chunk's backward
+margs = ModelArguments(model_name_or_path="x", inf_free=inf_free)
+dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10, flops_q_lambda=0.03,
+                              flops_q_T=10, flops_threshold=3 if kd else None, grad_cache_chunk=gc)
+targs = TrainingArguments(output_dir="/tmp/sm_dist", logging_steps=1000, learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, max_steps=6)
+trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
+                             loss_functions=[LOSS_CLS_MAP[kind](use_in_batch_negatives=ibn, weight=0.7, temperature=2.0)])
+NQ = 8
+g = torch.Generator().manual_seed(11)
+def toks(n, S):
+    ids = torch.randint(5, 520, (n, S), generator=g)
+    lens = torch.randint(3, S + 1, (n,), generator=g)
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    return ids * mask, mask
+q_ids, q_mask = toks(NQ, 8)
+d_ids, d_mask = toks(NQ * K, 16)
+nq = NQ // world
+sl_q, sl_d = slice(rank * nq, (rank + 1) * nq), slice(rank * nq * K, (rank + 1) * nq * K)
+inp = {"query": [{"input_ids": q_ids[sl_q].cuda(), "attention_mask": q_mask[sl_q].cuda()}],
+       "docs": [{"input_ids": d_ids[sl_d].cuda(), "attention_mask": d_mask[sl_d].cuda()}]}
+if kd:
+    inp["scores"] = (torch.randn(NQ, K, generator=torch.Generator().manual_seed(3)) * 3)[sl_q]
+trainer.state.global_step = 3
+loss = trainer.training_step(inp)
+torch.cuda.synchronize()
+if rank == 0:
+    np.savez(out, flat=bb.flat_param.cpu().numpy(), loss=float(loss))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print("done", rank)
+"""
+
+N_CASES = {4: ["infonce_ibn_k3", "kd_scores"], 8: ["infonce_ibn_k16", "learned_queries"]}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [(w, c) for w, cs in N_CASES.items() for c in cs])
+def test_four_and_eight_rank_steps_equal_the_single_process_step(tmp_path, world, case):
+    """4 and 8 ranks (gloo, all on the single test GPU), both exchange modes, against ONE process stepping on the concatenated
+    batch of 8 queries: k = 3 and k = 16 documents per query with in-batch negatives (k = 16 with rep-level gradient caching,
+    i.e. the overlapped slice all-reduce fired from the last chunk's backward), KL distillation on teacher scores, learned
+    queries (the query gradient crosses ranks).  The reference's invariant: utils.py:16-23 + trainer.py:139-141."""
+    script = tmp_path / "worker_n.py"
+    script.write_text(WORKER_N)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", SM_TEST_CASE=case)
+    one = str(tmp_path / "one.npz")
+    r1 = _run([sys.executable, str(script), ROOT, PKG, one], env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    a = np.load(one)
+    base = 29600 + 10 * world + 2 * N_CASES[world].index(case)
+    for port, mode in ((base, "gather"), (base + 1, "scores")):
+        many = str(tmp_path / f"n_{mode}.npz")
+        r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                  "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, many], dict(env, SM_EXCHANGE=mode))
+        assert r.returncode == 0, r.stdout + r.stderr
+        b = np.load(many)
+        assert abs(float(b["loss"]) - world * float(a["loss"])) <= 2e-3 * world * abs(float(a["loss"])), mode
+        diff = np.abs(a["flat"] - b["flat"])
+        assert (diff > 1e-4).sum() <= 1e-3 * diff.size, (mode, int((diff > 1e-4).sum()))
+        assert diff.max() <= 2.5e-3, mode
