@@ -1,25 +1,64 @@
-"""Cost of the loss head on gathered representations at N ranks (N x 32 queries, N x 512 documents), one GPU:
-what every rank pays after the all-gather of d_rep / q_rep (flops regulariser + InfoNCE in-batch + backward)."""
+"""Cost of the loss head at N ranks on ONE GPU (the collectives replaced by local stand-ins of the same shapes, so only the
+kernels are timed): what every rank pays per step
+  * gather mode: flops regulariser + InfoNCE in-batch + backward on the GATHERED representations (N x 32 queries, N x 512 documents);
+  * scores mode: sparse_hip.functional.distributed_loss on the LOCAL documents with N x 32 gathered queries.
+Message sizes per rank are printed beside the times (DESIGN 6 builds its predicted step times from these lines)."""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "opensearch-sparse-model-tuning-sample_amd"))
+import torch.distributed as dist
 from sparse_hip import functional as F
-V = 30522
-for N in (1, 2, 4, 8):
-    nq, nd = 32 * N, 512 * N
-    g = torch.Generator(device="cuda").manual_seed(0)
+V, NQ, K = 30522, 32, 16
+
+
+def timed(step, n=10):
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def reps(nq, nd, g):
     d = (torch.rand(nd, V, device="cuda", generator=g) * 2).requires_grad_(True)
     q = torch.zeros(nq, V, device="cuda")
-    idx = torch.randint(1000, V, (nq, 12), device="cuda", generator=g)
-    q.scatter_(1, idx, 1.0)
-    q.requires_grad_(True)
-    def step():
-        fl = F.flops_value(d, nd // nq)
+    q.scatter_(1, torch.randint(1000, V, (nq, 12), device="cuda", generator=g), 1.0)
+    return d, q.requires_grad_(True)
+
+
+for N in (1, 2, 4, 8):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    d, q = reps(NQ * N, NQ * K * N, g)
+
+    def gather_step():
+        fl = F.flops_value(d, K)
         rl = F.ranking_loss("infonce", q, d, None, True, 1.0, 32)
         (fl * 0.05 + rl).backward()
-        d.grad = None; q.grad = None
-    for _ in range(3): step()
-    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): step()
-    e1.record(); torch.cuda.synchronize()
-    print(f"N={N}: loss head fwd+bwd on gathered reps {e0.elapsed_time(e1)/10:.3f} ms  (all-gather payload per rank {nd*V*4/N/1e6:.0f} MB x {N-1})")
+        d.grad = None
+        q.grad = None
+    t_gather = timed(gather_step)
+    del d, q
+    # scores mode: local documents, the collectives stand-ins keep shapes and data flow (all-gather = N copies of the local block)
+    dl, ql = reps(NQ, NQ * K, g)
+    real = (F._world, dist.all_gather_into_tensor, dist.all_reduce)
+    F._world = lambda group: (N, 0)
+    dist.all_gather_into_tensor = lambda out, inp, group=None: out.view(N, *inp.shape).copy_(inp.unsqueeze(0).expand(N, *inp.shape))
+    dist.all_reduce = lambda t, group=None, **kw: t.mul_(N)
+    try:
+        def scores_step():
+            cfg = {"losses": [("infonce", 1.0, True, 1.0)], "q_cap": 32, "flops_threshold": None, "lambda_d": 0.05, "lambda_q": None}
+            F.distributed_loss(dl, ql, None, cfg).backward()
+            dl.grad = None
+            ql.grad = None
+        t_scores = timed(scores_step) if N > 1 else float("nan")
+    finally:
+        F._world, dist.all_gather_into_tensor, dist.all_reduce = real
+    del dl, ql
+    mb = lambda b: f"{b / 1e6:.2f} MB"
+    print(f"N={N}: gather mode loss head {t_gather:.3f} ms (receives d_rep {(N - 1)} x {mb(NQ * K * V * 4)} + q_rep {(N - 1)} x {mb(NQ * V * 4)}) | "
+          f"scores mode loss head {t_scores:.3f} ms (receives q_rep {(N - 1)} x {mb(NQ * V * 4)} [under the document encoder], score blocks "
+          f"{(N - 1)} x {mb(N * NQ * NQ * K * 4)}, all-reduces FLOPS column means {mb(K * V * 4)})")
