@@ -37,6 +37,11 @@ extern "C" {
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
  * sm_gemm_nt (A, B, C fp16; `preact` stays bf16, it is read by the backward), sm_sparse_head_fwd (t, E), sm_cast_weight*. */
 #define SM_F16 2
+/* fp8 operands of sm_gemm_nt (BASELINE configs[4] "fp8 MFMA", config_kd.yaml:9-16; OCP formats): A and B are one byte per element,
+ * quantised per tensor by sm_amax + sm_quantize_fp8; C and every epilogue tensor are bf16 (fp32 where out_f32 / residual_f32 say
+ * so).  SM_FP8: A e4m3, B e4m3 (forward).  SM_FP8_GRAD: A e5m2 (a gradient), B e4m3 (input-gradient GEMMs). */
+#define SM_FP8 3
+#define SM_FP8_GRAD 4
 
 #define SM_OK 0
 #define SM_ERR_INVALID (-1)
@@ -95,10 +100,19 @@ typedef struct sm_epilogue {
                                post-GELU operand of the FFN-down weight gradient when the forward did not keep it in this dtype */
   int gelu_grad_tiled;      /* 1: gelu_grad_of is the tile-major f1 that sm_ffn_pc_fwd leaves ([4 ceil(M/128)][N/32][64][16], 16-bit
                                dtypes, N % 32 == 0) instead of a row-major [M,N] tensor */
+  const float* scale_a;     /* SM_FP8 / SM_FP8_GRAD only: DEVICE scalars, the dequantisation scales of A and B (sm_quantize_fp8); the */
+  const float* scale_b;     /* accumulator is multiplied by *scale_a * *scale_b before the epilogue                                     */
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                int M, int N, int K, const sm_epilogue* epi, void* stream);
+
+/* Per-tensor fp8 quantisation, just in time and without a host round trip:
+ *   sm_amax:          *amax = max(*amax, max |x[i]|)            (the caller zeroes *amax first; dtype SM_BF16 or SM_F32)
+ *   sm_quantize_fp8:  q[i] = fp8(x[i] * fmax / *amax), *scale = *amax / fmax   (e5m2 = 0: e4m3fn, fmax 448; 1: e5m2, fmax 57344;
+ *                     round to nearest even, saturating)  -- x ~ q * *scale; *scale is what sm_epilogue.scale_a / scale_b point to */
+int sm_amax(int dtype, const void* x, long n, float* amax, void* stream);
+int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, void* stream);
 
 /* Input-gradient GEMM fused with the LayerNorm backward that consumes it (hf:293/351 backward):
  *   dy = A[M,K] . B[N,K]^T + residual;  dx = LN'(dy | x, gamma, mean, rstd);  dx_drop = dropout_bwd(dx) (optional);

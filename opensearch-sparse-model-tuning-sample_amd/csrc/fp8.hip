@@ -1,0 +1,118 @@
+// fp8 operands for the encoder linears of BASELINE configs[4] (config_kd.yaml:9-16 "bert-base student ... fp8 MFMA"; SURVEY 7
+// step 8: e4m3 forward / e5m2 gradient, per-tensor scales).  OCP formats (gfx950 converts to / from OCP e4m3fn and e5m2):
+//   e4m3fn: largest finite 448;  e5m2: largest finite 57344.
+// Per-tensor scaling, just in time: amax of the tensor (one pass, one atomic per workgroup), then q = x * (fmax / amax) rounded
+// to nearest even by the hardware conversion; the dequantisation scale amax / fmax stays ON THE DEVICE (the GEMM epilogue reads
+// it through a pointer), so no step of this ever synchronises with the host.  Both kernels are HBM-bound streams: 2 (bf16) or 4
+// (fp32) bytes read twice, one byte written per element.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float fp8_in(const T* p, long i) { return to_f32<T>(p[i]); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long n, float* __restrict__ amax) {
+  float m = 0.f;
+  const long n8 = n / 8;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n8; v += (long)gridDim.x * 256) {
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + v * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf((float)a[k]));
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + v * 8), b = *reinterpret_cast<const f32x4*>(x + v * 8 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(fabsf(a[k]), fabsf(b[k])));
+    }
+  }
+  if (blockIdx.x == 0)
+    for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(fp8_in<T>(x, i)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
+  }
+}
+
+// four floats -> four fp8 bytes (one dword), E5M2 selects the gradient format
+template <bool E5M2> __device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d) {
+  int w = 0;
+  if constexpr (E5M2) {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  }
+  return (uint32_t)w;
+}
+
+template <typename T, bool E5M2>
+__global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, long n, const float* __restrict__ amax,
+                                                       uint8_t* __restrict__ q, float* __restrict__ scale) {
+  constexpr float FMAX = E5M2 ? 57344.f : 448.f;
+  const float am = fmaxf(*amax, 1e-30f);
+  const float mul = FMAX / am;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale = am / FMAX;  // dequantisation scale: x ~ q * scale
+  const long n8 = n / 8;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n8; v += (long)gridDim.x * 256) {
+    float f[8];
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + v * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = (float)a[k];
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + v * 8), b = *reinterpret_cast<const f32x4*>(x + v * 8 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
+    }
+    // (|x| <= amax, so |x * mul| <= FMAX up to one rounding: the clamp keeps the conversion away from its overflow encoding)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(f[k] * mul, -FMAX), FMAX);
+    uint2 o;
+    o.x = pack4<E5M2>(f[0], f[1], f[2], f[3]);
+    o.y = pack4<E5M2>(f[4], f[5], f[6], f[7]);
+    *reinterpret_cast<uint2*>(q + v * 8) = o;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) {
+      const float f = fminf(fmaxf(fp8_in<T>(x, i) * mul, -FMAX), FMAX);
+      q[i] = (uint8_t)(pack4<E5M2>(f, 0.f, 0.f, 0.f) & 0xff);
+    }
+}
+
+}  // namespace
+
+extern "C" int sm_amax(int dtype, const void* x, long n, float* amax, void* stream) {
+  SM_REQUIRE(n > 0 && x && amax, "sm_amax: empty tensor");
+  SM_REQUIRE(((uintptr_t)x % 16) == 0, "sm_amax: x must be 16-byte aligned");
+  int grid = (int)((n / 8 + 255) / 256);
+  grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SM_BF16) hipLaunchKernelGGL(amax_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, n, amax);
+  else if (dtype == SM_F32) hipLaunchKernelGGL(amax_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, n, amax);
+  else SM_REQUIRE(false, "sm_amax: bad dtype %d", dtype);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+extern "C" int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, void* stream) {
+  SM_REQUIRE(n > 0 && x && amax && q && scale, "sm_quantize_fp8: empty tensor");
+  SM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0, "sm_quantize_fp8: x must be 16-byte, q 8-byte aligned");
+  int grid = (int)((n / 8 + 255) / 256);
+  grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+  hipStream_t st = (hipStream_t)stream;
+#define SM_Q(T, E) hipLaunchKernelGGL((quantize_kernel<T, E>), dim3(grid), dim3(256), 0, st, (const T*)x, n, amax, (uint8_t*)q, scale)
+  if (dtype == SM_BF16) { if (e5m2) SM_Q(bf16, true); else SM_Q(bf16, false); }
+  else if (dtype == SM_F32) { if (e5m2) SM_Q(float, true); else SM_Q(float, false); }
+  else SM_REQUIRE(false, "sm_quantize_fp8: bad dtype %d", dtype);
+#undef SM_Q
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}

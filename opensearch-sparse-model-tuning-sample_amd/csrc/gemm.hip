@@ -41,6 +41,26 @@ template <> struct Mma<f16> {
     return *reinterpret_cast<const Frag*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
   }
 };
+// fp8 operands (SM_FP8 / SM_FP8_GRAD; csrc/fp8.hip): one-byte tag types for the main loop only -- every epilogue tensor of such
+// a GEMM is bf16.  A 16-byte fragment holds 16 k-elements = TWO v_mfma_f32_16x16x32 steps (low / high 8 bytes); which 32 of the
+// stage row's 64 k-elements an MFMA sees is a permutation applied to A and B alike, so the sum over k is unchanged.
+struct fp8_op { uint8_t v; };    // A e4m3, B e4m3 (forward)
+struct bf8fp8_op { uint8_t v; }; // A e5m2 (a gradient), B e4m3 (input-gradient GEMMs)
+typedef long i64x2 __attribute__((ext_vector_type(2)));
+template <> struct Mma<fp8_op> {
+  using Frag = i64x2;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[0], b[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[1], b[1], c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf8fp8_op> {
+  using Frag = i64x2;
+  __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a[0], b[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a[1], b[1], c, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   static constexpr int KSTEP = 4, BK = 32;
   using Frag = float;
@@ -166,6 +186,13 @@ template <> struct GlFrag<f16> {
     return *reinterpret_cast<const f16x8*>(st + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
   }
 };
+template <> struct GlFrag<fp8_op> {
+  static constexpr int BK = 64, NS = 1;  // a 64-byte stage row = 64 k-elements
+  __device__ static __forceinline__ i64x2 load(const char* st, int row, int ks, int g) {
+    return *reinterpret_cast<const i64x2*>(st + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
+  }
+};
+template <> struct GlFrag<bf8fp8_op> : GlFrag<fp8_op> {};
 template <> struct GlFrag<float> {
   static constexpr int BK = 16, NS = 4;
   __device__ static __forceinline__ float load(const char* st, int row, int ks, int g) {
@@ -317,6 +344,7 @@ struct EpiArgs {
   const void* gelu_grad_of;
   void* gelu_out;    // with gelu_grad_of: gelu(gelu_grad_of) is written here too (the post-GELU tensor a weight gradient needs)
   int ggo_tiled;     // gelu_grad_of is the fused feed-forward's tile-major f1 (load_ggo8)
+  const float *scale_a, *scale_b;  // fp8 operands: the accumulator is multiplied by *scale_a * *scale_b (device scalars, csrc/fp8.hip)
   int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
   const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // res32: residual = LayerNorm(residual) recomputed from its fp32 input
 };
@@ -341,8 +369,9 @@ __device__ __forceinline__ void load_ggo8(const T* ggo, bool tiled, size_t off, 
   }
 }
 
-template <typename T, bool GLDS>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+// T: type of C and of every epilogue tensor; OP: operand type of the main loop (T, or an fp8 tag with T = bf16)
+template <typename T, bool GLDS, typename OP = T>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const OP* __restrict__ A, int lda, const OP* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
   // LDS: the glds variant uses a 3-stage ring (48 KiB) and stages the epilogue in two 64-row halves
   // (33 KiB), so three workgroups fit a CU and their main loops cover each other's epilogues
@@ -359,8 +388,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const T* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (GLDS) nt_mainloop_glds<T, NT_NST>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  if constexpr (GLDS) nt_mainloop_glds<OP, NT_NST>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
   else nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  if constexpr (!std::is_same<OP, T>::value) {  // fp8: dequantise (per-tensor scales, device scalars)
+    const float alpha = *e.scale_a * *e.scale_b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= alpha;
+  }
 
   // Epilogue through LDS, 64 rows (one wave row) at a time: the accumulators (MFMA C layout: one
   // column x 4 rows per lane) are staged as an fp32 [64][CS] tile so that every global access of the
@@ -1470,6 +1506,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   e.gelu_grad_of = epi ? epi->gelu_grad_of : nullptr;
   e.gelu_out = epi ? epi->gelu_out : nullptr;
   SM_REQUIRE(!e.gelu_out || e.gelu_grad_of, "sm_gemm_nt: gelu_out needs gelu_grad_of");
+  e.scale_a = e.scale_b = nullptr;
   e.ggo_tiled = epi ? epi->gelu_grad_tiled : 0;
   SM_REQUIRE(!e.ggo_tiled || (e.gelu_grad_of && sizeof(T) == 2 && N % 32 == 0 && ldc % 8 == 0),
              "sm_gemm_nt: gelu_grad_tiled needs a 16-bit gelu_grad_of, N %% 32 == 0");
@@ -1555,13 +1592,50 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
   return 0;
 }
 
+// fp8 operands, bf16 epilogue: the 128 x 128 LDS-DMA kernel with two fp8 MFMAs per 16-byte fragment
+template <typename OP>
+int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const sm_epilogue* epi,
+                       hipStream_t st) {
+  SM_REQUIRE(epi && epi->scale_a && epi->scale_b, "sm_gemm_nt: fp8 operands need epi->scale_a / scale_b (device scalars from sm_quantize_fp8)");
+  EpiArgs e;
+  e.bias = epi->bias;
+  e.act = epi->act;
+  e.preact = epi->preact;
+  e.drop = make_drop(&epi->drop);
+  e.residual = epi->residual;
+  e.gelu_grad_of = epi->gelu_grad_of;
+  e.gelu_out = epi->gelu_out;
+  SM_REQUIRE(!e.gelu_out || e.gelu_grad_of, "sm_gemm_nt: gelu_out needs gelu_grad_of");
+  e.ggo_tiled = epi->gelu_grad_tiled;
+  SM_REQUIRE(!e.ggo_tiled || (e.gelu_grad_of && N % 32 == 0 && ldc % 8 == 0), "sm_gemm_nt: gelu_grad_tiled needs N %% 32 == 0");
+  e.res32 = epi->residual_f32;
+  e.out32 = epi->out_f32;
+  e.rl_mean = epi->res_ln_mean;
+  e.rl_rstd = epi->res_ln_rstd;
+  e.rl_gamma = epi->res_ln_gamma;
+  e.rl_beta = epi->res_ln_beta;
+  SM_REQUIRE(!e.rl_mean || (e.res32 && e.residual && e.rl_rstd && e.rl_gamma && e.rl_beta && N % 8 == 0 && ((uintptr_t)e.rl_gamma % 16) == 0 &&
+                            ((uintptr_t)e.rl_beta % 16) == 0),
+             "sm_gemm_nt: res_ln_* need an fp32 residual, all four pointers, N %% 8 == 0");
+  e.scale_a = epi->scale_a;
+  e.scale_b = epi->scale_b;
+  e.xcd = 1;
+  const uintptr_t vb = 16;
+  e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
+             ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
+  dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
+  hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 0, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
+                     K, e);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                           int K, const sm_epilogue* epi, void* stream) {
   SM_REQUIRE(M > 0 && N > 0 && K > 0, "sm_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   SM_REQUIRE(K % 64 == 0, "sm_gemm_nt: K=%d must be a multiple of 64", K);
-  const int esz = (dtype == SM_BF16 || dtype == SM_F16) ? 2 : 4;
+  const int esz = (dtype == SM_FP8 || dtype == SM_FP8_GRAD) ? 1 : (dtype == SM_BF16 || dtype == SM_F16) ? 2 : 4;
   SM_REQUIRE((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "sm_gemm_nt: lda/ldb rows must be 16-byte aligned");
   SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_nt: A/B must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -1571,7 +1645,9 @@ extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int 
   else if (dtype == SM_F16) {
     SM_REQUIRE(!epi || (!epi->gelu_grad_of && (!epi->residual || epi->residual_f32)), "sm_gemm_nt: fp16 operands are a forward format (no gelu_grad_of, residual only as fp32)");
     rc = launch_gemm_nt<f16>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
-  } else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
+  } else if (dtype == SM_FP8) rc = launch_gemm_nt_fp8<fp8_op>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else if (dtype == SM_FP8_GRAD) rc = launch_gemm_nt_fp8<bf8fp8_op>(A, lda, B, ldb, C, ldc, M, N, K, epi, st);
+  else SM_REQUIRE(false, "sm_gemm_nt: bad dtype %d", dtype);
   if (rc != 0) return rc;
   SM_LAUNCH_CHECK();
   return SM_OK;

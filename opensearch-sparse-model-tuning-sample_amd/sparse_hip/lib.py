@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
-SM_F32, SM_BF16, SM_F16 = 0, 1, 2
+SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
 
 
 class SmDropout(C.Structure):
@@ -38,6 +38,8 @@ class SmEpilogue(C.Structure):
         ("res_ln_beta", C.c_void_p),
         ("gelu_out", C.c_void_p),  # with gelu_grad_of: gelu(gelu_grad_of) written here too
         ("gelu_grad_tiled", C.c_int),  # gelu_grad_of is the tile-major f1 of sm_ffn_pc_fwd
+        ("scale_a", C.c_void_p),  # fp8 operands: device scalars, dequantisation scales of A and B
+        ("scale_b", C.c_void_p),
     ]
 
 
@@ -56,6 +58,8 @@ _rag = C.POINTER(SmRagged)
 # name -> argtypes (all return int); must list every symbol declared in include/sparse_hip.h
 SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
+    "sm_amax": [_i, _p, _l, _p, _p],
+    "sm_quantize_fp8": [_i, _p, _l, _p, _i, _p, _p, _p],
     "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_ffn_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
@@ -144,6 +148,8 @@ def dtype_code(dt: torch.dtype) -> int:
         return SM_BF16
     if dt == torch.float16:  # forward operand format of bf16 runs where an entry point accepts it (include/sparse_hip.h)
         return SM_F16
+    if dt == torch.float8_e4m3fn:  # fp8 operands of sm_gemm_nt (A of an input-gradient GEMM is e5m2: SM_FP8_GRAD, see ops.gemm_nt)
+        return SM_FP8
     raise SparseHipError(f"unsupported compute dtype {dt}")
 
 

@@ -40,23 +40,28 @@ def _rag_ref(rag):
 def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, preact: Optional[Tensor] = None,
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
             gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None,
-            out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None, gelu_grad_tiled: bool = False) -> Tensor:
+            out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None, gelu_grad_tiled: bool = False,
+            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables).  fp32 residual stream of a
     bf16 run: an fp32 `residual` is added in fp32 and `out_f32` writes the sum as fp32; residual_ln = (mean, rstd, gamma, beta):
     `residual` is the fp32 INPUT of that LayerNorm and its output is recomputed on the fly.  fp16 A / B (SM_F16: forward operands
     of a bf16 run): `preact` must be bf16, `out` is fp16 unless out_f32.  gelu_out (with gelu_grad_of): receives gelu(gelu_grad_of);
-    gelu_grad_tiled: gelu_grad_of is the tile-major f1 of ffn_pc_fwd."""
+    gelu_grad_tiled: gelu_grad_of is the tile-major f1 of ffn_pc_fwd.  fp8 operands (quantize_fp8: A e4m3 or, for an input-gradient
+    GEMM, e5m2; B e4m3; scale_a / scale_b their device-side dequantisation scales): out and every epilogue tensor are bf16."""
     M, K = A.shape
     N = B.shape[0] if n is None else n
-    assert B.shape[1] == K and A.dtype == B.dtype
+    fp8 = B.dtype == torch.float8_e4m3fn
+    assert B.shape[1] == K and (A.dtype == B.dtype or (fp8 and A.dtype == torch.float8_e5m2))
+    assert not fp8 or (scale_a is not None and scale_b is not None)
     if out is None:
-        out = _new((M, N), torch.float32 if out_f32 else A.dtype, A)
+        out = _new((M, N), torch.float32 if out_f32 else (torch.bfloat16 if fp8 else A.dtype), A)
     res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
                        L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32),
-                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled))
+                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled), L.ptr(scale_a), L.ptr(scale_b))
     assert residual_ln is None or res32, "residual_ln needs an fp32 residual under a bf16 GEMM"
-    L.call("sm_gemm_nt", L.dtype_code(A.dtype), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
+    code = L.SM_FP8_GRAD if A.dtype == torch.float8_e5m2 else L.dtype_code(A.dtype)
+    L.call("sm_gemm_nt", code, L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
            out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())
     return out
 
@@ -133,6 +138,20 @@ def ffn_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2t: Tensor, w1tp: T
                          L.ptr(r1), _drop_ref(drop), L.ptr(df1), L.ptr(ga), L.ptr(dz1), L.ptr(dz1d), L.ptr(dgamma), L.ptr(dbeta),
                          T, H, I, L.stream_ptr())
     return (df1, ga, dz1, dz1d) if ok else None
+
+
+def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None):
+    """(q, scale): per-tensor fp8 copy of x (bf16 / fp32) and its device-side dequantisation scale, x ~ q * scale.  e4m3fn by
+    default (forward operands), e5m2 for gradients; amax: a [1] fp32 device tensor already holding max |x| (e.g. a weight's, for
+    its transposed copy), otherwise measured here"""
+    x = x.contiguous()
+    if amax is None:
+        amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        L.call("sm_amax", L.dtype_code(x.dtype), L.ptr(x), x.numel(), L.ptr(amax), L.stream_ptr())
+    q = torch.empty(x.shape, dtype=torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.call("sm_quantize_fp8", L.dtype_code(x.dtype), L.ptr(x), x.numel(), L.ptr(amax), int(e5m2), L.ptr(q), L.ptr(scale), L.stream_ptr())
+    return q, scale, amax
 
 
 def ffn_pc_stage(w1_layer0: Tensor, w2_layer0: Tensor, layer_stride: int, layers: int, w1f: Optional[Tensor], w2f: Optional[Tensor],

@@ -698,3 +698,56 @@ def test_layernorm_res32_fp16_copy(ops):
     y, y32, mean, rstd, y16 = ops.layernorm_fwd_res32(dev(x), dev(gamma), dev(beta), 1e-12, torch.bfloat16, want_y32=True, want_y16=True)
     assert y16.dtype == torch.float16 and torch.equal(y16, y32.to(torch.float16)) and torch.equal(y, y32.to(torch.bfloat16))
     close(y32, O._ln(x, gamma, beta, 1e-12), 1e-5, "fp32 output")
+
+
+# ---- fp8 operands (BASELINE configs[4]; csrc/fp8.hip, sm_gemm_nt SM_FP8 / SM_FP8_GRAD) ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("e5m2", [False, True])
+def test_quantize_fp8_matches_the_torch_conversion(ops, dtype, e5m2):
+    """per-tensor scaling: q = fp8(x * fmax / amax) byte for byte what torch's CPU round-to-nearest-even conversion gives (OCP
+    e4m3fn / e5m2), scale = amax / fmax; also the odd tail (n % 8 != 0) and a tensor whose amax sits in the tail"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (8 * 4096 + 5, 1237, 64):
+        x = (torch.randn(n, device="cuda", generator=g) * 3).to(dtype)
+        x[-1] = 17.5
+        q, scale, amax = ops.quantize_fp8(x, e5m2=e5m2)
+        fmax = 57344.0 if e5m2 else 448.0
+        assert float(amax) == 17.5 and abs(float(scale) - 17.5 / fmax) < 1e-9
+        ref = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(17.5))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
+        assert torch.equal(q.cpu().view(torch.uint8), ref.view(torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (4100, 768, 768), (2100, 3072, 768), (1000, 768, 3072)])
+@pytest.mark.parametrize("grad", [False, True])
+def test_gemm_nt_fp8_operands(ops, M, N, K, grad):
+    """C = (qA . qB^T) * sa * sb: against the same product of the DEQUANTISED operands in fp64 (the fp8 MFMA multiplies exactly and
+    accumulates in fp32), fp32 output 1e-4, bf16 output at its rounding; forward (e4m3 x e4m3) and input-gradient (e5m2 x e4m3)
+    formats, with the bias / GELU / pre-activation / residual epilogue of the encoder linears"""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    qa, sa, _ = ops.quantize_fp8(a, e5m2=grad)
+    qb, sb, _ = ops.quantize_fp8(b)
+    want = (qa.float().double() @ qb.float().double().t()) * float(sa) * float(sb)
+    got32 = ops.gemm_nt(qa, qb, scale_a=sa, scale_b=sb, out_f32=True)
+    scale = want.abs().max()
+    assert float((got32.double() - want).abs().max() / scale) < 1e-4  # (fp32 accumulation inside and between the MFMAs)
+    got = ops.gemm_nt(qa, qb, scale_a=sa, scale_b=sb)
+    assert got.dtype == torch.bfloat16 and float((got.double() - want).abs().max() / scale) < 5e-3
+    # and the quantisation error itself against the bf16 operands (what the fp8 format costs): printed, loosely bounded
+    exact = a.double() @ b.double().t()
+    rel = float((want - exact).norm() / exact.norm())
+    print(f"[fp8 gemm {M}x{N}x{K} {'e5m2' if grad else 'e4m3'} x e4m3] relative Frobenius error of the product {rel:.3e}")
+    assert rel < (1.5e-1 if grad else 6e-2)
+    if not grad:  # the encoder's forward epilogue: bias + GELU with the pre-activation kept, and an fp32 residual
+        bias = torch.randn(N, device="cuda", generator=g) * 0.1
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        act = ops.gemm_nt(qa, qb, bias=bias, act=1, preact=pre, scale_a=sa, scale_b=sb)
+        wpre = want + bias.double()
+        assert float((pre.double() - wpre).abs().max() / scale) < 5e-3
+        assert float((act.double() - torch.nn.functional.gelu(wpre)).abs().max() / scale) < 6e-3
+        res = torch.randn(M, N, device="cuda", generator=g)
+        z = ops.gemm_nt(qa, qb, bias=bias, residual=res, out_f32=True, scale_a=sa, scale_b=sb)
+        assert float((z.double() - (wpre + res.double())).abs().max() / (scale + 4)) < 1e-4
