@@ -60,6 +60,9 @@ class ModelArguments:
     # extension (no reference key): bf16 runs keep the residual stream in fp32, as torch autocast does; default on,
     # false = all-bf16 activation storage (+4.5 % throughput, worst sparse activation 1.4e-2 instead of 5.9e-3 off the fp32 path)
     residual_fp32: Optional[bool] = None
+    # extension: fp8 operands (e4m3 forward / e5m2 gradient, per-tensor scales) for the encoder linears of a bf16 run -- what
+    # BASELINE configs[4] names "fp8 MFMA"; None = the SM_FP8 environment switch (default off)
+    fp8: Optional[bool] = None
 
     def __post_init__(self):
         if self.tokenizer_name is None:

@@ -68,13 +68,14 @@ def _load_tokenizer(tokenizer_id):
 class SparseModel(torch.nn.Module):
     def __init__(self, model_id, idf=None, tokenizer_id=None, idf_requires_grad=False, prune_ratio=None,
                  preprocess_func=None, use_l0=True, compute_dtype: Optional[torch.dtype] = None, device=None,
-                 residual_fp32: Optional[bool] = None):
+                 residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None):
         super().__init__()
         compute_dtype = compute_dtype or torch.bfloat16
         if isinstance(model_id, HipBertMLM):
             self.backbone = model_id
         else:
-            self.backbone = HipBertMLM.from_pretrained(model_id, compute_dtype=compute_dtype, device=device, residual_fp32=residual_fp32)
+            self.backbone = HipBertMLM.from_pretrained(model_id, compute_dtype=compute_dtype, device=device, residual_fp32=residual_fp32,
+                                                       fp8=fp8)
         if tokenizer_id is None and not isinstance(model_id, HipBertMLM):
             tokenizer_id = model_id
         self.tokenizer = _load_tokenizer(tokenizer_id)

@@ -156,7 +156,7 @@ class HipBertMLM(torch.nn.Module):
 
     def __init__(self, cfg: BertConfigLite, compute_dtype: torch.dtype = torch.bfloat16,
                  device: Optional[torch.device] = None, init_seed: Optional[int] = 0, with_head: bool = True,
-                 residual_fp32: Optional[bool] = None):
+                 residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None):
         super().__init__()
         self.config = cfg
         self.compute_dtype = compute_dtype
@@ -188,7 +188,14 @@ class HipBertMLM(torch.nn.Module):
         # [T, I] write).  SM_FWD_F16=0 / SM_FFN_FWD_F16=0|1 override.
         self.fwd_f16 = compute_dtype == torch.bfloat16 and self.residual_fp32 and os.environ.get("SM_FWD_F16", "1") != "0"
         deep = cfg.num_hidden_layers >= 10
-        self.ffn_fwd_f16 = (self.fwd_f16 and not self.fused_ffn and not self.pc_ffn
+        # fp8: the four encoder linears of every layer (QKV, attention output, FFN up / down) take fp8 operands -- e4m3 x e4m3 forward,
+        # e5m2 x e4m3 for their input gradients, per-tensor just-in-time scales (csrc/fp8.hip) -- as BASELINE configs[4] asks
+        # ("fp8 MFMA", config_kd.yaml:9-16).  Head, attention core, weight gradients, LayerNorms and the residual stream keep their
+        # types.  SM_FP8=1 or HipBertMLM(fp8=True); bf16 runs only.
+        self.fp8 = compute_dtype == torch.bfloat16 and (bool(fp8) if fp8 is not None else os.environ.get("SM_FP8", "0") == "1")
+        if self.fp8:
+            self.fused_ffn = self.pc_ffn = False
+        self.ffn_fwd_f16 = (self.fwd_f16 and not self.fused_ffn and not self.pc_ffn and not self.fp8
                             and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1")
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
@@ -284,9 +291,9 @@ class HipBertMLM(torch.nn.Module):
 
     @classmethod
     def from_pretrained(cls, model_dir: str, compute_dtype=torch.bfloat16, device=None, with_head=True,
-                        residual_fp32: Optional[bool] = None) -> "HipBertMLM":
+                        residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None) -> "HipBertMLM":
         cfg = BertConfigLite.from_json(os.path.join(model_dir, "config.json"))
-        model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head, residual_fp32=residual_fp32)
+        model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head, residual_fp32=residual_fp32, fp8=fp8)
         st = os.path.join(model_dir, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
@@ -395,9 +402,23 @@ class HipBertMLM(torch.nn.Module):
                       - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
             ops.ffn_pc_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
                              st["pc_w1f"], st["pc_w2f"], None, None)
+        if self.fp8:  # e4m3 copies of the encoder linears' weights (and of their transposes, for the input gradients) + scales
+            for l in range(cfg.num_hidden_layers):
+                for k in ("qkv", "o", "w1", "w2"):
+                    for key in (f"{k}{l}", f"{k}T{l}"):
+                        st[key + "_8"], st[key + "_8s"], _ = ops.quantize_fp8(st[key])
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
+    def _lin(self, a: Tensor, key: str, grad: bool = False, **epi) -> Tensor:
+        """epilogue(a . W^T) for the staged weight `key` of an encoder linear: bf16 / fp32 operands, or (self.fp8) `a` quantised here
+        to e4m3 (e5m2 when it is a gradient) against the staged e4m3 weight"""
+        st = self._staged
+        if self.fp8 and a.dtype == torch.bfloat16:
+            aq, sa, _ = ops.quantize_fp8(a, e5m2=grad)
+            return ops.gemm_nt(aq, st[key + "_8"], scale_a=sa, scale_b=st[key + "_8s"], **epi)
+        return ops.gemm_nt(a, st[key], **epi)
+
     @staticmethod
     def padded_len(S: int) -> int:
         for s in SUPPORTED_S:
@@ -449,9 +470,9 @@ class HipBertMLM(torch.nn.Module):
             d_at = self._drop(pa, training, seed, l + 1, _Site.ATTN)
             d_h1 = self._drop(ph, training, seed, l + 1, _Site.HID1)
             d_h2 = self._drop(ph, training, seed, l + 1, _Site.HID2)
-            qkv = ops.gemm_nt(x, st[f"qkv{l}"], bias=self.qkv_bias(l))
+            qkv = self._lin(x, f"qkv{l}", bias=self.qkv_bias(l))
             ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at, rag)
-            z1 = ops.gemm_nt(ctx, st[f"o{l}"], bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
+            z1 = self._lin(ctx, f"o{l}", bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
                              residual_ln=res_ln)
             if self.fused_ffn:  # LayerNorm 1 .. LayerNorm 2 in one launch; gelu(f1) is not stored (the fused backward re-creates it)
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
@@ -499,8 +520,8 @@ class HipBertMLM(torch.nn.Module):
                 z2 = ops.gemm_nt(gah, st[f"w2h{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=True, residual_ln=res1_ln)
                 ga = None
             else:
-                ga = ops.gemm_nt(x1, st[f"w1{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
-                z2 = ops.gemm_nt(ga, st[f"w2{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
+                ga = self._lin(x1, f"w1{l}", bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
+                z2 = self._lin(ga, f"w2{l}", bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
             if r32:
                 g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
                 last16 = self.fwd_f16 and l == cfg.num_hidden_layers - 1  # the head transform's fp16 operand
@@ -754,7 +775,7 @@ class _EncodeFn(torch.autograd.Function):
             else:
                 if ga is not None:
                     wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1)
+                    df1 = model._lin(a2, f"w2T{l}", grad=True, gelu_grad_of=f1)
                 else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
                     ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
                     df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)
@@ -762,38 +783,38 @@ class _EncodeFn(torch.autograd.Function):
                 wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
                 # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
                 # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
-                fused = ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                fused = None if model.fp8 else ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                            g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
                                            d_h1, want_drop=d_h1 is not None)
             if fused is not None:
                 dz1, dz1d = fused
             else:
-                dx1 = ops.gemm_nt(df1, st[f"w1T{l}"], residual=dz2)
+                dx1 = model._lin(df1, f"w1T{l}", grad=True, residual=dz2)
                 dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                               g(p + "attention.output.LayerNorm.weight"),
                                               g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
             a1 = dz1d if d_h1 is not None else dz1
             wg.run(a1, ctxt, g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias"))
-            dctx = ops.gemm_nt(a1, st[f"oT{l}"])
+            dctx = model._lin(a1, f"oT{l}", grad=True)
             dqkv = ops.attention_bwd(qkv, mask, ctxt, dctx, lse, B, S, A, d_at, rag)
             wg.run(dqkv, x, model.qkv_weight(l, grad=True), model.qkv_bias(l, grad=True))
             if l > 0:  # the QKV input gradient feeds the output LayerNorm of layer l-1: same fusion
                 pp = f"bert.encoder.layer.{l - 1}."
                 z2p, m2p, r2p = ctx.saved["layers"][l - 1][10:13]
                 d_h2p = model._drop(ph, training, seed, l, _Site.HID2)
-                pending = ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z2p, v(pp + "output.LayerNorm.weight"), m2p, r2p,
+                pending = None if model.fp8 else ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z2p, v(pp + "output.LayerNorm.weight"), m2p, r2p,
                                              g(pp + "output.LayerNorm.weight"), g(pp + "output.LayerNorm.bias"),
                                              d_h2p, want_drop=d_h2p is not None)
             dz0 = None
             if l == 0:  # ... and of the embedding LayerNorm (with the embedding dropout in between)
                 z0, m0, r0 = ctx.saved["emb"]
                 d_emb = model._drop(ph, training, seed, 0, _Site.EMB)
-                fused = ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z0, v(e + "LayerNorm.weight"), m0, r0,
+                fused = None if model.fp8 else ops.gemm_nt_ln_bwd(dqkv, st[f"qkvT{l}"], dz1, z0, v(e + "LayerNorm.weight"), m0, r0,
                                            g(e + "LayerNorm.weight"), g(e + "LayerNorm.bias"), dy_drop=d_emb)
                 if fused is not None:
                     dz0 = fused[0]
             if pending is None and dz0 is None:
-                dx = ops.gemm_nt(dqkv, st[f"qkvT{l}"], residual=dz1)
+                dx = model._lin(dqkv, f"qkvT{l}", grad=True, residual=dz1)
             if model._layer_hook is not None:
                 model._layer_hook(l, wg.mark())
         z0, m0, r0 = ctx.saved["emb"]

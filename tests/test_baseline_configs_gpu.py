@@ -56,7 +56,7 @@ def _elementwise(got, want, what):
 
 
 def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTION_INSIDE, elementwise=None, od_identical=None,
-                   oloss_identical=None):
+                   oloss_identical=None, frob=1e-2, loss_tol=1e-2):
     d = out["d_rep"].detach().float().cpu()
     worst, inside = _elementwise(d, od, what + " d_rep" + (" [kernel error: oracle on the staged (bf16-rounded) weights]" if od_identical is not None else ""))
     if dtype == torch.float32:
@@ -64,18 +64,18 @@ def _check_outputs(dtype, loss, oloss, out, oq, od, what, fraction_inside=FRACTI
         assert abs(float(loss.detach()) - float(oloss)) <= 1e-3 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
     else:
         rel = float((d - od.detach()).norm() / od.detach().norm())
-        assert rel <= 1e-2, f"{what}: d_rep relative Frobenius error {rel:.3e} > 1e-2"
+        assert rel <= frob, f"{what}: d_rep relative Frobenius error {rel:.3e} > {frob}"
         bound = ELEMENTWISE_BF16 if elementwise is None else elementwise
         assert worst <= bound, f"{what}: d_rep worst element {worst:.3e} > {bound} (1+|ref|)"
         assert inside >= fraction_inside, f"{what}: only {inside:.5f} of d_rep inside 1e-2 (1+|ref|)"
-        assert abs(float(loss.detach()) - float(oloss)) <= 1e-2 * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
+        assert abs(float(loss.detach()) - float(oloss)) <= loss_tol * (1 + abs(float(oloss))), (float(loss.detach()), float(oloss))
         if od_identical is not None:  # the north-star comparison: same fp32 checkpoint in, reference CPU arithmetic
             worst_i, inside_i = _elementwise(d, od_identical, what + " d_rep [IDENTICAL INPUTS: oracle on the unrounded fp32 weights]")
             assert worst_i <= bound, f"{what}: d_rep worst element {worst_i:.3e} > {bound} (1+|ref|) against the unrounded fp32 oracle"
             assert inside_i >= fraction_inside
             dl = abs(float(loss.detach()) - float(oloss_identical))
             print(f"[{what}] loss {float(loss.detach()):.6f}, oracle (unrounded weights) {float(oloss_identical):.6f}, oracle (staged weights) {float(oloss):.6f}")
-            assert dl <= 1e-2 * (1 + abs(float(oloss_identical))), (float(loss.detach()), float(oloss_identical))
+            assert dl <= loss_tol * (1 + abs(float(oloss_identical))), (float(loss.detach()), float(oloss_identical))
     if oq is not None:
         assert torch.equal(out["q_rep"].detach().cpu(), oq.detach()), "inference-free query encoding must be bit-exact"
 
@@ -93,7 +93,7 @@ BF16_GRAD_REL = 4e-2    # relative Frobenius error of a parameter gradient, bf16
 BF16_GRAD_REL_UNROUTED = 8e-2  # ... against the oracle's OWN arg-max routing (measured <= 3.8e-2; near-tied maxima that rounding resolves the other way move whole gradient rows)
 
 
-def _check_grads(dtype, bb, pr, what, pr_unrouted=None):
+def _check_grads(dtype, bb, pr, what, pr_unrouted=None, grad_rel=None):
     rep = _grad_report(bb, pr)
     unrouted = _grad_report(bb, pr_unrouted) if pr_unrouted is not None else None
     for n in GRAD_NAMES:
@@ -104,13 +104,14 @@ def _check_grads(dtype, bb, pr, what, pr_unrouted=None):
         else:
             extra = f", oracle's own arg-max routing {unrouted[n][0]:.3e}" if unrouted is not None else ""
             print(f"[{what}] grad {n}: rel Frobenius {rel:.3e} (maxima routed as on the device){extra}")
-            assert rel <= BF16_GRAD_REL, f"{what} grad {n}: relative Frobenius error {rel:.3e} > {BF16_GRAD_REL}"
-            if unrouted is not None:  # near-tied maxima that bf16 rounding resolves the other way move whole gradient rows
+            assert rel <= (grad_rel or BF16_GRAD_REL), f"{what} grad {n}: relative Frobenius error {rel:.3e} > {grad_rel or BF16_GRAD_REL}"
+            if unrouted is not None and grad_rel is None:  # near-tied maxima that bf16 rounding resolves the other way move whole gradient rows
                 assert unrouted[n][0] <= BF16_GRAD_REL_UNROUTED, f"{what} grad {n}: relative Frobenius error {unrouted[n][0]:.3e} against the un-routed oracle"
 
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
-                  residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True):
+                  residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True, fp8=False, fraction_inside=FRACTION_INSIDE,
+                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
@@ -129,7 +130,8 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
             p[n] = 0.02 * torch.randn(p[n].shape, generator=g)
         elif n.endswith("LayerNorm.weight"):
             p[n] = 1 + 0.05 * torch.randn(p[n].shape, generator=g)
-    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32, fp8=fp8)
+    assert bb.fp8 == bool(fp8)
     bb.load_hf_state_dict(p)
     idf = torch.exp(torch.rand(V, generator=g) * 6.6 - 3.9)  # log-uniform in [0.02, 15.6] like idf.json
     use_l0 = bool(recipe.get("use_l0", False))
@@ -197,9 +199,11 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     rows = inp["docs"][0]["packed"].rag.rows if inp["docs"][0].get("packed") is not None else nq * k * S
     print(f"[{what}] oracle {time.time() - t0:.1f} s, {rows} token rows on the device")
     _check_outputs(dtype, loss, oloss, out, oq, od_free, what, elementwise=elementwise, od_identical=od_identical,
-                   oloss_identical=oloss_identical)
+                   oloss_identical=oloss_identical, fraction_inside=fraction_inside, frob=frob, loss_tol=loss_tol)
     if check_grads:
-        _check_grads(dtype, bb, pr, what, pr_unrouted)
+        _check_grads(dtype, bb, pr, what, pr_unrouted, grad_rel)
+    if ret is not None:
+        ret.update(d_rep=out["d_rep"].detach().float().cpu(), docs=d, params=p, oracle_rep=od_identical, shape=oc)
     return trainer, bb
 
 
@@ -237,7 +241,7 @@ def test_c3_config_l0_recipe_on_the_c2_slice():
 
 
 def test_c5_kd_precomputed_scores_bert_base_seq512_gradient_caching():
-    """BASELINE.json configs[4] (bf16 operands: this build has no fp8 GEMMs): bert-base student, documents of up to 512 tokens,
+    """BASELINE.json configs[4] with bf16 operands (the fp8 variant the config names is the next test): bert-base student, documents of up to 512 tokens,
     KL distillation on precomputed teacher scores (per-query pairs), rep-level gradient caching in chunks of 4 documents --
     1 query x 8 documents against the oracle (config_kd.yaml:9-16 with data_type kd; sparse_encoders.py:107-119)"""
     KD = dict(loss_types=["kldiv"], use_in_batch_negatives=False, flops_d_lambda=0.002, flops_d_T=200)
@@ -245,6 +249,42 @@ def test_c5_kd_precomputed_scores_bert_base_seq512_gradient_caching():
     scores = torch.rand(1, 8, generator=g) * 30
     _student_step(BASE, torch.bfloat16, nq=1, k=8, S=512, Sq=32, recipe=KD, seed=5, teacher_scores=scores, what="c5 slice",
                   grad_cache_chunk=4)
+
+
+FP8_ELEMENTWISE = 2.5e-1   # worst element of rep, in units of (1 + |ref|): the CPU emulation of the same arithmetic (per-tensor e4m3 operands in
+FP8_FROB = 6e-2            # the four encoder linears of each of the 12 layers, tools/fp8_error_budget.py) measures 1.2e-1 - 1.3e-1 worst,
+FP8_INSIDE_5E2 = 0.98      # 2.8e-2 - 2.9e-2 relative Frobenius, 99.4 - 99.5 % of the elements inside 5e-2: the bounds are 2x those
+
+
+def test_c5_fp8_operands_in_the_encoder_linears():
+    """BASELINE.json configs[4] AS NAMED ("fp8 MFMA"): the c5 slice above with e4m3 x e4m3 forward and e5m2 x e4m3 input-gradient
+    operands in the QKV / attention-output / FFN-up / FFN-down GEMMs (per-tensor just-in-time scales; head, attention core and
+    weight gradients stay bf16).  fp8 is outside the north star's 1e-2 by construction; the tolerance is what the format costs,
+    measured by a CPU emulation of the same arithmetic on the same inputs: the HIP result must be (a) inside 2x the emulation's
+    distance from the fp32 oracle and (b) as close to the emulation as two fp8 evaluations with different summation orders are."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fp8_error_budget import encode_fp8
+    KD = dict(loss_types=["kldiv"], use_in_batch_negatives=False, flops_d_lambda=0.002, flops_d_T=200)
+    g = torch.Generator().manual_seed(77)
+    scores = torch.rand(1, 8, generator=g) * 30
+    ret = {}
+    _student_step(BASE, torch.bfloat16, nq=1, k=8, S=512, Sq=32, recipe=KD, seed=5, teacher_scores=scores, what="c5 slice, fp8 operands",
+                  grad_cache_chunk=4, fp8=True, elementwise=FP8_ELEMENTWISE, fraction_inside=0.5, frob=FP8_FROB, loss_tol=5e-2, grad_rel=0.35,
+                  unrouted_grads=False, ret=ret)
+    d, ref, got = ret["docs"], ret["oracle_rep"], ret["d_rep"]
+    with torch.no_grad():
+        emu = O.sparse_activation(encode_fp8(ret["params"], d["input_ids"], d["attention_mask"], ret["shape"]), d["attention_mask"])
+    e_emu = (emu - ref).abs() / (1 + ref.abs())
+    e_hip = (got - ref).abs() / (1 + ref.abs())
+    between = float((got - emu).norm() / emu.norm())
+    print(f"[c5 slice, fp8] against the fp32 oracle: HIP worst {float(e_hip.max()):.3e}, inside 5e-2 {100 * float((e_hip <= 5e-2).float().mean()):.3f} %, "
+          f"rel Frobenius {float((got - ref).norm() / ref.norm()):.3e} | CPU emulation worst {float(e_emu.max()):.3e}, inside 5e-2 "
+          f"{100 * float((e_emu <= 5e-2).float().mean()):.3f} %, rel Frobenius {float((emu - ref).norm() / ref.norm()):.3e} | HIP against the "
+          f"emulation: rel Frobenius {between:.3e}")
+    assert float((e_hip <= 5e-2).float().mean()) >= FP8_INSIDE_5E2
+    assert float(e_hip.max()) <= 2 * float(e_emu.max()) and float((got - ref).norm()) <= 2 * float((emu - ref).norm())
+    assert between <= FP8_FROB
 
 
 def test_c4_kd_ensemble_bert_base_student_two_teachers_seq256():
