@@ -1532,7 +1532,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     constexpr int nt192_mink = 1024;
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
-    const bool nt192_shape = (N == NB_C && nt192_items <= 256) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
+    const bool nt192_shape = (N == NB_C && nt192_items <= 512) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
     if (nt192 && nt192_shape && nt192_types_ok && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
       auto kern = is_f16 ? gemm_nt192_kernel<false, 0, true> : gemm_nt192_kernel<false, 0, false>;
@@ -1663,7 +1663,7 @@ extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* 
   // (at K = 384 the 192 x 384 tile is ~8 % slower than the 128 x 128 GEMM, but the LayerNorm-backward launch it absorbs
   // costs more than the whole GEMM)
   constexpr int mink = 384;
-  if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 256) return 1;
+  if (!fuse || dtype != SM_BF16 || N != NB_C || K < mink || K % 32 != 0 || M < 32 * NB_R || sm_cdiv(M, NB_R) > 512) return 1;
   const uintptr_t al = (uintptr_t)A | (uintptr_t)B | (uintptr_t)residual | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_drop |
                        (uintptr_t)gamma;
   if ((al % 16) != 0 || (lda % 8) != 0 || (ldb % 8) != 0) return 1;
