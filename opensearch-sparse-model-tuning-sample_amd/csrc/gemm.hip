@@ -158,7 +158,10 @@ constexpr int GL_STAGE = 128 * 64;  // bytes per operand per stage
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename T>
+// WM = rows of waves: 2 -> a 128-row A tile, 4 waves, every wave loads two 16-row pieces of A and two of B per stage; 4 -> a
+// 256-row A tile, 8 waves, two pieces of A and ONE of B per wave and stage (3 LDS-DMA instructions for twice the MFMAs: at K = 384
+// the CU's global -> LDS path, ~36 B/clk, bounds the 128 x 128 tile at 64 flop/B; 256 x 128 gives 85 flop/B)
+template <typename T, int WM = 2>
 __device__ __forceinline__ void glds_issue(const T* __restrict__ A, int lda, int M, int m0, const T* __restrict__ B, int ldb,
                                            int N, int n0, int k0, char* sa, char* sb, int w, int lane) {
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -167,9 +170,15 @@ __device__ __forceinline__ void glds_issue(const T* __restrict__ A, int lda, int
     const int piece = w * 2 + p;
     const int row = piece * 16 + (lane >> 2);
     const int lchunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
-    const int ra = min(m0 + row, M - 1), rb = min(n0 + row, N - 1);
+    const int ra = min(m0 + row, M - 1);
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + (size_t)ra * lda + k0 + lchunk * EPC), (lds_void_t*)(sa + piece * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (size_t)rb * ldb + k0 + lchunk * EPC), (lds_void_t*)(sb + piece * 1024), 16, 0, 0);
+    if (WM == 2 || p == 0) {
+      const int pb = WM == 2 ? piece : w;
+      const int rowb = pb * 16 + (lane >> 2);
+      const int lcb = (lane & 3) ^ ((0 - (rowb >> 2)) & 3);
+      const int rb = min(n0 + rowb, N - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (size_t)rb * ldb + k0 + lcb * EPC), (lds_void_t*)(sb + pb * 1024), 16, 0, 0);
+    }
   }
 }
 
@@ -202,15 +211,24 @@ template <> struct GlFrag<float> {
 
 // smem >= 2 * NST * GL_STAGE; K % BK == 0.  NST = 4: three stages in flight (64 KiB);
 // NST = 3: two in flight (48 KiB, lets three workgroups share a CU)
-template <typename T, int NST = GL_NSTAGE>
+// -DNT_STAMPS: shader-clock stamps of one workgroup of gemm_nt_kernel (tools/gemm_nt_stamps.py); nothing in a normal build
+#ifdef NT_STAMPS
+__device__ unsigned long long nt_stamps[64];
+#define NT_STAMP(IDX) do { if (blockIdx.x == 1 && blockIdx.y == 40 && threadIdx.x == 0 && (IDX) < 64) nt_stamps[IDX] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT_STAMP(IDX) do { } while (0)
+#endif
+
+template <typename T, int NST = GL_NSTAGE, int WM = 2>
 __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int lda, int M, int m0,
                                                  const T* __restrict__ B, int ldb, int N, int n0, int K,
                                                  char* smem, f32x4 acc[4][4]) {
   using MM = Mma<T>;
   using GF = GlFrag<T>;
   constexpr int BK = GF::BK;
+  constexpr int A_STAGE = WM * 64 * 64;  // bytes of an A stage (GL_STAGE for the 128-row tile)
   char* const sA = smem;
-  char* const sB = smem + NST * GL_STAGE;
+  char* const sB = smem + NST * A_STAGE;
   const int nk = K / BK;
   // readfirstlane makes the wave id provably uniform: the LDS-DMA base goes to M0 without a
   // per-load waterfall loop (v_readfirstlane / s_and_saveexec retry sequence)
@@ -218,20 +236,27 @@ __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int ld
   const int wm = w >> 1, wn = w & 1, g = lane >> 4, li = lane & 15;
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, s * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
+    if (s < nk) glds_issue<T, WM>(A, lda, M, m0, B, ldb, N, n0, s * BK, sA + s * A_STAGE, sB + s * GL_STAGE, w, lane);
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; the (up to two) younger stages stay in flight: 4 loads per stage and wave
+    // stage kt must have landed; the (up to two) younger stages stay in flight: 4 (WM = 4: 3) loads per stage and wave
     const int younger = min(NST - 2, nk - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (WM == 2) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // every wave's pieces landed; stage (kt-1) % NSTAGE is free again
     asm volatile("" ::: "memory");
+    NT_STAMP(4 + kt);
     if (kt + NST - 1 < nk) {
       const int s = (kt + NST - 1) % NST;
-      glds_issue<T>(A, lda, M, m0, B, ldb, N, n0, (kt + NST - 1) * BK, sA + s * GL_STAGE, sB + s * GL_STAGE, w, lane);
+      glds_issue<T, WM>(A, lda, M, m0, B, ldb, N, n0, (kt + NST - 1) * BK, sA + s * A_STAGE, sB + s * GL_STAGE, w, lane);
     }
-    const char* a = sA + (kt % NST) * GL_STAGE;
+    const char* a = sA + (kt % NST) * A_STAGE;
     const char* b = sB + (kt % NST) * GL_STAGE;
 #pragma unroll
     for (int ks = 0; ks < GF::NS; ++ks) {
@@ -370,26 +395,31 @@ __device__ __forceinline__ void load_ggo8(const T* ggo, bool tiled, size_t off, 
 }
 
 // T: type of C and of every epilogue tensor; OP: operand type of the main loop (T, or an fp8 tag with T = bf16)
-template <typename T, bool GLDS, typename OP = T>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const OP* __restrict__ A, int lda, const OP* __restrict__ B, int ldb,
+// WM: rows of waves (2: the 128 x 128 tile, 256 threads; 4: a 256 x 128 tile, 512 threads, GLDS only -- see glds_issue)
+template <typename T, bool GLDS, typename OP = T, int WM = 2>
+__global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict__ A, int lda, const OP* __restrict__ B, int ldb,
                                                            T* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e) {
-  // LDS: the glds variant uses a 3-stage ring (48 KiB) and stages the epilogue in two 64-row halves
-  // (33 KiB), so three workgroups fit a CU and their main loops cover each other's epilogues
+  // LDS: the glds variant uses a 3-stage ring (48 KiB; 72 KiB for the 256-row tile) and stages the epilogue in 64-row passes
+  // (33 KiB), so three (two) workgroups fit a CU and their main loops cover each other's epilogues
   constexpr int NT_NST = 3;
-  constexpr int SMEM_GLDS = 2 * NT_NST * GL_STAGE, SMEM_REG = 4 * TILE_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[GLDS ? SMEM_GLDS : SMEM_REG];
-  static_assert(64 * CS * 4 <= SMEM_GLDS, "epilogue half tile must fit the ring");
+  constexpr int BMT = WM * 64;
+  constexpr int SMEM_GLDS = NT_NST * (BMT * 64 + GL_STAGE);  // (register-staged loop: 4 * TILE_BYTES)
+  static_assert(GLDS || WM == 2, "the register-staged loop has the 128-row tile only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // GLDS ? SMEM_GLDS : SMEM_REG (nt_smem_bytes)
+  static_assert(64 * CS * 4 <= SMEM_GLDS, "epilogue pass must fit the ring");
   int mt, nt;
-  xcd_tile((M + BM - 1) / BM, gridDim.x, 1, mt, nt, e.xcd);
+  xcd_tile((M + BMT - 1) / BMT, gridDim.x, 1, mt, nt, e.xcd);
   if (mt < 0) return;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BMT, n0 = nt * BN;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (GLDS) nt_mainloop_glds<OP, NT_NST>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  NT_STAMP(0);
+  if constexpr (GLDS) nt_mainloop_glds<OP, NT_NST, WM>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
   else nt_mainloop<T>(A, lda, M, m0, B, ldb, N, n0, K, smem, acc);
+  NT_STAMP(1);
   if constexpr (!std::is_same<OP, T>::value) {  // fp8: dequantise (per-tensor scales, device scalars)
     const float alpha = *e.scale_a * *e.scale_b;
 #pragma unroll
@@ -417,7 +447,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const OP* __restrict_
 #pragma unroll
   for (int k = 0; k < 8; ++k) bv[k] = (e.bias && col + k < N) ? e.bias[col + k] : 0.f;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < WM; ++half) {  // one wave row (64 tile rows) per pass
     if (half) __syncthreads();  // first half fully read before it is overwritten
     if (wm == half) {
 #pragma unroll
@@ -430,8 +460,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const OP* __restrict_
     __syncthreads();
     if (col < N) {
 #pragma unroll 2
-      for (int it = 0; it < 4; ++it) {
-        const int rt = r0 + 16 * it, row = m0 + half * 64 + rt;
+      for (int it = 0; it < 8 / WM; ++it) {
+        const int rt = r0 + 8 * WM * it, row = m0 + half * 64 + rt;
         if (row >= M) break;
         const size_t off = (size_t)row * ldc + col;
         float v[8];
@@ -484,6 +514,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(const OP* __restrict_
         else store8<T>(C + off, v, full, N - col);
       }
     }
+    NT_STAMP(2 + half);
   }
 }
 
@@ -1542,12 +1573,29 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
       return 0;
     }
   }
-  dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   constexpr int glds_on = 1;
+  if constexpr (sizeof(T) == 2) {
+    // 256 x 128 tiles (8 waves), OPT-IN (SM_NT256=1): measured SLOWER than the 128 x 128 tile where it was expected to pay
+    // (K = 384, 43.9 k rows: N = 1152 89 vs 74 us, N = 1536 163 vs 143 us; N = 384 40.6 vs 41.6 us) -- a workgroup's timeline
+    // (tools/gemm_nt_stamps.py) is one third epilogue, and two 72-KiB workgroups per CU cover each other's epilogues worse than
+    // three 48-KiB ones do
+    static const int nt256 = getenv("SM_NT256") ? atoi(getenv("SM_NT256")) : 0;
+    if (glds_on && nt256 && (long)sm_cdiv(M, 256) * sm_cdiv(N, BN) >= 1024) {
+      constexpr int smem256 = 3 * (256 * 64 + GL_STAGE);
+      auto kern = gemm_nt_kernel<T, true, T, 4>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem256);
+      dim3 grid256(sm_cdiv(N, BN), (sm_cdiv(M, 256) + 7) / 8 * 8);
+      hipLaunchKernelGGL(kern, grid256, dim3(512), smem256, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+      return 0;
+    }
+  }
+  dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   if (glds_on)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(NTHREADS), 2 * 3 * GL_STAGE, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N,
+                       K, e);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M, N, K, e);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(NTHREADS), 4 * TILE_BYTES, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M,
+                       N, K, e);
   return 0;
 }
 
@@ -1624,12 +1672,16 @@ int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, 
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
-  hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 0, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
+  hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 2 * 3 * GL_STAGE, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
                      K, e);
   return 0;
 }
 
 }  // namespace
+
+#ifdef NT_STAMPS
+extern "C" int sm_nt_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nt_stamps), sizeof(nt_stamps)); }
+#endif
 
 extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                           int K, const sm_epilogue* epi, void* stream) {

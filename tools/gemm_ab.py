@@ -13,17 +13,20 @@ def timeit(f, n=30):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-T = 43904
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 43904
 x = torch.randn(T, 384, device='cuda').bfloat16()
 out = []
-for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536)):
+for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536), ("attn_out", 384), ("dctx", 384)):
     W = torch.randn(N, 384, device='cuda').bfloat16() * 0.02
     b = torch.zeros(N, device='cuda')
     f1 = torch.randn(T, N, device='cuda').bfloat16()
     pre = torch.empty(T, N, device='cuda', dtype=torch.bfloat16)
-    if name == "qkv": f = lambda: ops.gemm_nt(x, W, bias=b)
+    if name == "attn_out":
+        res = torch.randn(T, N, device='cuda'); f = lambda: ops.gemm_nt(x, W, bias=b, residual=res, out_f32=True)
+    elif name == "dctx": f = lambda: ops.gemm_nt(x, W)
+    elif name == "qkv": f = lambda: ops.gemm_nt(x, W, bias=b)
     elif name == "ffn_up": f = lambda: ops.gemm_nt(x, W, bias=b, act=1, preact=pre)
     else: f = lambda: ops.gemm_nt(x, W, gelu_grad_of=f1)
     us = timeit(f)
     out.append(f"{name} N={N}: {us:.1f} us ({2*T*N*384/us/1e6:.0f} TF/s)")
-print(os.environ.get("SM_LIB", "default"), " | ".join(out))
+print(os.environ.get("SM_LIB", "default"), "SM_NT256=" + os.environ.get("SM_NT256", "1"), f"T={T}", " | ".join(out))
