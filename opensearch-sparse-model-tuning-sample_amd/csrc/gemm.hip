@@ -448,7 +448,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
   for (int k = 0; k < 8; ++k) bv[k] = (e.bias && col + k < N) ? e.bias[col + k] : 0.f;
 #pragma unroll
   for (int half = 0; half < WM; ++half) {  // one wave row (64 tile rows) per pass
-    if (half) __syncthreads();  // first half fully read before it is overwritten
+    // LDS-only barriers: __syncthreads() also waits for the previous pass's GLOBAL stores (vmcnt(0)), ~3 k cycles of write latency
+    // per pass that nothing here depends on
+    if (half) {  // first half fully read before it is overwritten
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -457,7 +463,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
 #pragma unroll
           for (int r = 0; r < 4; ++r) sC[(i * 16 + g * 4 + r) * CS + wn * 64 + j * 16 + li] = acc[i][j][r];
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NT_STAMP(20 + 8 * half);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    NT_STAMP(21 + 8 * half);
     if (col < N) {
 #pragma unroll 2
       for (int it = 0; it < 8 / WM; ++it) {
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
         }
         if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);
         else store8<T>(C + off, v, full, N - col);
+        NT_STAMP(22 + 8 * half + it);
       }
     }
     NT_STAMP(2 + half);

@@ -37,3 +37,5 @@ k = lambda i: (st[i] - st[0]) / 1000.0
 print(f"[{T} x {N} x {K}] {e0.elapsed_time(e1) * 50:.1f} us per launch; kilo-cycles since the workgroup's start (block (1, 40), thread 0)")
 print("  k-step barriers passed: " + " ".join(f"{k(4 + i):.2f}" for i in range(K // 32)))
 print(f"  main loop done {k(1):.2f}  epilogue half 0 done {k(2):.2f}  half 1 done {k(3):.2f}")
+for h in range(2):
+    print(f"  pass {h}: staged {k(20 + 8 * h):.2f}  barrier passed {k(21 + 8 * h):.2f}  row groups stored " + " ".join(f"{k(22 + 8 * h + i):.2f}" for i in range(4)))
