@@ -1586,12 +1586,15 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   }
   constexpr int glds_on = 1;
   if constexpr (sizeof(T) == 2) {
-    // 256 x 128 tiles (8 waves), OPT-IN (SM_NT256=1): measured SLOWER than the 128 x 128 tile where it was expected to pay
+    // 256 x 128 tiles (8 waves), a BUILD option (-DSM_NT256=1; the library reads no environment): measured SLOWER than the 128 x 128 tile where it was expected to pay
     // (K = 384, 43.9 k rows: N = 1152 89 vs 74 us, N = 1536 163 vs 143 us; N = 384 40.6 vs 41.6 us) -- a workgroup's timeline
     // (tools/gemm_nt_stamps.py) is one third epilogue, and two 72-KiB workgroups per CU cover each other's epilogues worse than
     // three 48-KiB ones do
-    static const int nt256 = getenv("SM_NT256") ? atoi(getenv("SM_NT256")) : 0;
-    if (glds_on && nt256 && (long)sm_cdiv(M, 256) * sm_cdiv(N, BN) >= 1024) {
+#ifndef SM_NT256
+#define SM_NT256 0
+#endif
+    constexpr bool nt256 = SM_NT256 != 0;
+    if (bool(glds_on) && nt256 && (long)sm_cdiv(M, 256) * sm_cdiv(N, BN) >= 1024) {
       constexpr int smem256 = 3 * (256 * 64 + GL_STAGE);
       auto kern = gemm_nt_kernel<T, true, T, 4>;
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem256);

@@ -29,4 +29,4 @@ for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536), ("att
     else: f = lambda: ops.gemm_nt(x, W, gelu_grad_of=f1)
     us = timeit(f)
     out.append(f"{name} N={N}: {us:.1f} us ({2*T*N*384/us/1e6:.0f} TF/s)")
-print(os.environ.get("SM_LIB", "default"), "SM_NT256=" + os.environ.get("SM_NT256", "0"), f"T={T}", " | ".join(out))
+print(os.environ.get("SM_LIB", "default"), f"T={T}", " | ".join(out))

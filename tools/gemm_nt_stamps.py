@@ -19,7 +19,6 @@ out = torch.empty(T, N, device="cuda", dtype=torch.bfloat16)
 bias = torch.zeros(N, device="cuda")
 epi = L.SmEpilogue(L.ptr(bias), 0, None, L.dropout(), None, None, 0, 0, None, None, None, None, None, 0, None, None)
 P = lambda t: C.c_void_p(L.ptr(t))
-os.environ["SM_NT256"] = "0"
 args = [C.c_int(L.SM_BF16), P(x), C.c_int(K), P(W), C.c_int(K), P(out), C.c_int(N), C.c_int(T), C.c_int(N), C.c_int(K), C.byref(epi),
         C.c_void_p(torch.cuda.current_stream().cuda_stream)]
 for _ in range(3):
