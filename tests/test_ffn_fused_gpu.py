@@ -342,3 +342,52 @@ def test_gemm_reads_tile_major_gelu_grad_of(ops, T, N, K):
     want = ops.gemm_nt(a, b, gelu_grad_of=f1, gelu_out=ga0)
     got = ops.gemm_nt(a, b, gelu_grad_of=_f1_tiles(f1, N), gelu_out=ga1, gelu_grad_tiled=True)
     assert torch.equal(want, got) and torch.equal(ga0, ga1)
+
+
+@pytest.mark.gpu
+def test_ffn_pc_forward_dropout_mask_is_the_unfused_kernels(ops):
+    """the producer / consumer kernel's hidden dropout (hf:349) uses the GEMM epilogue's hash on the same element index: the unfused
+    backward (dropout_bwd / the dz2 GEMM epilogue) then masks exactly the elements the fused forward dropped"""
+    from sparse_hip import lib as L
+    T = 2048 + 16
+    w1, w2 = _weights(seed=3)
+    w1f, w2f, _, _ = _stage_pc(ops, w1, w2, torch.float16)
+    z1 = _rnd(T, H, seed=21)
+    one, zero = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
+    bias1, bias2 = torch.zeros(I, device="cuda"), torch.zeros(H, device="cuda")
+    drop = L.dropout(0.1, 1234, 7)
+    a = ops.ffn_pc_fwd(z1, one, zero, 1e-12, w1f[0], bias1, w2f[0], bias2, one, zero, drop, save_f1=True)
+    plain = ops.ffn_pc_fwd(z1, one, zero, 1e-12, w1f[0], bias1, w2f[0], bias2, one, zero, None, save_f1=True)
+    lin_d, lin = a[4] - _ln(z1, one, zero)[0], plain[4] - _ln(z1, one, zero)[0]
+    big = lin.abs() > 1e-2
+    dropped = lin_d.abs() < 1e-5
+    frac = float(dropped[big].float().mean())
+    assert 0.08 < frac < 0.125, frac
+    kept = ~dropped & big
+    assert float((lin_d[kept] / lin[kept] - 256.0 / 230.0).abs().max()) < 2e-3
+    bf = torch.bfloat16
+    ref = ops.gemm_nt(torch.zeros(T, 64, dtype=bf, device="cuda"), torch.zeros(H, 64, dtype=bf, device="cuda"),
+                      bias=torch.ones(H, device="cuda"), drop=drop)
+    assert torch.equal((ref.float() == 0)[big], dropped[big]), "fused and unfused dropout masks differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inter", [128, 256, 3072])
+def test_ffn_pc_forward_other_intermediate_sizes(ops, inter):
+    """4, 8 and 96 chunks of 32 intermediate columns (the ring prologue covers three): same check as at I = 1536"""
+    T = 400
+    w1, w2 = _weights(seed=inter, inter=inter)
+    w1f, w2f, _, _ = _stage_pc(ops, w1, w2, torch.float16)
+    z1 = _rnd(T, H, seed=5)
+    g1, b1, g2, b2 = (1 + 0.05 * _rnd(H, seed=1), 0.05 * _rnd(H, seed=2), 1 + 0.05 * _rnd(H, seed=3), 0.05 * _rnd(H, seed=4))
+    bias1, bias2 = 0.05 * _rnd(inter, seed=6), 0.05 * _rnd(H, seed=7)
+    out = ops.ffn_pc_fwd(z1, g1, b1, 1e-12, w1f[0], bias1, w2f[0], bias2, g2, b2, None, save_f1=True)
+    assert out is not None
+    x1, m1, r1 = _ln(z1, g1, b1)
+    f1 = x1.to(torch.float16).float() @ w1[0].to(torch.float16).float().t() + bias1
+    ga = torch.nn.functional.gelu(f1).to(torch.float16).float()
+    z2 = ga @ w2[0].to(torch.float16).float().t() + bias2 + x1
+    x2 = _ln(z2, g2, b2)[0]
+    assert float((_f1_rows(out[3], T).float() - f1).abs().max() / (1 + f1.abs().max())) < 1e-2
+    assert float((out[4] - z2).abs().max() / (1 + z2.abs().max())) < 4e-3
+    assert float((out[5].float() - x2).abs().max() / (1 + x2.abs().max())) < 1e-2
