@@ -8,9 +8,12 @@ MS-MARCO triples, bs=32 x (1 pos + 15 negs), seq 128, bf16, dropout on, fused Ad
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one optimisation step over one batch per rank; batches are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line (contract in the task statement) with
-two extra objects: "roofline" (dominant kernel, timed live with HIP events on the launch
-stream) and "cpu_baseline" (the CPU oracle timed on a bounded sample; N=1 only).
+before the timed region.  `value` is measured on the DENSE layout (every padded token row
+computed; the ragged rate the product's trainer runs at is reported beside it).  Rank 0 prints
+ONE JSON line (contract in the task statement) with two extra objects: "roofline" (the step's
+dominant kernel class, the encoder GEMMs, timed live with HIP events on the streams they run
+on; the fused head forward under "roofline_head_fwd") and "cpu_baseline" (the CPU oracle timed
+at the full configs[1] shape, 2 steps; N=1 only).
 """
 import argparse
 import json
