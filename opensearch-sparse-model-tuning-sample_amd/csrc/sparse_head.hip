@@ -559,13 +559,17 @@ extern "C" int sm_flops_bwd(const float* rep, const float* colmean, const float*
   return SM_OK;
 }
 
+// csrc/scores_mfma.hip: the all-pairs products on the matrix pipe (fp32 MFMA); false = shape left to the scalar kernels here
+bool sm_scores_mfma_fwd(const float* q, const float* d, int nq, int nd, int D, float* scores, hipStream_t st);
+bool sm_scores_mfma_wsum(const float* w, long ws_i, long ws_j, const float* x, int ni, int nj, int D, float* out, int accumulate, hipStream_t st);
+
 extern "C" int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pairs, float* scores, void* stream) {
   SM_REQUIRE(nq > 0 && nd > 0 && D > 0, "sm_scores_fwd: empty problem");
   hipStream_t st = (hipStream_t)stream;
   if (pairs) {
     SM_REQUIRE(nd % nq == 0, "sm_scores_fwd: nd=%d must be a multiple of nq=%d", nd, nq);
     hipLaunchKernelGGL(scores_pairs_kernel, dim3(sm_cdiv(nd, 4)), dim3(256), 0, st, q, d, nq, nd / nq, D, scores);
-  } else {
+  } else if (!sm_scores_mfma_fwd(q, d, nq, nd, D, scores, st)) {
     hipLaunchKernelGGL(scores_all_kernel, dim3(sm_cdiv(nd, 16), sm_cdiv(nq, 16)), dim3(256), 0, st, q, d, nq, nd, D, scores);
   }
   SM_LAUNCH_CHECK();
@@ -580,8 +584,10 @@ extern "C" int sm_scores_bwd(const float* q, const float* d, const float* ds, in
     SM_REQUIRE(nd % nq == 0, "sm_scores_bwd: nd=%d must be a multiple of nq=%d", nd, nq);
     hipLaunchKernelGGL(scores_pairs_bwd_kernel, dim3(sm_cdiv(D, 256), nq), dim3(256), 0, st, q, d, ds, nq, nd / nq, D, dq, dd, accumulate);
   } else {
-    if (dq) hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nq, 16)), dim3(256), 0, st, ds, (long)nd, 1L, d, nq, nd, D, dq, accumulate);
-    if (dd) hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nd, 16)), dim3(256), 0, st, ds, 1L, (long)nd, q, nd, nq, D, dd, accumulate);
+    if (dq && !sm_scores_mfma_wsum(ds, (long)nd, 1L, d, nq, nd, D, dq, accumulate, st))
+      hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nq, 16)), dim3(256), 0, st, ds, (long)nd, 1L, d, nq, nd, D, dq, accumulate);
+    if (dd && !sm_scores_mfma_wsum(ds, 1L, (long)nd, q, nd, nq, D, dd, accumulate, st))
+      hipLaunchKernelGGL(wsum_rows_kernel, dim3(sm_cdiv(D, 256), sm_cdiv(nd, 16)), dim3(256), 0, st, ds, 1L, (long)nd, q, nd, nq, D, dd, accumulate);
   }
   SM_LAUNCH_CHECK();
   return SM_OK;

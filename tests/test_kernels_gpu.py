@@ -751,3 +751,25 @@ def test_gemm_nt_fp8_operands(ops, M, N, K, grad):
         res = torch.randn(M, N, device="cuda", generator=g)
         z = ops.gemm_nt(qa, qb, bias=bias, residual=res, out_f32=True, scale_a=sa, scale_b=sb)
         assert float((z.double() - (wpre + res.double())).abs().max() / (scale + 4)) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nd", [(256, 1024), (70, 333), (32, 512)])
+def test_scores_on_the_matrix_pipe(ops, nq, nd):
+    """all-pairs score matrix and its backward for DENSE queries through the fp32-MFMA kernels (csrc/scores_mfma.hip: split over
+    V with fp32 atomics / NN form), V = 30522 (rows 8-byte aligned only, tail of 26 columns): against fp64 products at 1e-4 of the
+    largest element -- loss.py:33-37, :94-98"""
+    D = 30522
+    g = torch.Generator(device="cuda").manual_seed(nq)
+    q = torch.relu(torch.randn(nq, D, device="cuda", generator=g) - 1.0)
+    d = torch.relu(torch.randn(nd, D, device="cuda", generator=g) - 0.5)
+    s = ops.scores_fwd(q, d, False)
+    want = q.double() @ d.double().t()
+    assert float((s.double() - want).abs().max() / want.abs().max()) < 1e-4
+    ds = torch.randn(nq, nd, device="cuda", generator=g)
+    dq, dd_ = torch.zeros(nq, D, device="cuda"), torch.full((nd, D), 0.5, device="cuda")
+    ops.scores_bwd(q, d, ds, False, dq, None, False)
+    ops.scores_bwd(q, d, ds, False, None, dd_, True)   # accumulate into 0.5
+    wq, wd = ds.double() @ d.double(), ds.double().t() @ q.double() + 0.5
+    assert float((dq.double() - wq).abs().max() / wq.abs().max()) < 1e-4
+    assert float((dd_.double() - wd).abs().max() / wd.abs().max()) < 1e-4
