@@ -19,6 +19,7 @@ constexpr int TILE_BYTES = 128 * 128;  // one operand stage
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
+  static constexpr bool FP8 = false;
   static constexpr int KSTEP = 32, BK = 64;
   using Frag = bf16x8;
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
@@ -31,6 +32,7 @@ template <> struct Mma<bf16> {
   }
 };
 template <> struct Mma<f16> {
+  static constexpr bool FP8 = false;
   static constexpr int KSTEP = 32, BK = 64;
   using Frag = f16x8;
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
@@ -47,21 +49,35 @@ template <> struct Mma<f16> {
 struct fp8_op { uint8_t v; };    // A e4m3, B e4m3 (forward)
 struct bf8fp8_op { uint8_t v; }; // A e5m2 (a gradient), B e4m3 (input-gradient GEMMs)
 typedef long i64x2 __attribute__((ext_vector_type(2)));
+// K % 128 == 0 (every encoder linear): the fragments of TWO consecutive stage rows feed one v_mfma_f32_16x16x128_f8f6f4 (32 bytes
+// per lane and operand, 65536 FLOP in the time the legacy instruction pair above does 32768: the fp8 rate of the chip); cbsz picks
+// A's format (0 e4m3, 1 e5m2), B is e4m3, the block scales are unused (non-scaled opcode)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int CBSZ> __device__ __forceinline__ f32x4 mma_f8_k128(i64x2 a0, i64x2 a1, i64x2 b0, i64x2 b1, f32x4 c) {
+  struct P { i64x2 lo, hi; };
+  const i32x8 a = __builtin_bit_cast(i32x8, P{a0, a1}), b = __builtin_bit_cast(i32x8, P{b0, b1});
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, CBSZ, 0, 0, 0, 0, 0);
+}
 template <> struct Mma<fp8_op> {
   using Frag = i64x2;
+  static constexpr bool FP8 = true;
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[0], b[0], c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[1], b[1], c, 0, 0, 0);
   }
+  __device__ static __forceinline__ f32x4 mma2(Frag a0, Frag a1, Frag b0, Frag b1, f32x4 c) { return mma_f8_k128<0>(a0, a1, b0, b1, c); }
 };
 template <> struct Mma<bf8fp8_op> {
   using Frag = i64x2;
+  static constexpr bool FP8 = true;
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a[0], b[0], c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a[1], b[1], c, 0, 0, 0);
   }
+  __device__ static __forceinline__ f32x4 mma2(Frag a0, Frag a1, Frag b0, Frag b1, f32x4 c) { return mma_f8_k128<1>(a0, a1, b0, b1, c); }
 };
 template <> struct Mma<float> {
+  static constexpr bool FP8 = false;
   static constexpr int KSTEP = 4, BK = 32;
   using Frag = float;
   __device__ static __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
@@ -237,8 +253,9 @@ __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int ld
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) glds_issue<T, WM>(A, lda, M, m0, B, ldb, N, n0, s * BK, sA + s * A_STAGE, sB + s * GL_STAGE, w, lane);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; the (up to two) younger stages stay in flight: 4 (WM = 4: 3) loads per stage and wave
+  // stage kt has landed (the up-to-two younger stages stay in flight: 4 (WM = 4: 3) loads per stage and wave), every wave is past
+  // its reads of stage kt - 1, whose slot is refilled
+  auto sync_and_issue = [&](int kt) __attribute__((always_inline)) {
     const int younger = min(NST - 2, nk - 1 - kt);
     if constexpr (WM == 2) {
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -249,13 +266,50 @@ __device__ __forceinline__ void nt_mainloop_glds(const T* __restrict__ A, int ld
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();  // every wave's pieces landed; stage (kt-1) % NSTAGE is free again
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     NT_STAMP(4 + kt);
     if (kt + NST - 1 < nk) {
       const int s = (kt + NST - 1) % NST;
       glds_issue<T, WM>(A, lda, M, m0, B, ldb, N, n0, (kt + NST - 1) * BK, sA + s * A_STAGE, sB + s * GL_STAGE, w, lane);
     }
+  };
+  if constexpr (MM::FP8) {
+    if ((nk & 1) == 0) {  // K % 128 == 0: stage pairs through the 128-wide fp8 MFMA (the even stage's fragments wait in registers)
+      for (int kt = 0; kt < nk; kt += 2) {
+        typename MM::Frag fa0[4], fb0[4], fa1[4], fb1[4];
+        sync_and_issue(kt);
+        {
+          const char* a = sA + (kt % NST) * A_STAGE;
+          const char* b = sB + (kt % NST) * GL_STAGE;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            fa0[i] = GF::load(a, wm * 64 + i * 16 + li, 0, g);
+            fb0[i] = GF::load(b, wn * 64 + i * 16 + li, 0, g);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage kt is in registers before its slot is handed back for refill
+        sync_and_issue(kt + 1);
+        {
+          const char* a = sA + ((kt + 1) % NST) * A_STAGE;
+          const char* b = sB + ((kt + 1) % NST) * GL_STAGE;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            fa1[i] = GF::load(a, wm * 64 + i * 16 + li, 0, g);
+            fb1[i] = GF::load(b, wn * 64 + i * 16 + li, 0, g);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma2(fa0[i], fa1[i], fb0[j], fb1[j], acc[i][j]);
+      }
+      __syncthreads();
+      return;
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    sync_and_issue(kt);
     const char* a = sA + (kt % NST) * A_STAGE;
     const char* b = sB + (kt % NST) * GL_STAGE;
 #pragma unroll
