@@ -110,9 +110,11 @@ int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* 
 /* Per-tensor fp8 quantisation, just in time and without a host round trip:
  *   sm_amax:          *amax = max(*amax, max |x[i]|)            (the caller zeroes *amax first; dtype SM_BF16 or SM_F32)
  *   sm_quantize_fp8:  q[i] = fp8(x[i] * fmax / *amax), *scale = *amax / fmax   (e5m2 = 0: e4m3fn, fmax 448; 1: e5m2, fmax 57344;
- *                     round to nearest even, saturating)  -- x ~ q * *scale; *scale is what sm_epilogue.scale_a / scale_b point to */
+ *                     round to nearest even, saturating)  -- x ~ q * *scale; *scale is what sm_epilogue.scale_a / scale_b point to.
+ *                     amax_next != NULL (delayed scaling): *amax is an earlier pass's maximum of this tensor site and this pass
+ *                     records max |x[i]| into *amax_next (atomic max; the caller zeroes it once per step): one pass instead of two */
 int sm_amax(int dtype, const void* x, long n, float* amax, void* stream);
-int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, void* stream);
+int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, float* amax_next, void* stream);
 
 /* Input-gradient GEMM fused with the LayerNorm backward that consumes it (hf:293/351 backward):
  *   dy = A[M,K] . B[N,K]^T + residual;  dx = LN'(dy | x, gamma, mean, rstd);  dx_drop = dropout_bwd(dx) (optional);

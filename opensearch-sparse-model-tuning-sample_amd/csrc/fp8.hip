@@ -53,12 +53,16 @@ template <bool E5M2> __device__ __forceinline__ uint32_t pack4(float a, float b,
   return (uint32_t)w;
 }
 
+// amax_next != NULL (delayed scaling): the scale comes from an EARLIER pass over this tensor site (*amax, e.g. the previous training
+// step's maximum) and this pass records the tensor's own maximum into *amax_next for the next one -- one pass over x instead of two;
+// values past the stale maximum saturate.
 template <typename T, bool E5M2>
 __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, long n, const float* __restrict__ amax,
-                                                       uint8_t* __restrict__ q, float* __restrict__ scale) {
+                                                       uint8_t* __restrict__ q, float* __restrict__ scale, float* __restrict__ amax_next) {
   constexpr float FMAX = E5M2 ? 57344.f : 448.f;
   const float am = fmaxf(*amax, 1e-30f);
   const float mul = FMAX / am;
+  float seen = 0.f;
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale = am / FMAX;  // dequantisation scale: x ~ q * scale
   const long n8 = n / 8;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n8; v += (long)gridDim.x * 256) {
@@ -72,6 +76,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) seen = fmaxf(seen, fabsf(f[k]));
     // (|x| <= amax, so |x * mul| <= FMAX up to one rounding: the clamp keeps the conversion away from its overflow encoding)
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(f[k] * mul, -FMAX), FMAX);
@@ -82,9 +88,20 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
   }
   if (blockIdx.x == 0)
     for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) {
-      const float f = fminf(fmaxf(fp8_in<T>(x, i) * mul, -FMAX), FMAX);
+      const float v = fp8_in<T>(x, i);
+      seen = fmaxf(seen, fabsf(v));
+      const float f = fminf(fmaxf(v * mul, -FMAX), FMAX);
       q[i] = (uint8_t)(pack4<E5M2>(f, 0.f, 0.f, 0.f) & 0xff);
     }
+  if (amax_next != nullptr) {  // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) seen = fmaxf(seen, __shfl_xor(seen, o));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = seen;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(reinterpret_cast<unsigned int*>(amax_next), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  }
 }
 
 }  // namespace
@@ -102,13 +119,14 @@ extern "C" int sm_amax(int dtype, const void* x, long n, float* amax, void* stre
   return SM_OK;
 }
 
-extern "C" int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, void* stream) {
+extern "C" int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, float* amax_next,
+                               void* stream) {
   SM_REQUIRE(n > 0 && x && amax && q && scale, "sm_quantize_fp8: empty tensor");
   SM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0, "sm_quantize_fp8: x must be 16-byte, q 8-byte aligned");
   int grid = (int)((n / 8 + 255) / 256);
   grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
   hipStream_t st = (hipStream_t)stream;
-#define SM_Q(T, E) hipLaunchKernelGGL((quantize_kernel<T, E>), dim3(grid), dim3(256), 0, st, (const T*)x, n, amax, (uint8_t*)q, scale)
+#define SM_Q(T, E) hipLaunchKernelGGL((quantize_kernel<T, E>), dim3(grid), dim3(256), 0, st, (const T*)x, n, amax, (uint8_t*)q, scale, amax_next)
   if (dtype == SM_BF16) { if (e5m2) SM_Q(bf16, true); else SM_Q(bf16, false); }
   else if (dtype == SM_F32) { if (e5m2) SM_Q(float, true); else SM_Q(float, false); }
   else SM_REQUIRE(false, "sm_quantize_fp8: bad dtype %d", dtype);

@@ -193,6 +193,12 @@ class HipBertMLM(torch.nn.Module):
         # ("fp8 MFMA", config_kd.yaml:9-16).  Head, attention core, weight gradients, LayerNorms and the residual stream keep their
         # types.  SM_FP8=1 or HipBertMLM(fp8=True); bf16 runs only.
         self.fp8 = compute_dtype == torch.bfloat16 and (bool(fp8) if fp8 is not None else os.environ.get("SM_FP8", "0") == "1")
+        # fp8 activations / gradients use DELAYED scaling from the second optimisation step on: a tensor site (layer, linear, forward or
+        # gradient) is scaled by the maximum it showed during the PREVIOUS step (all calls of the step: both passes of gradient
+        # caching, every chunk) and records this step's maximum in the same pass -- one pass over the tensor instead of two; the
+        # first step (and inference) measures just in time.  SM_FP8_DELAYED=0 keeps just-in-time scaling throughout.
+        self._fp8_delayed = os.environ.get("SM_FP8_DELAYED", "1") != "0"
+        self._fp8_sites, self._fp8_cur, self._fp8_next, self._fp8_ready = {}, None, None, set()
         if self.fp8:
             self.fused_ffn = self.pc_ffn = False
         self.ffn_fwd_f16 = (self.fwd_f16 and not self.fused_ffn and not self.pc_ffn and not self.fp8
@@ -407,6 +413,10 @@ class HipBertMLM(torch.nn.Module):
                 for k in ("qkv", "o", "w1", "w2"):
                     for key in (f"{k}{l}", f"{k}T{l}"):
                         st[key + "_8"], st[key + "_8s"], _ = ops.quantize_fp8(st[key])
+            if self._fp8_cur is not None:  # an optimisation step has passed: last step's maxima become this step's scales
+                self._fp8_cur, self._fp8_next = self._fp8_next, self._fp8_cur
+                self._fp8_next.zero_()
+                self._fp8_ready = set(self._fp8_sites.values())
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
@@ -415,7 +425,19 @@ class HipBertMLM(torch.nn.Module):
         to e4m3 (e5m2 when it is a gradient) against the staged e4m3 weight"""
         st = self._staged
         if self.fp8 and a.dtype == torch.bfloat16:
-            aq, sa, _ = ops.quantize_fp8(a, e5m2=grad)
+            if not self._fp8_delayed:
+                aq, sa, _ = ops.quantize_fp8(a, e5m2=grad)
+            else:
+                if self._fp8_cur is None:
+                    n = 8 * self.config.num_hidden_layers
+                    self._fp8_cur, self._fp8_next = (torch.zeros(n, dtype=torch.float32, device=a.device) for _ in range(2))
+                i = self._fp8_sites.setdefault(key, len(self._fp8_sites))
+                nxt = self._fp8_next[i:i + 1]
+                if i in self._fp8_ready:
+                    aq, sa, _ = ops.quantize_fp8(a, e5m2=grad, amax=self._fp8_cur[i:i + 1], amax_next=nxt)
+                else:  # no history for this site yet: measure now, remember for the next step
+                    aq, sa, am = ops.quantize_fp8(a, e5m2=grad)
+                    torch.maximum(nxt, am, out=nxt)
             return ops.gemm_nt(aq, st[key + "_8"], scale_a=sa, scale_b=st[key + "_8s"], **epi)
         return ops.gemm_nt(a, st[key], **epi)
 

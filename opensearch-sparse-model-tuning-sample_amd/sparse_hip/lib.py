@@ -59,7 +59,7 @@ _rag = C.POINTER(SmRagged)
 SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
     "sm_amax": [_i, _p, _l, _p, _p],
-    "sm_quantize_fp8": [_i, _p, _l, _p, _i, _p, _p, _p],
+    "sm_quantize_fp8": [_i, _p, _l, _p, _i, _p, _p, _p, _p],
     "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_ffn_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],

@@ -140,17 +140,18 @@ def ffn_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2t: Tensor, w1tp: T
     return (df1, ga, dz1, dz1d) if ok else None
 
 
-def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None):
-    """(q, scale): per-tensor fp8 copy of x (bf16 / fp32) and its device-side dequantisation scale, x ~ q * scale.  e4m3fn by
+def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None, amax_next: Optional[Tensor] = None):
+    """(q, scale, amax): per-tensor fp8 copy of x (bf16 / fp32) and its device-side dequantisation scale, x ~ q * scale.  e4m3fn by
     default (forward operands), e5m2 for gradients; amax: a [1] fp32 device tensor already holding max |x| (e.g. a weight's, for
-    its transposed copy), otherwise measured here"""
+    its transposed copy, or -- delayed scaling -- an earlier step's), otherwise measured here; amax_next: receives max |x| (atomic max)"""
     x = x.contiguous()
     if amax is None:
         amax = torch.zeros(1, dtype=torch.float32, device=x.device)
         L.call("sm_amax", L.dtype_code(x.dtype), L.ptr(x), x.numel(), L.ptr(amax), L.stream_ptr())
     q = torch.empty(x.shape, dtype=torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn, device=x.device)
     scale = torch.empty(1, dtype=torch.float32, device=x.device)
-    L.call("sm_quantize_fp8", L.dtype_code(x.dtype), L.ptr(x), x.numel(), L.ptr(amax), int(e5m2), L.ptr(q), L.ptr(scale), L.stream_ptr())
+    L.call("sm_quantize_fp8", L.dtype_code(x.dtype), L.ptr(x), x.numel(), L.ptr(amax), int(e5m2), L.ptr(q), L.ptr(scale),
+           L.ptr(amax_next), L.stream_ptr())
     return q, scale, amax
 
 

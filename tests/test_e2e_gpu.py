@@ -472,6 +472,41 @@ def test_training_mode_dropout_is_seeded_and_finite():
         close_out(m(inf_free=False, input_ids=ids, attention_mask=mask), g["rep_l00_prune0"], 1e-2, "eval = no dropout")
 
 
+def test_fp8_delayed_scaling_follows_just_in_time_scaling():
+    """fp8 mode of the encoder: from the second optimisation step on a tensor site is scaled by the maximum it showed during the
+    previous step (one pass instead of two).  Two steps on the same batch: the second step's representation under delayed
+    scaling stays as close to just-in-time scaling as fp8 rounding allows, and every site has a recorded maximum"""
+    from scripts.model.sparse_encoders import SparseModel
+    from sparse_hip import ops
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    cfg = BertConfigLite(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                         max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(5, 2000, (6, 32), generator=g).cuda()
+    mask = torch.ones(6, 32, dtype=torch.long).cuda()
+    reps = {}
+    for delayed in (True, False):
+        bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=3, fp8=True)
+        bb._fp8_delayed = delayed
+        m = SparseModel(bb, use_l0=False)
+        m.train()
+        adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
+        for step in range(2):
+            bb.flat_grad.zero_()
+            rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
+            (rep * rep).sum().backward()
+            ops.adamw(bb.flat_param, bb.flat_grad, adam["m"], adam["v"], 1e-4, 0.9, 0.999, 1e-8, 0.0, step + 1, 1.0)
+            bb.mark_weights_dirty()
+        with torch.no_grad():
+            reps[delayed] = m(inf_free=False, input_ids=ids, attention_mask=mask).float()
+        assert torch.isfinite(reps[delayed]).all() and torch.isfinite(bb.flat_grad).all()
+        if delayed:
+            assert len(bb._fp8_ready) == 8 * cfg.num_hidden_layers and float(bb._fp8_cur.min()) > 0
+    rel = float((reps[True] - reps[False]).norm() / reps[False].norm())
+    print(f"[fp8] delayed against just-in-time scaling after two steps: relative Frobenius {rel:.3e}")
+    assert rel < 5e-2
+
+
 def test_product_path_refuses_cpu_tensors():
     from sparse_hip import functional as F
     from sparse_hip.lib import SparseHipError

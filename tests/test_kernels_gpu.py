@@ -716,6 +716,12 @@ def test_quantize_fp8_matches_the_torch_conversion(ops, dtype, e5m2):
         assert float(amax) == 17.5 and abs(float(scale) - 17.5 / fmax) < 1e-9
         ref = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(17.5))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
         assert torch.equal(q.cpu().view(torch.uint8), ref.view(torch.uint8))
+        # delayed scaling: scale from a given (stale, here smaller) maximum, values past it saturate; this pass's maximum is recorded
+        stale, nxt = torch.full((1,), 4.0, device="cuda"), torch.zeros(1, device="cuda")
+        q2, scale2, _ = ops.quantize_fp8(x, e5m2=e5m2, amax=stale, amax_next=nxt)
+        assert float(nxt) == 17.5 and abs(float(scale2) - 4.0 / fmax) < 1e-9
+        ref2 = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(4.0))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
+        assert torch.equal(q2.cpu().view(torch.uint8), ref2.view(torch.uint8))
 
 
 @pytest.mark.gpu
