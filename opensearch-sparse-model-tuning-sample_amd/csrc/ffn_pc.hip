@@ -223,31 +223,48 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
     constexpr int HALF = decltype(halfc)::value;
     (void)half;
     const int sl = lane & 7, sub = lane >> 3;
+    // every global load of the half is issued BEFORE the first LDS wait (the waits are compiler barriers): issued where they are
+    // used, each of the six (row group, column group) bodies paid the full latency of its z1 read (~4 k cycles; the stamps showed
+    // 32 k cycles per half)
+    f32x4 zz[2][3][2];
+    float mu1[2], rs1[2];
+    int grs[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int rl = it * 64 + w * 8 + sub, grow = blk_row0 + rl;
-      const bool live = grow < T;
-      const int gr = min(grow, T - 1);
-      const float mu1 = a.m1[gr], rs1 = a.r1[gr];
-      const uint32_t ra = lds0 + (uint32_t)(rl * PC_EROW);
+      const int grow = blk_row0 + it * 64 + w * 8 + sub;
+      grs[it] = min(grow, T - 1);
+      mu1[it] = a.m1[grs[it]];
+      rs1[it] = a.r1[grs[it]];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int ci = sl + 8 * i, c0 = HALF * 192 + ci * 8;
+        const float* zr = a.z1 + (size_t)grs[it] * PC_H + HALF * 192 + (sl + 8 * i) * 8;
+        zz[it][i][0] = *reinterpret_cast<const f32x4*>(zr);
+        zz[it][i][1] = *reinterpret_cast<const f32x4*>(zr + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ci = sl + 8 * i, c0 = HALF * 192 + ci * 8;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias2 + c0), b1 = *reinterpret_cast<const f32x4*>(a.bias2 + c0 + 4);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rl = it * 64 + w * 8 + sub, grow = blk_row0 + rl;
+        const bool live = grow < T;
+        const int gr = grs[it];
+        const uint32_t ra = lds0 + (uint32_t)(rl * PC_EROW);
         f32x4 lo = pc_lds_read_f4(ra + (uint32_t)(ci * 32)), hi = pc_lds_read_f4(ra + (uint32_t)(ci * 32 + 16));
-        const float* zr = a.z1 + (size_t)gr * PC_H + c0;
-        const f32x4 z0 = *reinterpret_cast<const f32x4*>(zr), z1v = *reinterpret_cast<const f32x4*>(zr + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias2 + c0), b1 = *reinterpret_cast<const f32x4*>(a.bias2 + c0 + 4);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+        const f32x4 z0 = zz[it][i][0], z1v = zz[it][i][1];
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = lo[k] + b0[k]; v[4 + k] = hi[k] + b1[k]; }
         if (a.drop.thresh16) drop_apply8(a.drop, (uint64_t)gr * PC_H + c0, v);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          v[k] += (z0[k] - mu1) * rs1 * g0[k] + e0[k];
-          v[4 + k] += (z1v[k] - mu1) * rs1 * g1[k] + e1[k];
+          v[k] += (z0[k] - mu1[it]) * rs1[it] * g0[k] + e0[k];
+          v[4 + k] += (z1v[k] - mu1[it]) * rs1[it] * g1[k] + e1[k];
         }
         if (live) {
           float* zo = a.z2 + (size_t)grow * PC_H + c0;
@@ -261,10 +278,9 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   };
   auto rows_ln2 = [&]() __attribute__((always_inline)) {
     const int sl = lane & 7, sub = lane >> 3;
+    float mu2[2], rs2[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int rl = it * 64 + w * 8 + sub, grow = blk_row0 + rl;
-      const bool live = grow < T;
       float s1 = 0.f;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
@@ -272,33 +288,42 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int k = 0; k < 8; ++k) s1 += keep[it][h2][i][k];
-      const float mu2 = pc_lanes_sum<8>(s1) * (1.f / PC_H);
+      mu2[it] = pc_lanes_sum<8>(s1) * (1.f / PC_H);
       float q = 0.f;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { const float d = keep[it][h2][i][k] - mu2; q += d * d; }
-      const float rs2 = rsqrtf(pc_lanes_sum<8>(q) * (1.f / PC_H) + a.eps);
-      if (live) {
+          for (int k = 0; k < 8; ++k) { const float d = keep[it][h2][i][k] - mu2[it]; q += d * d; }
+      rs2[it] = rsqrtf(pc_lanes_sum<8>(q) * (1.f / PC_H) + a.eps);
+    }
+    // column constants once per column group (not once per row group and column group)
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
+    for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int c0 = h2 * 192 + (sl + 8 * i) * 8;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0 + 4);
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0 + 4);
+      for (int i = 0; i < 3; ++i) {
+        const int c0 = h2 * 192 + (sl + 8 * i) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln2_g + c0 + 4);
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln2_b + c0 + 4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int grow = blk_row0 + it * 64 + w * 8 + sub;
+          if (grow < T) {
             bf16x8 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              o[k] = (bf16)((keep[it][h2][i][k] - mu2) * rs2 * g0[k] + e0[k]);
-              o[4 + k] = (bf16)((keep[it][h2][i][4 + k] - mu2) * rs2 * g1[k] + e1[k]);
+              o[k] = (bf16)((keep[it][h2][i][k] - mu2[it]) * rs2[it] * g0[k] + e0[k]);
+              o[4 + k] = (bf16)((keep[it][h2][i][4 + k] - mu2[it]) * rs2[it] * g1[k] + e1[k]);
             }
             *reinterpret_cast<bf16x8*>(a.x2 + (size_t)grow * PC_H + c0) = o;
           }
-        if (sl == 0) { a.m2[grow] = mu2; a.r2[grow] = rs2; }
+        }
       }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int grow = blk_row0 + it * 64 + w * 8 + sub;
+      if (grow < T && sl == 0) { a.m2[grow] = mu2[it]; a.r2[grow] = rs2[it]; }
     }
   };
 
