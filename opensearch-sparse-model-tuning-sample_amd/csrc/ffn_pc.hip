@@ -165,16 +165,27 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   // and, in the operand type, into LDS in the producers' B-fragment order ((group, k-step, lane) -> 16 bytes)
   {
     const int sl = lane & 15, sub = lane >> 4;
-#pragma unroll 1
+    // the four row groups' z1 reads are all in flight before the first is used (96 registers that nothing else needs yet): one
+    // read latency (~4 k cycles) for the prologue instead of four
+    f32x4 zin[4][3][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float* zr = a.z1 + (size_t)min(blk_row0 + it * 32 + w * 4 + sub, T - 1) * PC_H;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        zin[it][i][0] = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8);
+        zin[it][i][1] = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8 + 4);
+      }
+    }
+#pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int rl = it * 32 + w * 4 + sub, grow = blk_row0 + rl;
       const bool live = grow < T;
-      const float* zr = a.z1 + (size_t)min(grow, T - 1) * PC_H;
       float v[3][8];
       float s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8), hi = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8 + 4);
+        const f32x4 lo = zin[it][i][0], hi = zin[it][i][1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[i][k] = lo[k]; v[i][4 + k] = hi[k]; s1 += lo[k] + hi[k]; }
       }
