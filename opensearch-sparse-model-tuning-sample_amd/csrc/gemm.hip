@@ -566,12 +566,26 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
           float xv[8];
           if constexpr (sizeof(T) == 2) load_ggo8<T>(ggo, e.ggo_tiled, off, row, col, N, xv, full, N - col);
           else load8<T>(ggo + off, xv, full, N - col);
+          if (sizeof(T) == 2 && e.ggo_tiled) {
+            // f1 of the fused feed-forward: its forward applied the sigmoid-form GELU (gelu_sig, csrc/common.h), so value and
+            // derivative come from that same function -- ~15 instructions for both instead of ~60 for the erf forms: with the
+            // exact forms this epilogue, not the product, bounded the launch
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
-          if (gout) {
+            for (int k = 0; k < 8; ++k) {
+              float gv, gp;
+              gelu_sig_both(xv[k], gv, gp);
+              v[k] *= gp;
+              xv[k] = gv;
+            }
+            if (gout) store8<T>(gout + off, xv, full, N - col);
+          } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = gelu_t<T>(xv[k]);
-            store8<T>(gout + off, xv, full, N - col);
+            for (int k = 0; k < 8; ++k) v[k] *= gelu_grad_t<T>(xv[k]);
+            if (gout) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) xv[k] = gelu_t<T>(xv[k]);
+              store8<T>(gout + off, xv, full, N - col);
+            }
           }
         }
         if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);

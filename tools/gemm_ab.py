@@ -16,7 +16,7 @@ def timeit(f, n=30):
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 43904
 x = torch.randn(T, 384, device='cuda').bfloat16()
 out = []
-for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536), ("attn_out", 384), ("dctx", 384)):
+for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536), ("dgrad+ga", 1536), ("dgrad+ga tiled f1", 1536), ("attn_out", 384), ("dctx", 384)):
     W = torch.randn(N, 384, device='cuda').bfloat16() * 0.02
     b = torch.zeros(N, device='cuda')
     f1 = torch.randn(T, N, device='cuda').bfloat16()
@@ -24,6 +24,12 @@ for name, N in (("qkv", 1152), ("ffn_up", 1536), ("ffn_down_dgrad", 1536), ("att
     if name == "attn_out":
         res = torch.randn(T, N, device='cuda'); f = lambda: ops.gemm_nt(x, W, bias=b, residual=res, out_f32=True)
     elif name == "dctx": f = lambda: ops.gemm_nt(x, W)
+    elif name == "dgrad+ga":
+        ga = torch.empty(T, N, device='cuda', dtype=torch.bfloat16); f = lambda: ops.gemm_nt(x, W, gelu_grad_of=f1, gelu_out=ga)
+    elif name == "dgrad+ga tiled f1":  # the fused feed-forward's layout: sigmoid-form GELU in the epilogue
+        ga = torch.empty(T, N, device='cuda', dtype=torch.bfloat16)
+        f1t = torch.randn(4 * ((T + 127) // 128), N // 32, 64, 16, device='cuda').bfloat16()
+        f = lambda: ops.gemm_nt(x, W, gelu_grad_of=f1t, gelu_out=ga, gelu_grad_tiled=True)
     elif name == "qkv": f = lambda: ops.gemm_nt(x, W, bias=b)
     elif name == "ffn_up": f = lambda: ops.gemm_nt(x, W, bias=b, act=1, preact=pre)
     else: f = lambda: ops.gemm_nt(x, W, gelu_grad_of=f1)
