@@ -1604,6 +1604,11 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   }
 }
 
+}  // namespace
+bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                    const void* f1_tiled, void* ga, hipStream_t st);  // gemm_ws.hip
+namespace {
+
 template <typename T>
 int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const sm_epilogue* epi, hipStream_t st) {
@@ -1653,6 +1658,14 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     }
   }
   constexpr int glds_on = 1;
+  if constexpr (std::is_same<T, bf16>::value) {
+    // K = 384 with a plain (bias) or dF1 (x gelu'(tile-major f1), + gelu(f1)) epilogue: the weight-stationary kernel (gemm_ws.hip)
+    const bool plain = !e.act && !e.preact && !e.drop.thresh16 && !e.residual && !e.out32 && !e.rl_mean;
+    const bool epi0 = !e.gelu_grad_of && !e.gelu_out, epi1 = e.gelu_grad_of && e.ggo_tiled && !e.bias;
+    if (plain && (epi0 || epi1) &&
+        sm_gemm_ws_try(SM_BF16, A, lda, B, ldb, C, ldc, M, N, K, e.bias, epi1 ? e.gelu_grad_of : nullptr, e.gelu_out, st))
+      return 0;
+  }
   if constexpr (sizeof(T) == 2) {
     // 256 x 128 tiles (8 waves), a BUILD option (-DSM_NT256=1; the library reads no environment): measured SLOWER than the 128 x 128 tile where it was expected to pay
     // (K = 384, 43.9 k rows: N = 1152 89 vs 74 us, N = 1536 163 vs 143 us; N = 384 40.6 vs 41.6 us) -- a workgroup's timeline

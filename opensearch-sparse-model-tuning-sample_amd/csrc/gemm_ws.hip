@@ -1,0 +1,366 @@
+// WEIGHT-STATIONARY NT GEMM for K = 384 (the encoder linears of the 384-wide models whose K is the hidden size: QKV forward, the
+// attention-output input gradient, the FFN-down input gradient dF1): C[M, N] = epi(A[M, 384] . W[N, 384]^T), 16-bit operands.
+//
+// Why: at K = 384 the 128 x 128 tile kernel (gemm.hip) spends its time on the CU's vector-memory path (~30 B/clk, shared by the
+// LDS-DMA of three co-resident workgroups and their epilogues' loads / stores): 64 FLOP per loaded byte, a prologue and an epilogue
+// per 12 K-steps (a workgroup's timeline: one third epilogue; MfmaUtil 20 %).  This kernel is the fused head forward's loop nest
+// (head_fwd.hip) with a store epilogue: a workgroup owns 128 output columns -- its [128, 384] slice of W lives in registers as
+// MFMA B fragments for the life of the workgroup (32 columns per compute wave) -- and a contiguous range of token rows streams
+// past it, 32 rows per step, through a 5-stage LDS ring filled by LDS-DMA: only A is loaded (128 FLOP per loaded byte), there
+// is no per-tile prologue or epilogue, every step's 24 MFMAs (32 x 32 x 16) are issued back to back by waves that do nothing else.
+//
+// 8 waves: 4 compute (one per SIMD) + 2 loaders (LDS-DMA only: an LDS-DMA instruction blocks its wave until the path takes it)
+// + 2 storers.  A compute wave hands the fp32 accumulators of step s - 1 to the storers through a double-buffered 32 x 128 LDS
+// tile, one ds_write_b32 per MFMA gap of step s; the storers read it row-major (16-byte vectors), run the epilogue (bias, or the
+// dF1 form: x gelu'(f1) with f1 in the fused feed-forward's tile-major layout, gelu(f1) written beside it) and store -- their
+// vector-memory stalls never reach the compute waves.  One s_barrier per step (B_s): stage s + 1 has landed, the slot of stage
+// s - 1 is free, the hand-over tile of step s - 2 has been read.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WS_H = 384, WS_KS = WS_H / 16, WS_ROWB = 2 * WS_H, WS_STAGE = 32 * WS_ROWB;  // 24 k-steps, 768-byte rows, 24 KiB stages
+constexpr int WS_NST = 5, WS_D = 8;                                                       // ring stages, A fragments in flight
+constexpr int WS_HSTRIDE = 132 * 4, WS_HBUF = 32 * WS_HSTRIDE;                            // hand-over tile: 32 rows of 132 floats
+constexpr int WS_LDS = WS_NST * WS_STAGE + 2 * WS_HBUF;                                   // 122880 + 33792 = 156672
+constexpr int WS_BAR_KS = 4;  // B_s sits behind MFMA 4 of step s
+static_assert(WS_LDS <= 160 * 1024, "LDS budget");
+
+template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ bf16x8 ws_lds_read(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 ws_lds_read_f4(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int OFF> __device__ __forceinline__ void ws_lds_write32(uint32_t addr, float v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void ws_wait_pair(bf16x8& f0, bf16x8& f1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N) : "memory");
+}
+template <int I, int N, typename F> __device__ __forceinline__ void ws_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ws_static_for<I + 1, N>(f);
+  }
+}
+template <bool F16> __device__ __forceinline__ f32x16 ws_mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct WsArgs {
+  const bf16* A;        // [M, 384] 16-bit (bf16, or fp16 with F16)
+  const bf16* W;        // [N, 384] same type
+  bf16* C;              // [M, N] bf16
+  const float* bias;    // [N] or null
+  const bf16* f1;       // EPI 1: tile-major f1 (include/sparse_hip.h, sm_ffn_pc_fwd)
+  bf16* ga;             // EPI 1: gelu(f1), [M, N] bf16 (may be null)
+  int M, N, rsplit;     // rsplit: row ranges (grid = (N / 128) * rsplit workgroups)
+};
+
+// EPI 0: C = acc + bias.  EPI 1: C = acc * gelu'(f1), ga = gelu(f1) (the fused forward's sigmoid-form GELU)
+template <bool F16, int EPI>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
+  constexpr int KS = WS_KS, NST = WS_NST, D = WS_D, BAR_KS = WS_BAR_KS;
+  extern __shared__ __attribute__((aligned(256))) char ws_smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // workgroups of one XCD (id % 8) take CONTIGUOUS (row range, column slice) pairs, row range major: the column slices of a row
+  // range run on one XCD and share its rows through that L2
+  const int ncs = a.N >> 7, total = ncs * a.rsplit;
+  const int per_xcd = (total + 7) >> 3;
+  const int j = (int)(blockIdx.x >> 3) + (int)(blockIdx.x & 7) * per_xcd;
+  if ((int)(blockIdx.x >> 3) >= per_xcd || j >= total) return;
+  const int ry = j / ncs, n0 = (j - ry * ncs) * 128;
+  const int steps_all = (a.M + 31) >> 5;
+  const int s_begin = (int)(((long)steps_all * ry) / a.rsplit), s_end = (int)(((long)steps_all * (ry + 1)) / a.rsplit);
+  const int nsteps = s_end - s_begin;
+  if (nsteps <= 0) return;
+  const int row_base = s_begin * 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)ws_smem;
+  const uint32_t hb0 = lds0 + NST * WS_STAGE;
+
+  if (w >= 6) {
+    // ------------------------------------------------------------------ storer waves: 16 rows of every step each, row-major
+    const int sw = w - 6;
+    const int cg = lane & 15, rq = lane >> 4;  // 8-column group, row within a 4-row pass
+    const int col = n0 + cg * 8;
+    float bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = (EPI == 0 && a.bias) ? a.bias[col + k] : 0.f;
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    u16x4 f1n[4][2];  // EPI 1: the f1 words of the step processed NEXT (fetched one barrier early)
+    auto f1_fetch = [&](int s) __attribute__((always_inline)) {
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int row = min(row_base + s * 32 + sw * 16 + p * 4 + rq, a.M - 1);
+          const size_t tile = (size_t)(row >> 5) * (size_t)(a.N >> 5) + (size_t)(col >> 5);
+          const bf16* q = a.f1 + (tile * 64 + (row & 31)) * 16 + ((col & 31) >> 3) * 4;
+          f1n[p][0] = *reinterpret_cast<const u16x4*>(q);
+          f1n[p][1] = *reinterpret_cast<const u16x4*>(q + 32 * 16);
+        }
+      }
+    };
+    auto process = [&](int s) __attribute__((always_inline)) {  // the hand-over tile of step s -> memory
+      const uint32_t hb = hb0 + (uint32_t)((s & 1) * WS_HBUF + (sw * 16 + rq) * WS_HSTRIDE + cg * 32);
+      f32x4 lo[4], hi[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        lo[p] = ws_lds_read_f4(hb + (uint32_t)(p * 4 * WS_HSTRIDE));
+        hi[p] = ws_lds_read_f4(hb + (uint32_t)(p * 4 * WS_HSTRIDE + 16));
+      }
+      // every read of the tile has returned before this wave reaches the next barrier (the compute waves overwrite it behind that)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                   :
+                   : "memory");
+      u16x4 f1c[4][2];
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { f1c[p][0] = f1n[p][0]; f1c[p][1] = f1n[p][1]; }
+        if (s + 1 < nsteps) f1_fetch(s + 1);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = row_base + s * 32 + sw * 16 + p * 4 + rq;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = lo[p][k] + bv[k]; v[4 + k] = hi[p][k] + bv[4 + k]; }
+        bf16x8 o, g;
+        if constexpr (EPI == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float x = (float)__builtin_bit_cast(bf16, (uint16_t)(k < 4 ? f1c[p][0][k] : f1c[p][1][k - 4]));
+            float gv, gp;
+            gelu_sig_both(x, gv, gp);
+            o[k] = (bf16)(v[k] * gp);
+            g[k] = (bf16)gv;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
+        }
+        if (row < a.M) {
+          const size_t off = (size_t)row * a.N + col;
+          *reinterpret_cast<bf16x8*>(a.C + off) = o;
+          if constexpr (EPI == 1) {
+            if (a.ga) *reinterpret_cast<bf16x8*>(a.ga + off) = g;
+          }
+        }
+      }
+    };
+    f1_fetch(0);
+    for (int t = 0; t < nsteps + 2; ++t) {
+      __builtin_amdgcn_s_barrier();  // B_t
+      asm volatile("" ::: "memory");
+      if (t >= 2) process(t - 2);
+    }
+    return;
+  }
+  if (w >= 4) {
+    // ------------------------------------------------------------------ loader waves: 16 rows of every stage each
+    const int lw = w - 4;
+    constexpr int PPL = KS / 2;  // pieces (1 KiB) per loader wave and stage
+    int soff[PPL];               // element offset of this lane's source chunk, per piece, relative to the stage's first row
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+      const int q = (lw * PPL + i) * 64 + lane;  // physical 16-byte chunk of the stage
+      const int r = q / (2 * KS), pc = q % (2 * KS);
+      const int c = (pc & ~15) | ((pc & 15) ^ (r & 15));
+      soff[i] = r * WS_H + c * 8;
+    }
+    auto issue = [&](int s) {  // stage s -> slot s % NST
+      char* dst = ws_smem + (s % NST) * WS_STAGE + lw * PPL * 1024;
+      const int row0 = row_base + s * 32;
+      if (row0 + 32 <= a.M) {
+        const bf16* src = a.A + (size_t)row0 * WS_H;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + soff[i]), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+      } else {  // rows past the end re-read the last row (never stored)
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+          const int r = soff[i] / WS_H, within = soff[i] - r * WS_H;
+          const int rr = min(row0 + r, a.M - 1);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(a.A + (size_t)rr * WS_H + within), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+        }
+      }
+    };
+    // before B_s: stage min(s + 1, nsteps - 1) has landed; stages up to s + NST - 2 have been issued
+    auto wait_landed = [&](int s) {
+      const int younger = min(s + NST - 2, nsteps - 1) - min(s + 1, nsteps - 1);
+      switch (younger) {
+        case 0: ws_wait_vm<0>(); break;
+        case 1: ws_wait_vm<PPL>(); break;
+        default: ws_wait_vm<2 * PPL>(); break;
+      }
+    };
+    static_assert(NST - 3 == 2, "wait_landed covers at most two younger stages");
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nsteps) issue(s);
+    for (int s = 0; s < nsteps; ++s) {
+      wait_landed(s);
+      __builtin_amdgcn_s_barrier();  // B_s
+      asm volatile("" ::: "memory");
+      if (s + NST - 1 < nsteps) issue(s + NST - 1);
+    }
+    __builtin_amdgcn_s_barrier();  // B_nsteps, B_nsteps+1: the storers' last two tiles
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves
+  const int col_l = lane & 31, h = lane >> 5;
+  bf16x8 fb[KS];  // resident B fragments: W[col, 16 ks + 8 h .. + 7]
+  {
+    const bf16* wrow = a.W + (size_t)(n0 + w * 32 + col_l) * WS_H + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fb[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
+  }
+  // LDS read addresses (head_fwd.hip): row (lane & 31), chunk 2 J + h -> physical (2 J & ~15) | ((2 J & 15) ^ y), y = h ^ (row & 15);
+  // eight registers (J & 7) cover a stage, the window (J >> 3) and the slot go into the instruction's offset -- slots 0-2 from
+  // one register set, slots 3-4 from a second one
+  uint32_t adr[2][8];
+  {
+    const uint32_t lane_base = lds0 + (uint32_t)col_l * WS_ROWB + (uint32_t)(((h ^ col_l) & 15) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      adr[0][jj] = lane_base ^ (uint32_t)(jj << 5);
+      adr[1][jj] = adr[0][jj] + 3u * WS_STAGE;
+    }
+  }
+  // hand-over: register i of an accumulator is row 8 (i / 4) + 4 h + i % 4, column 32 w + col_l of the step's tile
+  const uint32_t hw = hb0 + (uint32_t)(4 * h * WS_HSTRIDE + (w * 32 + col_l) * 4);
+  bf16x8 af[D];
+#define WS_READ(J, SLOT) af[(J) % D] = ws_lds_read<((SLOT) % 3) * WS_STAGE + (((J) >> 3) << 8)>(adr[(SLOT) / 3][(J) & 7])
+  auto hand_over = [&](auto ic, const f32x16& acc, int par) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int OFF = (8 * (i / 4) + i % 4) * WS_HSTRIDE;
+    if (par) ws_lds_write32<WS_HBUF + OFF>(hw, acc[i]);
+    else ws_lds_write32<OFF>(hw, acc[i]);
+  };
+
+  __builtin_amdgcn_s_barrier();  // B_0: stages 0 and 1 are in LDS
+  asm volatile("" ::: "memory");
+  ws_static_for<0, D>([&](auto jc) {
+    constexpr int jj = decltype(jc)::value;
+    WS_READ(jj, 0);
+  });
+  // One 32-row step in ring slot SLOT: KS MFMAs into `acc`; behind B_s (MFMA BAR_KS) the PREVIOUS step's accumulators go to the
+  // hand-over tile of parity (s - 1) & 1, one register per MFMA gap
+  auto step = [&](int s, auto slot_c, f32x16& acc, const f32x16& prev, auto first_c) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_c)::value, NEXT = (SLOT + 1) % NST;
+    constexpr bool FIRST = decltype(first_c)::value;
+    ws_static_for<0, KS>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks % 2 == 0) ws_wait_pair<D - 2>(af[ks % D], af[(ks + 1) % D]);
+      if constexpr (ks == 0) {
+        f32x16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+        acc = ws_mma<F16>(af[0], fb[0], zero);
+      } else {
+        acc = ws_mma<F16>(af[ks % D], fb[ks], acc);
+      }
+      if constexpr (ks == BAR_KS && !FIRST) {
+        __builtin_amdgcn_s_barrier();  // B_s
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (ks + D < KS) WS_READ(ks + D, SLOT);
+      else WS_READ(ks + D - KS, NEXT);  // (past the last stage: stale LDS, never used; keeps the lgkmcnt arithmetic valid)
+      if constexpr (!FIRST && ks > BAR_KS && ks <= BAR_KS + 16)
+        hand_over(std::integral_constant<int, ks - BAR_KS - 1>{}, prev, (s - 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  constexpr std::true_type T_{};
+  constexpr std::false_type F_{};
+  f32x16 acc0, acc1;
+  step(0, std::integral_constant<int, 0>{}, acc0, acc0, T_);
+  int s = 1;
+  bool odd_last = false;
+  while (s < nsteps) {
+    bool done = false;
+    ws_static_for<0, 2 * NST>([&](auto ic) {  // slot and accumulator parity are compile-time: 2 NST steps per trip
+      constexpr int i = decltype(ic)::value;
+      if (!done) {
+        if (s < nsteps) {
+          if constexpr ((1 + i) % 2) step(s, std::integral_constant<int, (1 + i) % NST>{}, acc1, acc0, F_);
+          else step(s, std::integral_constant<int, (1 + i) % NST>{}, acc0, acc1, F_);
+          odd_last = (1 + i) % 2;
+          ++s;
+        } else {
+          done = true;
+        }
+      }
+    });
+  }
+  static_assert(D == 8, "the operand list below names all D fragments");
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7])
+               :
+               : "memory");
+  // the last step's accumulators: behind B_nsteps like every other tile (tile s is written behind B_s+1, read behind B_s+2: the
+  // storers are still reading the tile of the same parity, step nsteps - 3, until they reach B_nsteps)
+  __builtin_amdgcn_s_barrier();  // B_nsteps
+  asm volatile("" ::: "memory");
+  {
+    const int par = (nsteps - 1) & 1;
+    if (odd_last) ws_static_for<0, 16>([&](auto ic) { hand_over(ic, acc1, par); });
+    else ws_static_for<0, 16>([&](auto ic) { hand_over(ic, acc0, par); });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // B_nsteps+1
+#undef WS_READ
+}
+
+}  // namespace
+
+// false: shape not taken (the caller runs the 128 x 128 kernel)
+bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                    const void* f1_tiled, void* ga, hipStream_t st) {
+  if ((dtype != SM_BF16 && dtype != SM_F16) || K != WS_H || lda != WS_H || ldb != WS_H || ldc != N || N % 128 != 0 || M < 8192) return false;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)f1_tiled | (uintptr_t)ga) % 16) return false;
+  if (dtype == SM_F16 && f1_tiled) return false;
+  WsArgs a;
+  a.A = (const bf16*)A;
+  a.W = (const bf16*)W;
+  a.C = (bf16*)C;
+  a.bias = bias;
+  a.f1 = (const bf16*)f1_tiled;
+  a.ga = (bf16*)ga;
+  a.M = M;
+  a.N = N;
+  const int ncs = N / 128;
+  int rs = 256 / ncs;  // one round of (at most) 256 workgroups
+  const int steps_all = (M + 31) / 32;
+  if (rs > steps_all / 8) rs = steps_all / 8;  // at least 8 steps per workgroup: the weight slice is loaded once per workgroup
+  if (rs < 1) rs = 1;
+  a.rsplit = rs;
+  const int total = ncs * rs, grid = ((total + 7) / 8) * 8;
+#define WS_GO(F16, EPI)                                                                                                 \
+  do {                                                                                                                  \
+    auto kern = gemm_ws_kernel<F16, EPI>;                                                                               \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess) return false; \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WS_LDS, st, a);                                                     \
+  } while (0)
+  if (f1_tiled) WS_GO(false, 1);
+  else if (dtype == SM_F16) return false;  // (no fp16-operand caller at K = 384 with a plain epilogue)
+  else WS_GO(false, 0);
+#undef WS_GO
+  return true;
+}

@@ -779,3 +779,50 @@ def test_scores_on_the_matrix_pipe(ops, nq, nd):
     wq, wd = ds.double() @ d.double(), ds.double().t() @ q.double() + 0.5
     assert float((dq.double() - wq).abs().max() / wq.abs().max()) < 1e-4
     assert float((dd_.double() - wd).abs().max() / wd.abs().max()) < 1e-4
+
+
+# ---- weight-stationary NT GEMM for K = 384 (csrc/gemm_ws.hip) ------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,bias", [(8192, 1152, True), (43904 + 16, 384, False), (12345 // 16 * 16, 1536, True), (65536, 1152, True)])
+def test_gemm_ws_plain_epilogue(ops, M, N, bias):
+    """C = A . W^T (+ bias) at K = 384, M >= 8192 through the weight-stationary kernel: against the fp64 product at bf16 rounding, and
+    against the 128 x 128 kernel (taken below 8192 rows) on the first and last rows -- same products, different summation order"""
+    g = torch.Generator(device="cuda").manual_seed(M % 1000)
+    a = (torch.randn(M, 384, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    w = (torch.randn(N, 384, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1 if bias else None
+    got = ops.gemm_nt(a, w, bias=b)
+    torch.cuda.synchronize()
+    for sl in (slice(0, 4096), slice(M - 4096, M), slice(M // 2 - 1000, M // 2 + 1000)):
+        want = a[sl].double() @ w.double().t() + (b.double() if bias else 0)
+        err = (got[sl].double() - want).abs()
+        assert float((err / (want.abs() * 2 ** -7 + 2e-3)).max()) <= 1.0, float(err.max())
+        old = ops.gemm_nt(a[sl].contiguous(), w, bias=b)
+        assert float((old.float() - got[sl].float()).abs().max()) <= 2 ** -6 * float(want.abs().max())
+    again = ops.gemm_nt(a, w, bias=b)
+    assert torch.equal(got, again), "two launches on the same inputs must agree bit for bit"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [8192, 43904, 20000 // 16 * 16])
+def test_gemm_ws_df1_epilogue(ops, M):
+    """dF1 = (dy . W2) * gelu'(f1), ga = gelu(f1) with f1 in the fused feed-forward's tile-major layout (the forward's sigmoid-form
+    GELU), K = 384, N = 1536: against torch on the row-major f1"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ffn_fused_gpu import _f1_tiles
+    N = 1536
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = (torch.randn(M, 384, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, 384, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    f1 = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    ga = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    got = ops.gemm_nt(a, w, gelu_grad_of=_f1_tiles(f1, N), gelu_out=ga, gelu_grad_tiled=True)
+    x = f1.float().requires_grad_(True)
+    u = x * (1.59501576 + 7.40113008e-2 * x * x - 7.03034904e-4 * x ** 4)
+    y = x * torch.sigmoid(u)
+    (gp,) = torch.autograd.grad(y.sum(), x)
+    want = (a.float() @ w.float().t()) * gp
+    scale = float(want.abs().max())
+    assert float((got.float() - want).abs().max()) <= 1.2e-2 * scale
+    assert float((ga.float() - y.detach()).abs().max()) <= 2e-2 and float((ga.float() - y.detach()).abs().mean()) < 1e-3
