@@ -333,6 +333,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
 // false: shape not taken (the caller runs the 128 x 128 kernel)
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
                     const void* f1_tiled, void* ga, hipStream_t st) {
+#ifdef SM_WS_DISABLE  // (A/B builds of tools/: the 128 x 128 kernel everywhere)
+  return false;
+#endif
   if ((dtype != SM_BF16 && dtype != SM_F16) || K != WS_H || lda != WS_H || ldb != WS_H || ldc != N || N % 128 != 0 || M < 8192) return false;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)f1_tiled | (uintptr_t)ga) % 16) return false;
   if (dtype == SM_F16 && f1_tiled) return false;

@@ -118,6 +118,7 @@ class SparseModelTrainer:
         self._comm_stream = None
         self._pending = []
         self._q_prefetch = None
+        self._step_done = []  # events at the end of the last steps (training_step: bounded host lead)
         if self.accelerator.num_processes > 1:
             self._setup_grad_overlap()
             if sparse_model.backbone.device.type == "cuda":
@@ -479,6 +480,13 @@ class SparseModelTrainer:
         SM_TRACE_RANGES=1 brackets the phases with roctx ranges (rocprofv3 --marker-trace)."""
         self.model.train()
         bb = self.model.sparse_model.backbone
+        # The host never runs more than two steps ahead of the device.  Nothing in a step synchronises, so an unthrottled host
+        # queues dozens of steps; tensors handed to the weight-gradient stream (record_stream) cannot be recycled until the device
+        # reaches them, the caching allocator then grows by fresh hipMalloc calls (slow, synchronising) for as many steps as the
+        # host is ahead -- measured as 2x slower steps at the start of a run.  Two steps of lead hide every host gap.
+        if bb.device.type == "cuda":
+            if len(self._step_done) >= 2:
+                self._step_done.pop(0).synchronize()
         bb.set_dropout_seed(self.args.seed * 1000003 + self.state.global_step * 64 + self.accelerator.process_index)
         with _trace_range("forward+loss"):
             loss = self.compute_loss(self.model, inputs)
@@ -490,6 +498,10 @@ class SparseModelTrainer:
             self._optimizer_step()
             self.zero_grad()
         self.state.global_step += 1
+        if bb.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_done.append(ev)
         return loss.detach()
 
     def train(self):
