@@ -336,6 +336,12 @@ class SparseModelTrainer:
         try:
             enc = obj["docs"][0]
             bb = self.model.sparse_model.backbone
+            if not getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda and not int(getattr(self.data_args, "grad_cache_chunk", 0) or 0):
+                from sparse_hip.encoder import dense_embed_hints  # dense layout: only the embedding backward's sorted row lists
+                hints = dense_embed_hints(enc["input_ids"], enc["attention_mask"], self.accelerator.device,
+                                          bb.padded_len(enc["input_ids"].shape[1]))
+                if hints is not None:
+                    out["docs"][0]["packed"] = hints
             if getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda:
                 from sparse_hip.encoder import pack_documents
                 n = int(getattr(self.data_args, "grad_cache_chunk", 0) or 0)

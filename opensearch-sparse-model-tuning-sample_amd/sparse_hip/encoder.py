@@ -78,6 +78,32 @@ def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_
     return PackedDocs(t(pids, np.int64), t(valid, np.uint8), rag)
 
 
+class DenseHints:
+    """Host-side hints for a DENSE [B, S] batch (padding tokens computed): the attended rows sorted by token id and by position,
+    for the embedding backward's run-sum kernel (the dense layout otherwise scatters one atomic row per token row: 0.73 ms against
+    0.1 ms at 65 536 rows).  Travels in the `packed` argument like PackedDocs."""
+
+    def __init__(self, emb_sorted):
+        self.emb_sorted = emb_sorted
+
+
+def dense_embed_hints(input_ids: Tensor, attention_mask: Tensor, device, S_padded: int) -> Optional[DenseHints]:
+    import numpy as np
+
+    ids = input_ids.cpu().numpy()
+    mask = attention_mask.cpu().numpy() != 0
+    B, S = ids.shape
+    if S > S_padded:
+        return None
+    vb, vs = np.nonzero(mask)
+    vrows = (vb * S_padded + vs).astype(np.int64)  # row of the device's [B, S_padded] layout
+    pids, pos = ids[vb, vs].astype(np.int64), vs.astype(np.int64)
+    by_id, by_pos = np.argsort(pids, kind="stable"), np.argsort(pos, kind="stable")
+    dev = torch.device(device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
+    return DenseHints((t(vrows[by_id]), t(pids[by_id]), t(vrows[by_pos]), t(pos[by_pos])))
+
+
 @dataclass
 class BertConfigLite:
     """The BertConfig fields the path reads (config.json of the checkpoint)."""
@@ -571,7 +597,11 @@ class HipBertMLM(torch.nn.Module):
     def encode(self, input_ids: Tensor, attention_mask: Tensor, use_l0: bool = False,
                prune_ratio: Optional[float] = None, packed: Optional[PackedDocs] = None) -> Tensor:
         """rep[B,V] = log1p(relu(max_l mask*logits)) (scripts/model/sparse_encoders.py:107-119).
-        ``packed`` (from pack_documents) selects the ragged layout: padding tokens are not computed."""
+        ``packed`` (from pack_documents) selects the ragged layout: padding tokens are not computed; a DenseHints object keeps the
+        dense layout and only carries host-sorted row lists for the embedding backward."""
+        hints = packed if isinstance(packed, DenseHints) else None
+        if hints is not None:
+            packed = None
         if packed is not None:
             ids, mask, B, S = packed.ids, packed.mask, packed.rag.n_docs, packed.rag.max_len
         else:
@@ -581,7 +611,7 @@ class HipBertMLM(torch.nn.Module):
         training = self.training and (need_grad or self._dropout_without_grad)
         self._invocation += 1
         seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._invocation) & 0xFFFFFFFFFFFFFFFF
-        return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad, rag)
+        return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad, rag, hints)
 
     def encode_cached(self, chunks: List[Tuple[Tensor, Tensor, Optional[PackedDocs]]], use_l0: bool = False,
                       prune_ratio: Optional[float] = None) -> Tensor:
@@ -704,7 +734,7 @@ class _WgradStream:
 
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad, rag):
+    def forward(ctx, anchor, model: HipBertMLM, ids, mask, B, S, use_l0, prune_ratio, training, seed, need_grad, rag, hints=None):
         cfg = model.config
         x, saved = model._forward_impl(ids, mask, B, S, training, seed, need_grad, rag)
         v, st = model.view, model._staged
@@ -733,6 +763,7 @@ class _EncodeFn(torch.autograd.Function):
             ctx.model, ctx.saved = model, saved
             ctx.head = (x, ft, gt, mt, rt, tn, rep, argmax)
             ctx.meta = (ids, mask, B, S, use_l0, training, seed, rag)
+            ctx.hints = hints
         return rep
 
     @staticmethod
@@ -860,12 +891,13 @@ class _EncodeFn(torch.autograd.Function):
                                        g(e + "LayerNorm.bias"))
         if head_de_done is not None:  # both add into the tied word-embedding gradient, the head's half without atomics
             torch.cuda.current_stream().wait_event(head_de_done)
+        hints = getattr(ctx, "hints", None)
         ops.embed_bwd(dz0, ids, g(e + "word_embeddings.weight"), g(e + "position_embeddings.weight"),
-                      g(e + "token_type_embeddings.weight")[0], rag)
+                      g(e + "token_type_embeddings.weight")[0], rag, srt=hints.emb_sorted if hints is not None else None)
         wg.join()
         ctx.saved = ctx.head = None
         model._reattach_grads()
-        return (None,) * 12
+        return (None,) * 13
 
 
 HipBertMLM._layer_hook = None

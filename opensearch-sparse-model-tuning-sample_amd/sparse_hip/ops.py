@@ -246,13 +246,16 @@ def embed_fwd(ids: Tensor, word: Tensor, pos: Tensor, type0: Tensor, gamma: Tens
     return z, y, mean, rstd
 
 
-def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tensor, rag: Optional[Ragged] = None):
+def embed_bwd(dz: Tensor, ids: Tensor, gword: Tensor, gpos: Tensor, gtype0: Tensor, rag: Optional[Ragged] = None, srt=None):
+    """srt: (rows sorted by token id, their ids, rows sorted by position, their positions) -- from pack_documents (ragged layout) or
+    dense_embed_hints (dense layout; rows index dz)"""
     if rag is None:
         B, S = ids.shape
     else:
         B, S = rag.rows, 1
     H = dz.shape[1]
-    srt = getattr(rag, "emb_sorted", None) if rag is not None else None
+    if srt is None:
+        srt = getattr(rag, "emb_sorted", None) if rag is not None else None
     if srt is not None and dz.dtype == torch.bfloat16 and H % 128 == 0 and H // 128 in (1, 2, 3, 4, 6, 8):  # the widths the kernel instantiates
         # rows sorted on the host by token id and by position (pack_documents): run sums instead of one atomic row per token row
         order_id, ids_sorted, order_pos, pos_sorted = srt

@@ -672,3 +672,32 @@ def test_inference_postprocessor_matches_reference_golden_and_oracle():
                 assert abs(x - ref[t]) <= 1e-3 * (1 + abs(ref[t]))
     # do_count: per-token document frequencies of the batch (column 0 is never emitted)
     assert int(enc.count_tensor[1:].sum()) == sum(len(d) for d in out)
+
+
+def test_dense_layout_embedding_backward_with_host_sorted_rows():
+    """dense [B, S] batches carry host-sorted row lists (DenseHints) so that the embedding backward sums runs of equal token ids
+    instead of scattering one atomic row per token row: same gradients as the scatter kernel (bf16 rows, fp32 sums: the order of
+    the additions differs)"""
+    from scripts.model.sparse_encoders import SparseModel
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM, dense_embed_hints
+    cfg = BertConfigLite(vocab_size=3000, hidden_size=128, num_hidden_layers=1, num_attention_heads=4, intermediate_size=256,
+                         max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 60, (12, 48), generator=g)   # few distinct ids: long runs
+    lens = torch.randint(3, 49, (12,), generator=g)
+    mask = (torch.arange(48)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    grads = []
+    for use_hints in (False, True):
+        bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=5)
+        m = SparseModel(bb, use_l0=False)
+        m.train()
+        hints = dense_embed_hints(ids, mask, "cuda", bb.padded_len(48)) if use_hints else None
+        rep = m(inf_free=False, input_ids=ids.cuda(), attention_mask=mask.cuda(), packed=hints)
+        (rep * rep).sum().backward()
+        grads.append({n: bb.view(n, grad=True).float().clone() for n in ("bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+                                                                        "bert.embeddings.token_type_embeddings.weight")})
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-6, n
+    assert float(grads[1]["bert.embeddings.word_embeddings.weight"].abs().sum()) > 0
