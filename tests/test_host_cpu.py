@@ -251,3 +251,19 @@ def test_gather_rep_two_process_gloo(tmp_path):
         capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_dense_embed_hints_sort_the_attended_rows():
+    """host side of the dense-layout embedding backward: attended rows of the [B, S_padded] device layout, sorted by token id and by
+    position (stable), padding rows left out"""
+    import numpy as np
+    import torch
+    from sparse_hip.encoder import dense_embed_hints
+    ids = torch.tensor([[7, 3, 7, 0], [3, 9, 0, 0], [7, 0, 0, 0]])
+    mask = (ids != 0).long()
+    h = dense_embed_hints(ids, mask, "cpu", 16)   # the device pads S = 4 to 16
+    rows_id, ids_sorted, rows_pos, pos_sorted = (t.numpy() for t in h.emb_sorted)
+    assert ids_sorted.tolist() == [3, 3, 7, 7, 7, 9]
+    assert rows_id.tolist() == [1, 16, 0, 2, 32, 17]          # b * 16 + s, stable inside a run
+    assert pos_sorted.tolist() == [0, 0, 0, 1, 1, 2] and rows_pos.tolist() == [0, 16, 32, 1, 17, 2]
+    assert dense_embed_hints(ids, mask, "cpu", 2) is None     # the device layout cannot be narrower than the batch
