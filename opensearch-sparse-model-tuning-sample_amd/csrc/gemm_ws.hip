@@ -31,6 +31,9 @@ constexpr int WS_NST = 5, WS_D = 8;                                             
 constexpr int WS_HSTRIDE = 132 * 4, WS_HBUF = 32 * WS_HSTRIDE;                            // hand-over tile: 32 rows of 132 floats
 constexpr int WS_LDS = WS_NST * WS_STAGE + 2 * WS_HBUF;                                   // 122880 + 33792 = 156672
 constexpr int WS_BAR_KS = 4;  // B_s sits behind MFMA 4 of step s
+#ifndef WS_ROUNDS
+#define WS_ROUNDS 1  // (2: two rounds of half-size workgroups -- measured: 5-20 % slower alone, no different in the step)
+#endif
 static_assert(WS_LDS <= 160 * 1024, "LDS budget");
 
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -349,7 +352,7 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
   a.M = M;
   a.N = N;
   const int ncs = N / 128;
-  int rs = 256 / ncs;  // one round of (at most) 256 workgroups
+  int rs = WS_ROUNDS * 256 / ncs;  // WS_ROUNDS rounds of (at most) 256 workgroups
   const int steps_all = (M + 31) / 32;
   if (rs > steps_all / 8) rs = steps_all / 8;  // at least 8 steps per workgroup: the weight slice is loaded once per workgroup
   if (rs < 1) rs = 1;
