@@ -137,7 +137,7 @@ class GemmRoofline:
     def __init__(self, ops):
         self.ops, self.rec, self.orig = ops, {}, {}
 
-    def _wrap(self, name, flops):
+    def _wrap(self, name, flops, label=None):
         orig = getattr(self.ops, name)
         self.orig[name] = orig
 
@@ -147,12 +147,24 @@ class GemmRoofline:
             out = orig(*a, **kw)
             e1.record()
             if out is not None:  # (a fused entry point that declines the shape returns None and its caller runs the unfused ops, which
-                self.rec.setdefault(name, []).append((e0, e1, flops(*a, **kw)))  # are counted themselves)
+                key = name if label is None else label(*a, **kw)                     # are counted themselves)
+                self.rec.setdefault(key, []).append((e0, e1, flops(*a, **kw)))
             return out
         setattr(self.ops, name, wrapped)
 
+    @staticmethod
+    def _nt_label(A, B, *a, n=None, **k):
+        """which kernel an NT launch takes (csrc/gemm.hip launch_gemm_nt): the weight-stationary one (K = 384, plain or dF1 epilogue,
+        >= 8192 rows, bf16) or a tile kernel"""
+        plain = not any(k.get(x) for x in ("act", "preact", "drop", "residual", "out_f32", "residual_ln"))
+        epi0 = k.get("gelu_grad_of") is None and k.get("gelu_out") is None
+        epi1 = k.get("gelu_grad_of") is not None and k.get("gelu_grad_tiled") and k.get("bias") is None
+        N = B.shape[0] if n is None else n
+        ws = A.dtype == torch.bfloat16 and A.shape[1] == 384 and A.shape[0] >= 8192 and N % 128 == 0 and plain and (epi0 or epi1)
+        return "gemm_nt (weight-stationary, K = 384)" if ws else "gemm_nt (tile kernels)"
+
     def __enter__(self):
-        self._wrap("gemm_nt", lambda A, B, *a, n=None, **k: 2.0 * A.shape[0] * A.shape[1] * (B.shape[0] if n is None else n))
+        self._wrap("gemm_nt", lambda A, B, *a, n=None, **k: 2.0 * A.shape[0] * A.shape[1] * (B.shape[0] if n is None else n), self._nt_label)
         self._wrap("gemm_nt_ln_bwd", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
         self._wrap("gemm_tn_acc", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
         # the fused feed-forward forward (LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2): its two GEMMs' FLOPs
