@@ -783,7 +783,8 @@ def test_scores_on_the_matrix_pipe(ops, nq, nd):
 
 # ---- weight-stationary NT GEMM for K = 384 (csrc/gemm_ws.hip) ------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,bias", [(8192, 1152, True), (43904 + 16, 384, False), (12345 // 16 * 16, 1536, True), (65536, 1152, True)])
+@pytest.mark.parametrize("M,N,bias", [(8192, 1152, True), (43904 + 16, 384, False), (12345 // 16 * 16, 1536, True), (65536, 1152, True),
+                                      (8200 + 9, 128, True), (9001, 2048, False)])  # (rows that are no multiple of 16 / 32; one and sixteen column slices)
 def test_gemm_ws_plain_epilogue(ops, M, N, bias):
     """C = A . W^T (+ bias) at K = 384, M >= 8192 through the weight-stationary kernel: against the fp64 product at bf16 rounding, and
     against the 128 x 128 kernel (taken below 8192 rows) on the first and last rows -- same products, different summation order"""
