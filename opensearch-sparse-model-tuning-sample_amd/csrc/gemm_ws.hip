@@ -64,6 +64,14 @@ template <bool F16> __device__ __forceinline__ f32x16 ws_mma(bf16x8 a, bf16x8 b,
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// -DWS_STAMPS: shader-clock stamps of workgroup 8 (tools/gemm_ws_stamps.py); nothing in a normal build
+#ifdef WS_STAMPS
+__device__ unsigned long long ws_stamps[4][128];
+#define WS_STAMP(ROLE, IDX) do { if (blockIdx.x == 8 && lane == 0 && (IDX) < 128) ws_stamps[ROLE][IDX] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(ROLE, IDX) do { } while (0)
+#endif
+
 struct WsArgs {
   const bf16* A;        // [M, 384] 16-bit (bf16, or fp16 with F16)
   const bf16* W;        // [N, 384] same type
@@ -169,7 +177,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
     for (int t = 0; t < nsteps + 2; ++t) {
       __builtin_amdgcn_s_barrier();  // B_t
       asm volatile("" ::: "memory");
+      if (sw == 0) WS_STAMP(2, 2 * t);
       if (t >= 2) process(t - 2);
+      if (sw == 0) WS_STAMP(2, 2 * t + 1);
     }
     return;
   }
@@ -217,9 +227,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
       if (s < nsteps) issue(s);
     for (int s = 0; s < nsteps; ++s) {
       wait_landed(s);
+      if (lw == 0) WS_STAMP(1, 3 * s);
       __builtin_amdgcn_s_barrier();  // B_s
       asm volatile("" ::: "memory");
+      if (lw == 0) WS_STAMP(1, 3 * s + 1);
       if (s + NST - 1 < nsteps) issue(s + NST - 1);
+      if (lw == 0) WS_STAMP(1, 3 * s + 2);
     }
     __builtin_amdgcn_s_barrier();  // B_nsteps, B_nsteps+1: the storers' last two tiles
     __builtin_amdgcn_s_barrier();
@@ -257,8 +270,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
     else ws_lds_write32<OFF>(hw, acc[i]);
   };
 
+  if (w == 0) WS_STAMP(0, 0);
   __builtin_amdgcn_s_barrier();  // B_0: stages 0 and 1 are in LDS
   asm volatile("" ::: "memory");
+  if (w == 0) WS_STAMP(0, 1);
   ws_static_for<0, D>([&](auto jc) {
     constexpr int jj = decltype(jc)::value;
     WS_READ(jj, 0);
@@ -280,8 +295,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
         acc = ws_mma<F16>(af[ks % D], fb[ks], acc);
       }
       if constexpr (ks == BAR_KS && !FIRST) {
+        if (w == 0) WS_STAMP(0, 2 * s);
         __builtin_amdgcn_s_barrier();  // B_s
         asm volatile("" ::: "memory");
+        if (w == 0) WS_STAMP(0, 2 * s + 1);
       }
       if constexpr (ks + D < KS) WS_READ(ks + D, SLOT);
       else WS_READ(ks + D - KS, NEXT);  // (past the last stage: stale LDS, never used; keeps the lgkmcnt arithmetic valid)
@@ -332,6 +349,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
 }
 
 }  // namespace
+
+#ifdef WS_STAMPS
+extern "C" int sm_ws_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_stamps), sizeof(ws_stamps)); }
+#endif
 
 // false: shape not taken (the caller runs the 128 x 128 kernel)
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
