@@ -32,7 +32,7 @@ buf = (C.c_ulonglong * 512)()
 assert dbg.sm_ws_debug_stamps(buf) == 0
 st = np.array(buf, dtype=np.uint64).reshape(4, 128).astype(np.int64)
 t0 = st[0][0]
-k = lambda r, i: (st[r][i] - t0) / 1000.0
+k = lambda r, i: (st[r][i] - t0) / 1000.0 if st[r][i] > 0 else float("nan")   # (steps this workgroup did not have print nan)
 print(f"[{T} x {N} x 384] {e0.elapsed_time(e1) * 50:.1f} us per launch; kilo-cycles since compute wave 0 reached B_0 (workgroup 8)")
 print("  compute wave 0: B_0 passed %.2f;" % k(0, 1), "arrives / passes B_s: " + " ".join(f"{k(0, 2 * s):.2f}/{k(0, 2 * s + 1):.2f}" for s in (1, 2, 3, 10, 20, 30, 40)))
 print("  loader 0: landed / barrier passed / issued, steps 0 1 2 10 20 30: " + " ".join(f"{k(1, 3 * s):.2f}/{k(1, 3 * s + 1):.2f}/{k(1, 3 * s + 2):.2f}" for s in (0, 1, 2, 10, 20, 30)))
