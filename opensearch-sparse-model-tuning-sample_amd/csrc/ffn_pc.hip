@@ -37,8 +37,6 @@ typedef __attribute__((address_space(3))) char lds_char;
 constexpr int PC_H = 384, PC_KS = PC_H / 16, PC_NT = PC_H / 32, PC_IC = 32, PC_TOK = 128;
 constexpr int PC_CHUNK = PC_IC * PC_H * 2;  // bytes of one chunk of either weight: 24 pieces of 1 KiB
 constexpr int PC_W1_OFF = 0, PC_W2_OFF = 3 * PC_CHUNK, PC_G_OFF = PC_W2_OFF + 3 * PC_CHUNK;
-constexpr int PC_STAT_OFF = PC_G_OFF;                 // LayerNorm-1 statistics: written before P0, read right behind it (then the hand-over buffers own the bytes)
-constexpr int PC_VEC_OFF = PC_W1_OFF;                 // epilogue: bias2 | ln1_g | ln1_b | ln2_g | ln2_b (5 x 384 fp32) in the idle ring 1
 constexpr int PC_LDS = PC_G_OFF + 2 * 4 * 2048;       // 160 KiB exactly
 constexpr int PC_RING = 8, PC_D = 6;  // fragment registers / reads in flight of either role
 
