@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 3
+#define SM_ABI_VERSION 4
 #define SM_F32 0
 #define SM_BF16 1
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
@@ -134,36 +134,16 @@ int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, fl
                    int M, int N, int Kc, float* colsum, void* stream);
 
 /* ---- fused feed-forward block, hidden size 384, fp32 residual stream (hf:334-351: intermediate.dense -> GELU ->
- * output.dense -> dropout -> + residual -> LayerNorm, together with the attention-output LayerNorm hf:293 in front of it) ----
- * The [T, I] intermediate never makes a round trip through HBM between the two GEMMs (csrc/ffn_fused.hip).
- * Every entry point returns 0 when the fused kernel ran, 1 when the shape is not eligible (H != 384, I % 64, T % 16: run the
- * unfused sm_gemm_nt / sm_layernorm_* sequence), < 0 on error.
- *
- * sm_ffn_stage: the operand copies of ALL layers in one launch (the layers of a flat parameter buffer are equally spaced:
- * w1 / w2 point at layer 0, layer l is layer_stride floats further).  op_f16 = 1: fp16 forward operands (same MFMA rate as
- * bf16, three more mantissa bits), 0: bf16.
- *   w1h  [L][I][H]        W1 in the forward operand type
- *   w2p  [L][I/32][H][32] W2[n][32c + kk(p)] at position p of chunk c, forward operand type
- *   w1tp [L][I/32][H][32] W1[32c + kk(p)][n], bf16 (backward);  kk(8g + j) = 4g + j for j < 4, 16 + 4g + (j - 4) otherwise
- * (any of the three may be NULL) */
-int sm_ffn_stage(int op_f16, const float* w1, const float* w2, long layer_stride, int layers, int H, int I, void* w1h, void* w2p,
-                 void* w1tp, void* stream);
-/* forward: x1 = LN(z1; ln1);  f1 = x1 W1^T + bias1;  z2 = dropout(gelu(f1) W2^T + bias2) + x1 (fp32);  x2 = LN(z2; ln2).
- * z1 [T,H] fp32 in; out: x1 (bf16, for the W1 weight gradient), m1 / r1, f1 [T,I] bf16 (NULL: not saved), z2 [T,H] fp32,
- * x2 [T,H] bf16, m2 / r2.  w1h / w2p: one layer's slices of the staged copies. */
-int sm_ffn_fwd(int op_f16, const float* z1, const float* ln1_g, const float* ln1_b, float eps, const void* w1h, const float* bias1,
-               const void* w2p, const float* bias2, const float* ln2_g, const float* ln2_b, const sm_dropout* drop, void* x1,
-               float* m1, float* r1, void* f1, float* z2, void* x2, float* m2, float* r2, int T, int H, int I, void* stream);
-/* backward (bf16 operands): dF1 = (dy W2) * gelu'(f1), written with gelu(f1) for the two weight-gradient GEMMs;
- * dx1 = dF1 W1 + dres;  dz1 = LN'(dx1 | z1, ln1_g, m1, r1), dz1d = dropout_bwd(dz1) (NULL: not wanted); dgamma / dbeta
- * accumulated.  w2t [I,H] bf16 = W2^T (the staged transpose of sm_cast_weight), w1tp from sm_ffn_stage. */
-int sm_ffn_bwd(const void* dy, const void* dres, const void* f1, const void* w2t, const void* w1tp, const float* z1,
-               const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
-               void* dz1d, float* dgamma, float* dbeta, int T, int H, int I, void* stream);
-
-/* ---- the same block in PRODUCER / CONSUMER form (csrc/ffn_pc.hip: a pair of waves per 32 tokens, 32x32x16 MFMAs, weights
- * staged fragment-major so that every LDS-DMA piece is one linear KiB).  Same contract as sm_ffn_fwd; its operands come from
- * sm_ffn_pc_stage (e = ((c * 24 + piece) * 64 + lane) * 8 + j, lane = (kg, r) = (lane >> 5, lane & 31)):
+ * output.dense -> dropout -> + residual -> LayerNorm, together with the attention-output LayerNorm hf:293 in front of it) in
+ * PRODUCER / CONSUMER form (csrc/ffn_pc.hip: a pair of waves per 32 tokens, 32x32x16 MFMAs, weights staged fragment-major so that
+ * every LDS-DMA piece is one linear KiB).  The [T, I] intermediate never makes a round trip through HBM between the two GEMMs.
+ * Every entry point returns 0 when the fused kernel ran, 1 when the shape is not eligible (H != 384, I % 32, T % 16: run the
+ * unfused sm_gemm_nt / sm_layernorm_* sequence), < 0 on error.  op_f16 = 1: fp16 forward operands (same MFMA rate as bf16, three
+ * more mantissa bits), 0: bf16.
+ * forward: x1 = LN(z1; ln1);  f1 = x1 W1^T + bias1;  z2 = dropout(gelu(f1) W2^T + bias2) + x1 (fp32);  x2 = LN(z2; ln2).
+ * z1 [T,H] fp32 in; out: x1 (bf16, for the W1 weight gradient), m1 / r1, f1 (NULL: not saved), z2 [T,H] fp32, x2 [T,H] bf16,
+ * m2 / r2.  Its operands come from sm_ffn_pc_stage: the copies of ALL layers in one launch (the layers of a flat parameter buffer
+ * are equally spaced: w1 / w2 point at layer 0, layer l is layer_stride floats further) (e = ((c * 24 + piece) * 64 + lane) * 8 + j, lane = (kg, r) = (lane >> 5, lane & 31)):
  *   w1f  [L][I/32][24][64][8]  W1[32c + r][16 piece + 8 kg + j]                                   forward GEMM 1, operand type
  *   w2f  [L][I/32][24][64][8]  W2[32 (piece >> 1) + r][32c + kp(piece & 1, kg, j)]                forward GEMM 2, operand type
  *   w2tf [L][I/32][24][64][8]  W2[16 piece + 8 kg + j][32c + r]                                    backward GEMM A, bf16

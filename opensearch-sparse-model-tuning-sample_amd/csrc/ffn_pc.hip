@@ -144,7 +144,7 @@ template <int N> __device__ __forceinline__ float pc_lanes_sum(float v) {  // su
 }
 constexpr int PC_EROW = 192 * 4 + 16;  // epilogue staging: row stride of a [128 rows][192 columns] fp32 half tile (bank-spreading pad)
 
-template <bool F16>
+template <bool F16, bool SAVE_F1>
 __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   using OP = PcOp<F16>;
   using V = typename OP::V;
@@ -463,25 +463,24 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
 
   // f1 in the kernels' private TILE-MAJOR layout: (group of 32 tokens, chunk, lane) -> 16 bf16 = the lane's 16 accumulator
   // registers, 32 contiguous bytes (the fused backward reads it back the same way)
-  bf16* const f1lane = a.f1 ? a.f1 + ((size_t)(blockIdx.x * 4 + t) * NC * 64 + lane) * 16 : nullptr;
+  bf16* const f1lane = SAVE_F1 ? a.f1 + ((size_t)(blockIdx.x * 4 + t) * NC * 64 + lane) * 16 : nullptr;
   // Accumulator initialised with the bias: register 4 q + k <-> chunk row 8 q + 4 hh + k (four 16-byte loads that every lane of a
-  // half shares: L1 hits).  The loads are issued in assembly one step ahead and awaited with a COUNTED vmcnt: left to the compiler
-  // the wait is vmcnt(0), which, vmcnt being in order, also drains the f1 stores the previous step issued last.  Vector-memory operations of a producer step, in issue order: 4 bias loads at
-  // gap 0, then the two f1 stores (training only).
+  // half shares: L1 hits), fetched one step ahead (gap 0 of step s - 1 for chunk s + 1).  PLAIN loads, awaited by the compiler's
+  // own wait-count: with SAVE_F1 a compile-time switch it counts the two f1 stores behind them exactly (vmcnt(2)).  Round 3 issued
+  // them as inline assembly with a hand-counted `s_waitcnt vmcnt(2)` whose "+v" operands the register allocator was free to tie
+  // to the ACCUMULATOR tuple -- it then copied the four destination registers into the accumulator BEFORE the wait, i.e. whatever
+  // those registers held (weight fragments of the previous MFMAs) whenever a load took longer than a step: a rare, load-latency
+  // dependent garbage bias (GPUTEST_r03's training collapse).  A register that a load is still writing must
+  // never be visible to the compiler as a finished value.
   const float* const bias_lane = a.bias1 + 4 * hh;
-  const bool has_f1 = a.f1 != nullptr;
   auto bias_issue = [&](int c, f32x4(&b)[4]) __attribute__((always_inline)) {
-    const float* bp = bias_lane + c * PC_IC;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[0]) : "v"(bp));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(b[1]) : "v"(bp));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(b[2]) : "v"(bp));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(b[3]) : "v"(bp));
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bias_lane + c * PC_IC);
+    b[0] = bp[0];
+    b[1] = bp[2];
+    b[2] = bp[4];
+    b[3] = bp[6];
   };
-  auto bias_take = [&](f32x4(&b)[4], bool all) __attribute__((always_inline)) -> f32x16 {
-    // everything but the tail of the previous step has landed
-    if (all) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    else if (has_f1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  auto bias_take = [&](const f32x4(&b)[4]) __attribute__((always_inline)) -> f32x16 {
     f32x16 x;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -534,7 +533,7 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
       ghi = OP::pack(hi8);
       asm volatile("" : "+v"(ghi));
     } else if constexpr (k == 21 || k == 22) {
-      if (has_f1) {  // rows past T included: the f1 buffer is whole 128-row blocks (counted vmcnt: the stores are unconditional)
+      if constexpr (SAVE_F1) {  // rows past T included: the f1 buffer is whole 128-row blocks
         bf16x8 f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = (bf16)X[(k - 21) * 8 + j];
@@ -553,20 +552,22 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
 
   f32x4 bn[4];
   bias_issue(0, bn);
-  f32x16 X = bias_take(bn, true);
+  f32x16 X = bias_take(bn);
   pc_stream24<V>(lbase + PC_W1_OFF,
                  [&](auto kc, V fr) __attribute__((always_inline)) {
                    constexpr int k = decltype(kc)::value;
                    X = OP::mma(fr, xb[k], X);
                  },
                  [&](auto) __attribute__((always_inline)) {});
-  bias_issue(1, bn);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]));
+  bias_issue(min(1, NC - 1), bn);
+  // (a use here: the compiler waits for these four loads BEFORE the loop -- otherwise the loop head inherits them as pending and
+  //  every iteration's first MFMA waits vmcnt(4), i.e. for the previous step's f1 stores as well)
+  asm volatile("" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]));
   __builtin_amdgcn_s_barrier();  // P1
   asm volatile("" ::: "memory");
   PC_STAMP(0, 2);
   for (int s = 0; s + 1 < NC; ++s) {
-    f32x16 Xn = bias_take(bn, false);  // chunk s + 1's bias, issued at gap 0 of step s - 1
+    f32x16 Xn = bias_take(bn);  // chunk s + 1's bias, issued at gap 0 of step s - 1
     pc_stream24<V>(lbase + PC_W1_OFF + (uint32_t)(((s + 1) % 3) * PC_CHUNK),
                    [&](auto kc, V fr) __attribute__((always_inline)) {
                      constexpr int k = decltype(kc)::value;
@@ -664,13 +665,10 @@ extern "C" int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, co
   const int lds = PC_LDS;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = sm_cdiv(T, PC_TOK);
-  if (op_f16) {
-    SM_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_pc_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(ffn_pc_fwd_kernel<true>, dim3(blocks), dim3(512), lds, st, a);
-  } else {
-    SM_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_pc_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(ffn_pc_fwd_kernel<false>, dim3(blocks), dim3(512), lds, st, a);
-  }
+  auto kern = op_f16 ? (f1 ? ffn_pc_fwd_kernel<true, true> : ffn_pc_fwd_kernel<true, false>)
+                     : (f1 ? ffn_pc_fwd_kernel<false, true> : ffn_pc_fwd_kernel<false, false>);
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, a);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

@@ -420,23 +420,38 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
   };
   constexpr std::true_type T_{};
   constexpr std::false_type F_{};
-  f32x16 acc0, acc1;
-  step(0, acc0, acc0, T_);
-  // steps 1 .. nsteps - 1, two per iteration so that the accumulators ping-pong without copies
-  auto one = [&](int s, f32x16& acc, const f32x16& prev) { step(s, acc, prev, F_); };
-  int s = 1;
-  for (; s + 1 < nsteps; s += 2) {
-    one(s, acc1, acc0);
-    one(s + 1, acc0, acc1);
-  }
-  // the last step's blocks (the second one may not exist) and the last document are finished here, with branches
-  auto finish = [&](const f32x16& acc) {
-    // the last step's look-ahead reads are still in flight: their destination registers must stay reserved until they land
-    static_assert(D >= 8, "the operand list below names the first 8 fragments");
+  // A step ends with its look-ahead reads (the next stage's first D fragments) IN FLIGHT.  The compiler does not know that: to it
+  // a[] are finished values from the asm statement on, and on a control-flow edge where its register assignment changes (loop
+  // entry / exit, the peeled last step) it copies them -- round 3's build copied all eight at the loop exit, ~150 cycles behind
+  // the last ds_read, into the registers the peeled step reads (tools/asm_hazard_check.py).  So: no read is in flight across
+  // the loop's entry or exit -- `drain` is the wait, with a[] as operands so the copies cannot be hoisted above it.
+  static_assert(D == 8, "the operand list below names all D fragments");
+  auto drain = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
                  :
                  : "memory");
+  };
+  f32x16 acc0, acc1;
+  step(0, acc0, acc0, T_);
+  drain();
+  // steps 1 .. nsteps - 1, two per iteration so that the accumulators ping-pong without copies
+  auto one = [&](int s, f32x16& acc, const f32x16& prev) { step(s, acc, prev, F_); };
+  int s = 1;
+  if (s + 1 < nsteps) {
+    for (;;) {
+      one(s, acc1, acc0);
+      one(s + 1, acc0, acc1);
+      s += 2;
+      if (!(s + 1 < nsteps)) {  // the loop's only exit: the wait sits on it
+        drain();
+        break;
+      }
+    }
+  }
+  // the last step's blocks (the second one may not exist) and the last document are finished here, with branches
+  auto finish = [&](const f32x16& acc) {
+    drain();  // the last step's look-ahead reads: their destination registers must stay reserved until they land
     epilogue(acc, nblk - 2 * (nsteps - 1), meta_prev);
     if (cur >= 0) store_doc(cur, __float_as_uint(run));
   };

@@ -101,6 +101,11 @@ class TrainingArguments:
     # a checkpoint-N directory written by this trainer (HF-layout weights + trainer_state.pt): weights, AdamW moments and the
     # step counter are restored (the reference never wires this, train_ir.py:143; a set key must not restart silently)
     resume_from_checkpoint: Optional[str] = None
+    # extension (no HF key): after backward and after the optimiser update of EVERY step, check the flat gradient / parameter
+    # buffers for NaN / Inf and raise FloatingPointError naming the tensors (one device reduction + one host sync per check:
+    # a debugging mode; SM_CHECK_FINITE=1 switches it on too).  The reference would surface a dead run in its logged loss
+    # (trainer.py:120-138); a relu after a NaN hides it (max(NaN, 0) = 0), so the check looks at the buffers themselves
+    check_finite: bool = False
     # set by the launcher (train_ir.py) from the torchrun environment; what the dataset loaders shard by
     world_size: int = 1
     local_process_index: int = 0

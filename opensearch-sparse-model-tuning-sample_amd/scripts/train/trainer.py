@@ -500,8 +500,13 @@ class SparseModelTrainer:
             loss.backward()
         with _trace_range("grad_reduce"):
             self._finish_grad_reduce()
+        check = getattr(self.args, "check_finite", False) or _CHECK_FINITE
+        if check:
+            self._raise_if_nonfinite(grad=True, loss=loss)
         with _trace_range("optimizer"):
             self._optimizer_step()
+            if check:
+                self._raise_if_nonfinite(grad=False)
             self.zero_grad()
         self.state.global_step += 1
         if bb.device.type == "cuda":
@@ -509,6 +514,19 @@ class SparseModelTrainer:
             ev.record()
             self._step_done.append(ev)
         return loss.detach()
+
+    def _raise_if_nonfinite(self, grad: bool, loss=None) -> None:
+        """check_finite mode: name every parameter (or gradient) tensor that holds a NaN / Inf at this point of the step"""
+        sm = self.model.sparse_model
+        what = "gradient" if grad else "parameter"
+        bad = [f"{n} ({c} of {tot})" for n, c, tot in sm.backbone.nonfinite_report(grad=grad)]
+        idf = sm.idf_vector.grad if grad else sm.idf_vector.data
+        if sm.idf_vector.requires_grad and idf is not None and not bool(torch.isfinite(idf).all()):
+            bad.append("idf_vector")
+        if loss is not None and not bool(torch.isfinite(loss.detach()).all()):
+            bad.insert(0, "loss")
+        if bad:
+            raise FloatingPointError(f"step {self.state.global_step}: non-finite {what} values in " + ", ".join(bad))
 
     def train(self):
         a = self.args
@@ -544,6 +562,7 @@ class SparseModelTrainer:
 
 
 _TRACE_RANGES = os.environ.get("SM_TRACE_RANGES", "0") == "1"
+_CHECK_FINITE = os.environ.get("SM_CHECK_FINITE", "0") == "1"
 
 
 class _trace_range:

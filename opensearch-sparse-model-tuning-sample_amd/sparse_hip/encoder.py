@@ -193,18 +193,14 @@ class HipBertMLM(torch.nn.Module):
         self.residual_fp32 = (True if residual_fp32 is None else bool(residual_fp32)) and compute_dtype != torch.float32
         self.with_head = with_head
         H = cfg.hidden_size
-        # Fused feed-forward block (csrc/ffn_fused.hip: LayerNorm-1 + FFN-up + GELU + FFN-down + residual + LayerNorm-2 in one
-        # launch, its backward in another; the [T, I] intermediate stays on the chip between the two GEMMs): bf16 runs with the
-        # fp32 residual stream at hidden size 384.  ffn_f16: its FORWARD operands are fp16 instead of bf16 (same MFMA rate, three
-        # more mantissa bits; gradients stay bf16).  OPT-IN (SM_FUSED_FFN=1): measured LDS-read bound, not faster than the unfused
-        # launches at the bench shape (csrc/ffn_fused.hip header); SM_FFN_F16=0 selects bf16 operands.
-        self.fused_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
-                          and cfg.intermediate_size >= 128 and os.environ.get("SM_FUSED_FFN", "0") == "1")
+        # Fused feed-forward FORWARD (csrc/ffn_pc.hip: LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2 in one
+        # producer / consumer launch, 195-215 us against 250-265 us of the unfused launches at 43.9 k rows): bf16 runs with the fp32
+        # residual stream at hidden size 384; the backward stays unfused and reads the kernel's tile-major f1 in the dF1 epilogue.
+        # ffn_f16: its operands are fp16 instead of bf16 (same MFMA rate, three more mantissa bits; gradients stay bf16).
+        # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_fused_gpu.py).
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
-        # pc_ffn: the FORWARD of the same block in producer / consumer form (csrc/ffn_pc.hip: 195-215 us against 250-265 us of the
-        # unfused launches at 43.9 k rows); the backward stays unfused and reads the kernel's tile-major f1 in the dF1 epilogue.
         self.pc_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
-                       and cfg.intermediate_size >= 128 and not self.fused_ffn and os.environ.get("SM_PC_FFN", "1") == "1")
+                       and cfg.intermediate_size >= 128 and os.environ.get("SM_PC_FFN", "1") == "1")
         # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
         # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
         # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
@@ -226,8 +222,8 @@ class HipBertMLM(torch.nn.Module):
         self._fp8_delayed = os.environ.get("SM_FP8_DELAYED", "1") != "0"
         self._fp8_sites, self._fp8_cur, self._fp8_next, self._fp8_ready = {}, None, None, set()
         if self.fp8:
-            self.fused_ffn = self.pc_ffn = False
-        self.ffn_fwd_f16 = (self.fwd_f16 and not self.fused_ffn and not self.pc_ffn and not self.fp8
+            self.pc_ffn = False
+        self.ffn_fwd_f16 = (self.fwd_f16 and not self.pc_ffn and not self.fp8
                             and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1")
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
@@ -365,6 +361,22 @@ class HipBertMLM(torch.nn.Module):
     def mark_weights_dirty(self) -> None:
         self._weights_dirty = True
 
+    def nonfinite_report(self, grad: bool = False) -> List[Tuple[str, int, int]]:
+        """(name, non-finite elements, elements) of every parameter (grad: gradient) tensor that holds a NaN / Inf, in
+        flat-buffer order; [] when the whole buffer is finite (one reduction + one host read in that case)."""
+        buf = self.flat_grad if grad else self.flat_param
+        bad = ~torch.isfinite(buf)
+        if not bool(bad.any()):
+            return []
+        out = []
+        for name, shape in self._layout:
+            o, _ = self._offsets[name]
+            n = int(math.prod(shape))
+            c = int(bad[o:o + n].sum())
+            if c:
+                out.append((name, c, n))
+        return out
+
     # ------------------------------------------------------------------ staging copies
     def sync_weights(self) -> None:
         """Refresh the compute-dtype copies (and transposes) of every GEMM weight."""
@@ -411,18 +423,6 @@ class HipBertMLM(torch.nn.Module):
                 self._cast_table16 = ops.CastTable(ent)
                 self._cast_key16 = key16
             self._cast_table16.run()
-        if self.fused_ffn and cfg.num_hidden_layers > 0:
-            nl = cfg.num_hidden_layers
-            op = torch.float16 if self.ffn_f16 else torch.bfloat16
-            if "ffn_w1h" not in st:
-                st["ffn_w1h"] = torch.empty((nl, I, H), dtype=op, device=dev)
-                st["ffn_w2p"] = torch.empty((nl, I // 32, H, 32), dtype=op, device=dev)
-                st["ffn_w1tp"] = torch.empty((nl, I // 32, H, 32), dtype=torch.bfloat16, device=dev)
-            n0 = "bert.encoder.layer.0."
-            stride = (self._offsets["bert.encoder.layer.1.intermediate.dense.weight"][0]
-                      - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
-            ops.ffn_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
-                          st["ffn_w1h"], st["ffn_w2p"], st["ffn_w1tp"])
         if self.pc_ffn and cfg.num_hidden_layers > 0:
             nl = cfg.num_hidden_layers
             op = torch.float16 if self.ffn_f16 else torch.bfloat16
@@ -522,19 +522,6 @@ class HipBertMLM(torch.nn.Module):
             ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, d_at, rag)
             z1 = self._lin(ctx, f"o{l}", bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
                              residual_ln=res_ln)
-            if self.fused_ffn:  # LayerNorm 1 .. LayerNorm 2 in one launch; gelu(f1) is not stored (the fused backward re-creates it)
-                g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
-                g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
-                fused = ops.ffn_fwd(z1, g1, b1, eps, st["ffn_w1h"][l], v(p + "intermediate.dense.bias"), st["ffn_w2p"][l],
-                                    v(p + "output.dense.bias"), g2, b2, d_h2, save_f1=save)
-                if fused is None:
-                    raise L.SparseHipError("fused feed-forward kernel declined a shape it was enabled for")
-                x1, m1, r1, f1, z2, x2, m2, r2 = fused
-                x32, res_ln = z2, (m2, r2, g2, b2)
-                if save:
-                    saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
-                x = x2
-                continue
             fused = None
             if self.pc_ffn and z1.shape[0] % 16 == 0:
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
@@ -826,30 +813,19 @@ class _EncodeFn(torch.autograd.Function):
                                               d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
             fused = None
-            if ga is None and model.fused_ffn:  # the forward ran the fused block: its backward in one launch (dF1 and gelu(f1) come out for the weight gradients)
-                fb = ops.ffn_bwd(a2, dz2, f1, st[f"w2T{l}"], st["ffn_w1tp"][l], z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
-                                 d_h1, g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
-                                 want_drop=d_h1 is not None)
-                if fb is None:
-                    raise L.SparseHipError("fused feed-forward backward declined a shape its forward took")
-                df1, ga, dz1, dz1d = fb
-                fused = (dz1, dz1d)
+            if ga is not None:
                 wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
-            else:
-                if ga is not None:
-                    wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                    df1 = model._lin(a2, f"w2T{l}", grad=True, gelu_grad_of=f1)
-                else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
-                    ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
-                    df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)
-                    wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
-                # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
-                # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
-                fused = None if model.fp8 else ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
-                                           g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
-                                           d_h1, want_drop=d_h1 is not None)
+                df1 = model._lin(a2, f"w2T{l}", grad=True, gelu_grad_of=f1)
+            else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
+                ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
+                df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)
+                wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+            wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
+            # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
+            # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
+            fused = None if model.fp8 else ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                       g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
+                                       d_h1, want_drop=d_h1 is not None)
             if fused is not None:
                 dz1, dz1d = fused
             else:

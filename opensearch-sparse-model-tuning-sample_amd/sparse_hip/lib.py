@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
 SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
+ABI_VERSION = 4  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
 
 
 class SmDropout(C.Structure):
@@ -62,9 +63,6 @@ SIGNATURES = {
     "sm_quantize_fp8": [_i, _p, _l, _p, _i, _p, _p, _p, _p],
     "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
-    "sm_ffn_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
-    "sm_ffn_fwd": [_i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "sm_ffn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_ffn_pc_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],
     "sm_ffn_pc_fwd": [_i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
@@ -129,6 +127,9 @@ def load():
     lib.sm_last_error.argtypes = []
     lib.sm_abi_version.restype = C.c_int
     lib.sm_abi_version.argtypes = []
+    if lib.sm_abi_version() != ABI_VERSION:
+        raise SparseHipError(f"{_LIB_PATH} has ABI version {lib.sm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                             "(python -c 'import __graft_entry__ as g; g.build()')")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes

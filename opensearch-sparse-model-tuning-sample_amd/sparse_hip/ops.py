@@ -95,51 +95,7 @@ def gemm_tn_acc(A: Tensor, B: Tensor, out: Tensor, colsum: Optional[Tensor] = No
     return out
 
 
-# ---------------------------------------------------------------- fused feed-forward block (hidden 384)
-def ffn_stage(w1_layer0: Tensor, w2_layer0: Tensor, layer_stride: int, layers: int, w1h: Optional[Tensor], w2p: Optional[Tensor],
-              w1tp: Optional[Tensor]):
-    """operand copies of every layer's FFN weights for the fused kernels, one launch (layers equally spaced in the flat buffer)"""
-    I, H = w1_layer0.shape
-    ref = w1h if w1h is not None else w2p
-    f16 = int(ref is not None and ref.dtype == torch.float16)
-    L.call("sm_ffn_stage", f16, L.ptr(w1_layer0), L.ptr(w2_layer0), int(layer_stride), int(layers), H, I, L.ptr(w1h), L.ptr(w2p),
-           L.ptr(w1tp), L.stream_ptr())
-
-
-def ffn_fwd(z1: Tensor, ln1_g: Tensor, ln1_b: Tensor, eps: float, w1h: Tensor, bias1: Tensor, w2p: Tensor, bias2: Tensor,
-            ln2_g: Tensor, ln2_b: Tensor, drop: Optional[L.SmDropout], save_f1: bool):
-    """(x1, m1, r1, f1, z2, x2, m2, r2) of the fused block, or None when the kernel does not take the shape"""
-    T, H = z1.shape
-    I = bias1.shape[0]
-    if z1.dtype != torch.float32 or not z1.is_contiguous() or H != 384 or I % 64 or T % 16:
-        return None
-    bf = torch.bfloat16
-    x1, x2 = _new((T, H), bf, z1), _new((T, H), bf, z1)
-    z2 = _new((T, H), torch.float32, z1)
-    m1, r1, m2, r2 = (_new((T,), torch.float32, z1) for _ in range(4))
-    f1 = _new((T, I), bf, z1) if save_f1 else None
-    ok = L.call_optional("sm_ffn_fwd", int(w1h.dtype == torch.float16), L.ptr(z1), L.ptr(ln1_g), L.ptr(ln1_b), float(eps), L.ptr(w1h),
-                         L.ptr(bias1), L.ptr(w2p), L.ptr(bias2), L.ptr(ln2_g), L.ptr(ln2_b), _drop_ref(drop), L.ptr(x1), L.ptr(m1),
-                         L.ptr(r1), L.ptr(f1), L.ptr(z2), L.ptr(x2), L.ptr(m2), L.ptr(r2), T, H, I, L.stream_ptr())
-    return (x1, m1, r1, f1, z2, x2, m2, r2) if ok else None
-
-
-def ffn_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2t: Tensor, w1tp: Tensor, z1: Tensor, ln1_g: Tensor, m1: Tensor,
-            r1: Tensor, drop: Optional[L.SmDropout], dgamma: Tensor, dbeta: Tensor, want_drop: bool):
-    """(df1, ga, dz1, dz1d) of the fused block's backward, or None when the kernel does not take the shape"""
-    T, H = dy.shape
-    I = f1.shape[1]
-    if dy.dtype != torch.bfloat16 or H != 384 or I % 64 or T % 16 or z1.dtype != torch.float32:
-        return None
-    df1, ga = torch.empty_like(f1), torch.empty_like(f1)
-    dz1 = torch.empty_like(dy)
-    dz1d = torch.empty_like(dy) if want_drop else None
-    ok = L.call_optional("sm_ffn_bwd", L.ptr(dy), L.ptr(dres), L.ptr(f1), L.ptr(w2t), L.ptr(w1tp), L.ptr(z1), L.ptr(ln1_g), L.ptr(m1),
-                         L.ptr(r1), _drop_ref(drop), L.ptr(df1), L.ptr(ga), L.ptr(dz1), L.ptr(dz1d), L.ptr(dgamma), L.ptr(dbeta),
-                         T, H, I, L.stream_ptr())
-    return (df1, ga, dz1, dz1d) if ok else None
-
-
+# ---------------------------------------------------------------- fp8 operands
 def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None, amax_next: Optional[Tensor] = None):
     """(q, scale, amax): per-tensor fp8 copy of x (bf16 / fp32) and its device-side dequantisation scale, x ~ q * scale.  e4m3fn by
     default (forward operands), e5m2 for gradients; amax: a [1] fp32 device tensor already holding max |x| (e.g. a weight's, for
@@ -155,6 +111,7 @@ def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None, a
     return q, scale, amax
 
 
+# ---------------------------------------------------------------- fused feed-forward block (hidden 384)
 def ffn_pc_stage(w1_layer0: Tensor, w2_layer0: Tensor, layer_stride: int, layers: int, w1f: Optional[Tensor], w2f: Optional[Tensor],
                  w2tf: Optional[Tensor], w1tf: Optional[Tensor]):
     """fragment-major operand copies of every layer's FFN weights for the producer / consumer kernels (csrc/ffn_pc.hip), one launch"""

@@ -1,4 +1,4 @@
-"""The fused feed-forward block (csrc/ffn_fused.hip, hf:334-351 + the LayerNorm in front of it) against a plain torch fp32
+"""The fused feed-forward block (csrc/ffn_pc.hip, hf:334-351 + the LayerNorm in front of it) against a plain torch fp32
 restatement of the same ops on the same seeded inputs, forward and backward, through the C ABI.
 
 The reference computes in fp32 from the values the kernel multiplies (weights rounded to the operand type: that is a property of
@@ -29,44 +29,10 @@ def _rnd(*shape, seed, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).cuda()
 
 
-def _kk(p):
-    g, j = p >> 3, p & 7
-    return 4 * g + j if j < 4 else 16 + 4 * g + (j - 4)
-
-
 def _weights(L=1, seed=0, inter=I):
     w1 = _rnd(L, inter, H, seed=seed + 1, scale=0.04)
     w2 = _rnd(L, H, inter, seed=seed + 2, scale=0.04)
     return w1, w2
-
-
-def _stage(ops, w1, w2, op_dtype):
-    """flat fp32 buffer with equally spaced layers -> the three staged copies"""
-    L, inter, _ = w1.shape
-    per = inter * H
-    flat = torch.empty(L * (2 * per + 64), device="cuda")  # (+64: the stride is not the tensor size)
-    stride = 2 * per + 64
-    for l in range(L):
-        flat[l * stride: l * stride + per] = w1[l].reshape(-1)
-        flat[l * stride + per: l * stride + 2 * per] = w2[l].reshape(-1)
-    w1h = torch.empty((L, inter, H), dtype=op_dtype, device="cuda")
-    w2p = torch.empty((L, inter // 32, H, 32), dtype=op_dtype, device="cuda")
-    w1tp = torch.empty((L, inter // 32, H, 32), dtype=torch.bfloat16, device="cuda")
-    ops.ffn_stage(flat[:per].view(inter, H), flat[per:2 * per].view(H, inter), stride, L, w1h, w2p, w1tp)
-    return w1h, w2p, w1tp
-
-
-@pytest.mark.parametrize("op_dtype", [torch.float16, torch.bfloat16])
-def test_stage_layouts(ops, op_dtype):
-    w1, w2 = _weights(L=3, seed=5, inter=256)
-    w1h, w2p, w1tp = _stage(ops, w1, w2, op_dtype)
-    torch.cuda.synchronize()
-    assert torch.equal(w1h, w1.to(op_dtype))
-    kk = torch.tensor([_kk(p) for p in range(32)], device="cuda")
-    for l in range(3):
-        for c in (0, 3, 7):
-            assert torch.equal(w2p[l, c], w2[l][:, 32 * c + kk].to(op_dtype)), (l, c)                 # [H, 32]: W2[n][32c + kk(p)]
-            assert torch.equal(w1tp[l, c], w1[l][32 * c + kk, :].t().contiguous().to(torch.bfloat16))  # [H, 32]: W1[32c + kk(p)][n]
 
 
 def _gelu(x):
@@ -96,106 +62,6 @@ def _close(got, want, tol, what):
     return err / scale
 
 
-@pytest.mark.parametrize("op_dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("T", [16, 112, 128, 1008, 4096 + 48])
-def test_ffn_forward_matches_torch(ops, op_dtype, tol, T):
-    w1, w2 = _weights(seed=T)
-    w1h, w2p, _ = _stage(ops, w1, w2, op_dtype)
-    z1 = _rnd(T, H, seed=11, scale=1.5) + 0.3
-    g1, b1 = 1 + _rnd(H, seed=12, scale=0.1), _rnd(H, seed=13, scale=0.1)
-    g2, b2 = 1 + _rnd(H, seed=14, scale=0.1), _rnd(H, seed=15, scale=0.1)
-    bias1, bias2 = _rnd(I, seed=16, scale=0.1), _rnd(H, seed=17, scale=0.1)
-    out = ops.ffn_fwd(z1, g1, b1, 1e-12, w1h[0], bias1, w2p[0], bias2, g2, b2, None, save_f1=True)
-    assert out is not None
-    torch.cuda.synchronize()
-    want = _reference_forward(z1, g1, b1, w1[0].to(op_dtype).float(), bias1, w2[0].to(op_dtype).float(), bias2, g2, b2)
-    names = ("x1", "m1", "r1", "f1", "z2", "x2", "m2", "r2")
-    errs = {n: _close(g_, w_, 1e-2 if n in ("x1", "f1", "x2") else tol, n) for n, g_, w_ in zip(names, out, want)}
-    print(f"[ffn fwd {op_dtype} T={T}] " + " ".join(f"{n} {e:.1e}" for n, e in errs.items()))
-    # without f1 (inference): same outputs
-    out2 = ops.ffn_fwd(z1, g1, b1, 1e-12, w1h[0], bias1, w2p[0], bias2, g2, b2, None, save_f1=False)
-    assert out2[3] is None and torch.equal(out2[4], out[4]) and torch.equal(out2[5], out[5])
-
-
-def test_ffn_forward_dropout_and_determinism(ops):
-    from sparse_hip import lib as L
-    T = 2048 + 16
-    w1, w2 = _weights(seed=3)
-    w1h, w2p, _ = _stage(ops, w1, w2, torch.float16)
-    z1 = _rnd(T, H, seed=21)
-    one, zero = torch.ones(H, device="cuda"), torch.zeros(H, device="cuda")
-    bias1, bias2 = torch.zeros(I, device="cuda"), torch.zeros(H, device="cuda")
-    drop = L.dropout(0.1, 1234, 7)
-    a = ops.ffn_fwd(z1, one, zero, 1e-12, w1h[0], bias1, w2p[0], bias2, one, zero, drop, save_f1=True)
-    b = ops.ffn_fwd(z1, one, zero, 1e-12, w1h[0], bias1, w2p[0], bias2, one, zero, drop, save_f1=True)
-    plain = ops.ffn_fwd(z1, one, zero, 1e-12, w1h[0], bias1, w2p[0], bias2, one, zero, None, save_f1=True)
-    torch.cuda.synchronize()
-    for x, y in zip(a, b):
-        assert torch.equal(x, y), "two launches on the same inputs must agree bit for bit"
-    # z2 - x1 is the (dropped) FFN output: dropped elements are exactly 0, kept ones are the plain value / (1 - p_q)
-    x1 = a[0].float()
-    lin_d, lin = a[4] - _ln(z1, one, zero)[0], plain[4] - _ln(z1, one, zero)[0]
-    big = lin.abs() > 1e-2                      # (where the plain value is tiny a kept element cannot be told from a dropped one)
-    dropped = lin_d.abs() < 1e-5
-    frac = float(dropped[big].float().mean())
-    assert 0.08 < frac < 0.125, frac            # p quantised to 26/256 = 0.1016
-    kept = ~dropped & big
-    ratio = lin_d[kept] / lin[kept]
-    assert float((ratio - 256.0 / 230.0).abs().max()) < 2e-3
-    # the mask is the GEMM epilogue's (same hash, same element index): the unfused kernel drops the same elements
-    bf = torch.bfloat16
-    ref = ops.gemm_nt(torch.zeros(T, 64, dtype=bf, device="cuda"), torch.zeros(H, 64, dtype=bf, device="cuda"),
-                      bias=torch.ones(H, device="cuda"), drop=drop)
-    assert torch.equal((ref.float() == 0)[big], dropped[big]), "fused and unfused dropout masks differ"
-    assert x1.shape == (T, H)
-
-
-@pytest.mark.parametrize("T", [16, 240, 1024, 4096 + 80])
-def test_ffn_backward_matches_torch_autograd(ops, T):
-    from sparse_hip import lib as L
-    w1, w2 = _weights(seed=T + 1)
-    _, _, w1tp = _stage(ops, w1, w2, torch.float16)
-    bf = torch.bfloat16
-    w1b, w2b = w1[0].to(bf).float(), w2[0].to(bf).float()
-    w2t = w2[0].t().contiguous().to(bf)
-    z1 = (_rnd(T, H, seed=31, scale=1.2) + 0.2).requires_grad_(True)
-    g1 = (1 + _rnd(H, seed=32, scale=0.1)).requires_grad_(True)
-    b1 = _rnd(H, seed=33, scale=0.1).requires_grad_(True)
-    bias1 = _rnd(I, seed=34, scale=0.1)
-    dy = _rnd(T, H, seed=35, scale=0.02).to(bf)
-    dres = _rnd(T, H, seed=36, scale=0.02).to(bf)
-    # reference: x1 = LN(z1); f1 = bf16(x1 W1^T + b1) as stored; out = gelu(f1) W2^T; loss = <out, dy> + <x1, dres>
-    x1, m1, r1 = _ln(z1, g1, b1)
-    f1_store = (x1 @ w1b.t() + bias1).to(bf)
-    f1 = f1_store.float().detach().requires_grad_(True)
-    out = _gelu(f1) @ w2b.t()
-    (df1_want,) = torch.autograd.grad((out * dy.float()).sum(), f1)
-    dx1 = df1_want.to(bf).float() @ w1b + dres.float()          # the kernel multiplies the bf16-rounded dF1
-    (x1 * dx1.detach()).sum().backward()
-    dgamma, dbeta = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    drop = L.dropout(0.1, 99, 3)
-    got = ops.ffn_bwd(dy, dres, f1_store, w2t, w1tp[0], z1.detach(), g1.detach(), m1.detach(), r1.detach(), drop, dgamma, dbeta, want_drop=True)
-    assert got is not None
-    df1, ga, dz1, dz1d = got
-    torch.cuda.synchronize()
-    e = {"df1": _close(df1, df1_want, 1e-2, "df1"), "ga": _close(ga, _gelu(f1_store.float()), 1e-2, "gelu(f1)"),
-         "dz1": _close(dz1, z1.grad, 1e-2, "dz1"), "dgamma": _close(dgamma, g1.grad, 1e-2, "dgamma"), "dbeta": _close(dbeta, b1.grad, 1e-2, "dbeta")}
-    print(f"[ffn bwd T={T}] " + " ".join(f"{n} {v:.1e}" for n, v in e.items()))
-    # dz1d = dropout mask of the unfused kernels applied to dz1
-    want_d = ops.dropout_bwd(dz1, drop)
-    assert torch.equal(dz1d, want_d)
-    # no residual branch, no dropout copy
-    dg2, db2 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    got2 = ops.ffn_bwd(dy, None, f1_store, w2t, w1tp[0], z1.detach(), g1.detach(), m1.detach(), r1.detach(), None, dg2, db2, want_drop=False)
-    assert got2[3] is None and torch.equal(got2[0], df1) and torch.equal(got2[1], ga)
-    # bit-identical repeats (the token sums of dgamma / dbeta are the only atomics: compare them loosely)
-    dg3, db3 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    got3 = ops.ffn_bwd(dy, dres, f1_store, w2t, w1tp[0], z1.detach(), g1.detach(), m1.detach(), r1.detach(), drop, dg3, db3, want_drop=True)
-    torch.cuda.synchronize()
-    assert all(torch.equal(x, y) for x, y in zip(got, got3))
-    assert float((dg3 - dgamma).abs().max()) <= 1e-4 * max(1.0, float(dgamma.abs().max()))
-
-
 def test_encoder_layer_fused_matches_unfused(monkeypatch):
     """the whole encoder with the fused block against the same model on the unfused kernels (bf16 operands in both, so that
     only the fusion differs): sparse activations and parameter gradients"""
@@ -210,10 +76,10 @@ def test_encoder_layer_fused_matches_unfused(monkeypatch):
     up = torch.randn(12, 3000, generator=g).cuda() * 1e-2
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SM_FUSED_FFN", mode)
+        monkeypatch.setenv("SM_PC_FFN", mode)
         monkeypatch.setenv("SM_FFN_F16", "0")
         bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=3)
-        assert bb.fused_ffn == (mode == "1")
+        assert bb.pc_ffn == (mode == "1")
         bb.train()
         rep = bb.encode(ids.cuda(), mask.cuda())
         (rep * up).sum().backward()
