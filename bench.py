@@ -353,7 +353,7 @@ def latest_traffic(kernel_names, layout):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             pmc = json.load(open(path))
-            if pmc.get("layout", "ragged") != layout:  # (summaries older than round 3 were taken on the ragged layout)
+            if pmc.get("layout", "ragged") != layout or pmc.get("csrc_sha") != csrc_sha():  # other layout / other kernels: not reported
                 continue
             for name in kernel_names:
                 if name in pmc["kernels"]:
@@ -364,7 +364,21 @@ def latest_traffic(kernel_names, layout):
     return None, None, None, None
 
 
-GEMM_KERNELS = ("gemm_nt_kernel", "gemm_nt192_kernel", "gemm_tn_pc_kernel", "gemm_tn_kernel", "ffn_pc_fwd_kernel")
+GEMM_KERNELS = ("gemm_nt_kernel", "gemm_nt192_kernel", "gemm_ws_kernel", "gemm_tn_pc_kernel", "gemm_tn_kernel", "ffn_pc_fwd_kernel",
+                "ffn_pc_bwd_kernel")
+
+
+def csrc_sha() -> str:
+    """hash of the kernel sources: a PMC summary is only reported beside a bench line of the SAME kernels (tools/pmc_summary.py
+    stores this value; round 3's line carried a traffic figure measured before a kernel was added)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def latest_gemm_traffic(layout):
@@ -374,7 +388,7 @@ def latest_gemm_traffic(layout):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             pmc = json.load(open(path))
-            if not pmc.get("steps") or pmc.get("layout") != layout:
+            if not pmc.get("steps") or pmc.get("layout") != layout or pmc.get("csrc_sha") != csrc_sha():
                 continue
             ks = {n: v for n, v in pmc["kernels"].items() if any(n.startswith(g) for g in GEMM_KERNELS)}
             if ks:
@@ -421,19 +435,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    live = {}
+
     def timed(layout, kt=None):
-        """W untimed + exactly K timed steps bracketed by barrier + synchronize; max over ranks"""
+        """W untimed + exactly K timed steps bracketed by barrier + synchronize; max over ranks.  The loss of every timed step
+        stays on the device (no sync inside the region) and is read afterwards: a run whose parameters went non-finite, or whose
+        loss stopped moving, is not a measurement (GPUTEST_r03: relu(NaN) = 0 pins the loss at ln(columns) without a NaN in it)"""
         bs_ = batches[layout]
         for i in range(args.warmup):
             trainer.training_step(bs_[i % len(bs_)])
         barrier()
         if kt is not None:
             kt.enabled = True
+        losses = []
         t0 = time.perf_counter()
         for i in range(args.steps):
-            trainer.training_step(bs_[i % len(bs_)])
+            losses.append(trainer.training_step(bs_[i % len(bs_)]))
         barrier()
         el = time.perf_counter() - t0
+        bb_ = trainer.model.sparse_model.backbone
+        ls = [float(x) for x in torch.stack([l.reshape(()) for l in losses]).float().cpu()]
+        live[layout] = {"loss_first": ls[0], "loss_last": ls[-1], "loss_min": min(ls), "loss_max": max(ls),
+                        "distinct_losses": len(set(ls)),
+                        "finite": bool(all(l == l and abs(l) != float("inf") for l in ls)) and bool(torch.isfinite(bb_.flat_param).all())
+                        and not bb_.nonfinite_report(grad=False)}
         if kt is not None:
             kt.enabled = False
         tmax = torch.tensor([el], device=device, dtype=torch.float64)
@@ -490,6 +515,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic MS-MARCO-shaped triples, random-init weights",
         "value_layout": args.layout,
+        # liveness of the timed region itself (all ranks' own values on rank 0's line are rank 0's)
+        "loss_first": live[args.layout]["loss_first"], "loss_last": live[args.layout]["loss_last"],
+        "finite": live[args.layout]["finite"] and live[args.layout]["distinct_losses"] > min(2, args.steps - 1),
+        "liveness": live,
         "value_dense_layout": sps(elapsed if args.layout == "dense" else elapsed_other),
         "value_ragged_layout": sps(elapsed if args.layout == "ragged" else elapsed_other),
         "config": {"workload": "configs[1]: config_infonce.yaml recipe, v2-mini-shaped encoder (6L/384H/12A/1536I/V30522), "
@@ -548,6 +577,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not result["finite"]:
+        print("bench.py: the timed region did not train (non-finite parameters / losses, or a loss that does not move): " + json.dumps(live),
+              file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -118,6 +118,7 @@ class SparseModelTrainer:
         self._comm_stream = None
         self._pending = []
         self._q_prefetch = None
+        self._in_compute_loss = False
         self._step_done = []  # events at the end of the last steps (training_step: bounded host lead)
         if self.accelerator.num_processes > 1:
             self._setup_grad_overlap()
@@ -146,6 +147,8 @@ class SparseModelTrainer:
         """N > 1: the all-gather of q_rep (reference trainer.py:101-104 gathers it after both encoders) is issued on the
         communication stream as soon as q_rep exists, i.e. under the document encoder; the loss waits for it where it reads
         the gathered queries.  Same collective, same place in every rank's collective order (the first of the step)."""
+        if not self._in_compute_loss:  # a forward outside compute_loss (evaluation, a user's own call) must not launch a
+            return                     # collective that nobody consumes
         q = q_rep.detach().contiguous()
         n = self.accelerator.num_processes
         q_all = torch.empty((n * q.shape[0],) + tuple(q.shape[1:]), dtype=q.dtype, device=q.device)
@@ -161,6 +164,14 @@ class SparseModelTrainer:
         return pre[:2] if pre is not None else None
 
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
+        self._q_prefetch = None
+        self._in_compute_loss = True
+        try:
+            return self._compute_loss(model, inputs, return_outputs)
+        finally:
+            self._in_compute_loss = False
+
+    def _compute_loss(self, model, inputs, return_outputs=False):
         if hasattr(self, "bi_encoder_teacher"):
             inputs["scores"] = self.bi_encoder_teacher.get_scores_batch(
                 q_features_list=inputs["query"][1:], d_features_list=inputs["docs"][1:])
@@ -333,31 +344,36 @@ class SparseModelTrainer:
         """H2D copy of the collator output.  The student's document encoding is additionally packed on
         the host into the ragged layout (padding tokens are then never computed on the device)."""
         out = self._to_device(obj)
-        try:
-            enc = obj["docs"][0]
-            bb = self.model.sparse_model.backbone
-            if not getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda and not int(getattr(self.data_args, "grad_cache_chunk", 0) or 0):
+        # only the collators' own layout is packed: {"docs": [{"input_ids", "attention_mask"}, ...]} with HOST tensors (anything
+        # else -- a caller's own dict, device tensors -- goes through unchanged and takes the dense layout); a failure INSIDE
+        # the packing is a bug and propagates
+        from collections.abc import Mapping  # (the text collators return transformers.BatchEncoding, a UserDict)
+        docs = obj.get("docs") if isinstance(obj, Mapping) else None
+        enc = docs[0] if isinstance(docs, (list, tuple)) and docs and isinstance(docs[0], Mapping) else None
+        if enc is None or not all(isinstance(enc.get(k), torch.Tensor) for k in ("input_ids", "attention_mask")) or enc["input_ids"].is_cuda:
+            return out
+        bb = self.model.sparse_model.backbone
+        n = int(getattr(self.data_args, "grad_cache_chunk", 0) or 0)
+        if not getattr(bb, "varlen", True):
+            if not n:
                 from sparse_hip.encoder import dense_embed_hints  # dense layout: only the embedding backward's sorted row lists
                 hints = dense_embed_hints(enc["input_ids"], enc["attention_mask"], self.accelerator.device,
                                           bb.padded_len(enc["input_ids"].shape[1]))
                 if hints is not None:
                     out["docs"][0]["packed"] = hints
-            if getattr(bb, "varlen", True) and not enc["input_ids"].is_cuda:
-                from sparse_hip.encoder import pack_documents
-                n = int(getattr(self.data_args, "grad_cache_chunk", 0) or 0)
-                if n > 0:  # rep-level gradient caching: every chunk gets its own ragged layout
-                    ids, mask = enc["input_ids"], enc["attention_mask"]
-                    chunks = []
-                    for a in range(0, ids.shape[0], n):
-                        pk = pack_documents(ids[a:a + n], mask[a:a + n], self.accelerator.device, bb.config.pad_token_id)
-                        chunks.append((out["docs"][0]["input_ids"][a:a + n], out["docs"][0]["attention_mask"][a:a + n], pk))
-                    out["docs"][0]["packed_chunks"] = chunks
-                else:
-                    packed = pack_documents(enc["input_ids"], enc["attention_mask"], self.accelerator.device, bb.config.pad_token_id)
-                    if packed is not None:
-                        out["docs"][0]["packed"] = packed
-        except (KeyError, IndexError, TypeError, AttributeError):
-            pass
+            return out
+        from sparse_hip.encoder import pack_documents
+        if n > 0:  # rep-level gradient caching: every chunk gets its own ragged layout
+            ids, mask = enc["input_ids"], enc["attention_mask"]
+            chunks = []
+            for a in range(0, ids.shape[0], n):
+                pk = pack_documents(ids[a:a + n], mask[a:a + n], self.accelerator.device, bb.config.pad_token_id)
+                chunks.append((out["docs"][0]["input_ids"][a:a + n], out["docs"][0]["attention_mask"][a:a + n], pk))
+            out["docs"][0]["packed_chunks"] = chunks
+        else:
+            packed = pack_documents(enc["input_ids"], enc["attention_mask"], self.accelerator.device, bb.config.pad_token_id)
+            if packed is not None:
+                out["docs"][0]["packed"] = packed
         return out
 
     def _to_device(self, obj):
@@ -460,6 +476,34 @@ class SparseModelTrainer:
                       a.adam_beta2, a.adam_epsilon, a.weight_decay, step + 1, 1.0 / n)
         bb.mark_weights_dirty()
 
+    def resume_from_checkpoint(self, checkpoint_dir: str) -> None:
+        """Everything a checkpoint-N directory of this trainer holds: HF-layout weights, the trained IDF vector (idf.json, written
+        by ModelWrapper.save when idf_requires_grad), the optimiser state and the step counter.  train() then continues the
+        DATA stream where the interrupted run stopped (epoch and position inside it follow from global_step)."""
+        if not os.path.exists(os.path.join(checkpoint_dir, "trainer_state.pt")):
+            raise FileNotFoundError(f"resume_from_checkpoint={checkpoint_dir!r}: no trainer_state.pt there (not a checkpoint of this trainer)")
+        sm = self.model.sparse_model
+        if os.path.exists(os.path.join(checkpoint_dir, "model.safetensors")):
+            from safetensors.torch import load_file
+            sd = load_file(os.path.join(checkpoint_dir, "model.safetensors"))
+        else:
+            sd = torch.load(os.path.join(checkpoint_dir, "pytorch_model.bin"), map_location="cpu")
+        sm.backbone.load_hf_state_dict(sd)
+        if sm.idf_requires_grad:  # the moments restored below belong to the TRAINED vector, not to model_args.idf_path's
+            path = os.path.join(checkpoint_dir, "idf.json")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path}: an idf_requires_grad run cannot resume without its trained IDF vector")
+            with open(path) as f:
+                idf_json = json.load(f)
+            tok = sm.tokenizer
+            vec = torch.zeros(sm.idf_vector.shape[0])  # save() writes the non-zero entries only
+            for key, value in idf_json.items():
+                idx = tok._convert_token_to_id_with_added_voc(key) if tok is not None else int(key)
+                vec[idx] = float(value)
+            with torch.no_grad():
+                sm.idf_vector.data.copy_(vec.to(sm.idf_vector.device))
+        self.load_trainer_state(checkpoint_dir)
+
     def load_trainer_state(self, checkpoint_dir: str) -> None:
         """resume: AdamW moments + global_step written by _save next to the HF-format weights"""
         st = torch.load(os.path.join(checkpoint_dir, "trainer_state.pt"), map_location="cpu")
@@ -534,8 +578,14 @@ class SparseModelTrainer:
         dl = self.get_train_dataloader()
         self.zero_grad()
         loss = None
-        feed = _InputPrefetcher(self, dl) if os.environ.get("SM_PREFETCH", "1") != "0" and torch.cuda.is_available() else None
-        it, epoch = (None if feed else iter(dl)), 0
+        # a resumed run (global_step > 0) continues the data stream: epoch = steps done // batches per epoch (the samplers are
+        # seeded by the epoch), and the batches of that epoch already consumed are skipped -- as hf trainer.py does on resume
+        epoch, skip = divmod(self.state.global_step, max(1, len(dl))) if self.state.global_step > 0 else (0, 0)
+        feed = (_InputPrefetcher(self, dl, epoch=epoch, skip=skip)
+                if os.environ.get("SM_PREFETCH", "1") != "0" and torch.cuda.is_available() else None)
+        it = None
+        if feed is None:
+            it = _epoch_iter(dl, epoch, skip)
         while self.state.global_step < a.max_steps:
             if feed is not None:
                 inputs = feed.get()
@@ -544,9 +594,7 @@ class SparseModelTrainer:
                     batch = next(it)
                 except StopIteration:
                     epoch += 1
-                    if hasattr(dl.sampler, "set_epoch"):
-                        dl.sampler.set_epoch(epoch)
-                    it = iter(dl)
+                    it = _epoch_iter(dl, epoch, 0)
                     batch = next(it)
                 inputs = self._prepare_inputs(batch)
             loss = self.training_step(inputs)
@@ -559,6 +607,24 @@ class SparseModelTrainer:
         if feed is not None:
             feed.close()
         return loss
+
+
+def _epoch_iter(dl, epoch: int, skip: int):
+    """iterator over epoch `epoch` of the loader with its first `skip` batches dropped.  Samplers that are seeded per epoch
+    (DistributedSampler, CombinedRandomSampler) get set_epoch; a RandomSampler draws from its own generator, which a resumed run
+    advances by replaying the permutations of the epochs already done."""
+    import itertools
+    sampler = getattr(dl, "batch_sampler", None)
+    sampler = sampler if hasattr(sampler, "set_epoch") else getattr(dl, "sampler", None)
+    if hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
+    elif epoch > 0 and getattr(dl, "_sm_epochs_drawn", 0) < epoch and getattr(sampler, "generator", None) is not None:
+        for _ in range(epoch - getattr(dl, "_sm_epochs_drawn", 0)):  # (only on resume: a running loop draws one permutation per epoch itself)
+            for _ in sampler:
+                pass
+    dl._sm_epochs_drawn = epoch + 1
+    it = iter(dl)
+    return itertools.islice(it, skip, None) if skip else it
 
 
 _TRACE_RANGES = os.environ.get("SM_TRACE_RANGES", "0") == "1"
@@ -623,10 +689,11 @@ class _InputPrefetcher:
     ahead.  The consumer waits for the copy's event on the compute stream (no host sync) and tells the caching
     allocator that the tensors are now used there."""
 
-    def __init__(self, trainer, dataloader, depth: int = 2):
+    def __init__(self, trainer, dataloader, depth: int = 2, epoch: int = 0, skip: int = 0):
         import queue
         import threading
         self.trainer, self.dl = trainer, dataloader
+        self.epoch0, self.skip0 = epoch, skip
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
         self.device = trainer.accelerator.device
@@ -637,15 +704,14 @@ class _InputPrefetcher:
         try:
             torch.cuda.set_device(self.device)
             stream = torch.cuda.Stream(device=self.device)
-            it, epoch = iter(self.dl), 0
+            epoch = self.epoch0
+            it = _epoch_iter(self.dl, epoch, self.skip0)
             while not self.stop.is_set():
                 try:
                     batch = next(it)
                 except StopIteration:
                     epoch += 1
-                    if hasattr(self.dl.sampler, "set_epoch"):
-                        self.dl.sampler.set_epoch(epoch)
-                    it = iter(self.dl)
+                    it = _epoch_iter(self.dl, epoch, 0)
                     batch = next(it)
                 with torch.cuda.stream(stream):
                     inputs = self.trainer._prepare_inputs(batch)

@@ -79,18 +79,8 @@ def main():
         logger.info("Set bi-encoder teacher. %s", data_args.kd_ensemble_teacher_kwargs)
         trainer.set_bi_encoder_teacher()
     if training_args.resume_from_checkpoint:
-        ckpt = training_args.resume_from_checkpoint
-        if not os.path.exists(os.path.join(ckpt, "trainer_state.pt")):
-            raise FileNotFoundError(f"resume_from_checkpoint={ckpt!r}: no trainer_state.pt there (not a checkpoint of this trainer)")
-        bb = model.backbone
-        if os.path.exists(os.path.join(ckpt, "model.safetensors")):
-            from safetensors.torch import load_file
-            sd = load_file(os.path.join(ckpt, "model.safetensors"))
-        else:
-            sd = torch.load(os.path.join(ckpt, "pytorch_model.bin"), map_location="cpu")
-        bb.load_hf_state_dict(sd)
-        trainer.load_trainer_state(ckpt)
-        logger.info("Resumed from %s at step %d", ckpt, trainer.state.global_step)
+        trainer.resume_from_checkpoint(training_args.resume_from_checkpoint)
+        logger.info("Resumed from %s at step %d", training_args.resume_from_checkpoint, trainer.state.global_step)
     trainer.train()
     if dist.is_initialized():
         dist.barrier()

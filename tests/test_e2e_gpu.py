@@ -446,6 +446,62 @@ def test_train_loop_prefetcher_checkpoint_and_resume(tmp_path):
         lc = c.training_step(c._prepare_inputs(batches[i % 5]))
     assert abs(float(lc) - float(last)) <= 1e-4 * (1 + abs(float(last))), (float(lc), float(last))
     close_out(outputs(c), ra, 1e-3, "resumed run")
+    # (3) the product's own resume: resume_from_checkpoint + train() -- the data stream continues at step 4 (batch 4 of epoch 0,
+    # then epoch 1 of the SAME seeded sampler), it does not restart at batch 0 (with and without the prefetch thread)
+    for prefetch in ("1", "0"):
+        os.environ["SM_PREFETCH"] = prefetch
+        try:
+            d = make(tmp_path / ("d" + prefetch), steps)
+            d.resume_from_checkpoint(str(ck))
+            assert d.state.global_step == 4
+            ld = d.train()
+        finally:
+            os.environ.pop("SM_PREFETCH", None)
+        assert d.state.global_step == steps
+        assert abs(float(ld) - float(last)) <= 1e-4 * (1 + abs(float(last))), (prefetch, float(ld), float(last))
+        close_out(outputs(d), ra, 1e-3, "resume_from_checkpoint + train()")
+
+
+def test_resume_restores_the_trained_idf_vector(tmp_path):
+    """idf_requires_grad: the checkpoint's idf.json (token id -> value; ModelWrapper.save) comes back into model.idf_vector on
+    resume, next to the moments that belong to it -- a resumed run ends where the uninterrupted one does, and a checkpoint
+    without idf.json is refused"""
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    ds = SyntheticTriplesDataset(16, 3, 32, 16, 520, seed=23, len_mean=20, len_std=8)
+
+    def make(out, max_steps, save_steps=0):
+        margs = ModelArguments(model_name_or_path="unused", inf_free=True, idf_requires_grad=True)
+        dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.0, flops_d_T=1, idf_lr=5e-2)
+        targs = TrainingArguments(output_dir=str(out), per_device_train_batch_size=4, logging_steps=1000, learning_rate=1e-3,
+                                  max_steps=max_steps, save_strategy="steps" if save_steps else "no", save_steps=save_steps,
+                                  dataloader_drop_last=True, seed=5)
+        base = tiny_sparse_model(torch.float32)
+        g = torch.Generator().manual_seed(9)
+        model = SparseModel(base.backbone, idf=torch.rand(520, generator=g) * 3 + 0.5, idf_requires_grad=True, use_l0=False)
+        return SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs, train_dataset=ds, data_collator=PreTokenizedCollator(),
+                                  loss_functions=[LOSS_CLS_MAP["infonce"](use_in_batch_negatives=True, weight=1, temperature=1.0)])
+
+    a = make(tmp_path / "a", 6, save_steps=3)
+    idf0 = a.model.sparse_model.idf_vector.detach().clone()
+    a.train()
+    idf_a = a.model.sparse_model.idf_vector.detach().clone()
+    assert float((idf_a - idf0).abs().max()) > 1e-2, "the IDF vector was not trained"
+    ck = tmp_path / "a" / "checkpoint-3"
+    assert (ck / "idf.json").exists()
+    b = make(tmp_path / "b", 6)
+    b.resume_from_checkpoint(str(ck))
+    mid = b.model.sparse_model.idf_vector.detach().clone()
+    assert float((mid - idf0).abs().max()) > 1e-3, "resume kept the initial IDF vector"
+    b.train()
+    idf_b = b.model.sparse_model.idf_vector.detach()
+    assert float((idf_b - idf_a).abs().max()) <= 1e-4 * (1 + float(idf_a.abs().max())), float((idf_b - idf_a).abs().max())
+    (ck / "idf.json").unlink()
+    with pytest.raises(FileNotFoundError):
+        make(tmp_path / "c", 6).resume_from_checkpoint(str(ck))
 
 
 def test_training_mode_dropout_is_seeded_and_finite():

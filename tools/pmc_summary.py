@@ -4,7 +4,8 @@
 (FETCH_SIZE needs 3 of the 4 TCC slots and WRITE_SIZE 2: one counter per pass.)  Both counters are in units
 of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled
 (/opt/skills/guides/MI355X_MICROARCH.md, 'HBM').  usage: pmc_summary.py fetch.csv write.csv out.json [git revision the passes were measured at] [steps run] [layout]"""
-import csv, collections, json, re, sys
+import csv, collections, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def load(path):
     d = collections.defaultdict(lambda: [0, 0.0])
@@ -30,6 +31,6 @@ steps = int(sys.argv[5]) if len(sys.argv) > 5 else None    # training steps the 
 layout = sys.argv[6] if len(sys.argv) > 6 else None
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --only-value-layout "
                      "--no-cpu-baseline --no-gemm-roofline; FETCH_SIZE x2 (gfx950)",
-           "git": git, "steps": steps, "layout": layout, "kernels": out}, open(sys.argv[3], "w"), indent=1)
+           "git": git, "csrc_sha": __import__("bench").csrc_sha(), "steps": steps, "layout": layout, "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for n, v in list(out.items())[:12]:
     print(f"{n:36s} x{v['launches']:4d}  read {v['read_bytes_per_launch']/1e6:9.1f} MB  write {v['write_bytes_per_launch']/1e6:9.1f} MB per launch")
