@@ -62,7 +62,24 @@ def _gelu(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def _drop(x: Tensor, p: float, gen: Optional[torch.Generator]) -> Tensor:
+class DropMasks:
+    """Dropout with GIVEN masks instead of a generator (tests: the device's counter-based masks, exported through
+    sm_dropout_bwd(ones), fed to the oracle so that a dropout-on step can be compared elementwise).  `masks`: one entry per
+    _drop call of bert_mlm_logits in call order -- embeddings, then per layer (attention probabilities, attention output,
+    feed-forward output); an entry is a tensor broadcastable to the site's activation holding keep * scale, or None (site off)."""
+
+    def __init__(self, masks):
+        self.masks, self.i = list(masks), 0
+
+    def apply(self, x: Tensor) -> Tensor:
+        m = self.masks[self.i]
+        self.i += 1
+        return x if m is None else x * m.to(x.dtype)
+
+
+def _drop(x: Tensor, p: float, gen) -> Tensor:
+    if isinstance(gen, DropMasks):
+        return gen.apply(x)
     if p <= 0.0:
         return x
     keep = (torch.rand(x.shape, generator=gen) >= p).to(x.dtype)

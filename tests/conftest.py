@@ -21,9 +21,10 @@ def golden_dir():
     return GOLDEN
 
 
-# kernel / end-to-end parity first, multi-process cases last: a stalled rendezvous must not hide the parity results
-_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_kernels_gpu", "test_ffn_fused_gpu", "test_e2e_gpu", "test_baseline_configs_gpu",
-          "test_fullsize_gpu", "test_bench_cli", "test_distributed")
+# kernel / end-to-end parity first; the multi-process cases (every leg bounded to 120 s in its own process group) run BEFORE the
+# slow full-size files: in round 3 one failure in test_fullsize_gpu hid all twelve distributed legs behind `-x`
+_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_asm_hazards_cpu", "test_kernels_gpu", "test_ffn_fused_gpu", "test_e2e_gpu",
+          "test_distributed", "test_bench_cli", "test_baseline_configs_gpu", "test_fullsize_gpu")
 
 
 def pytest_collection_modifyitems(session, config, items):

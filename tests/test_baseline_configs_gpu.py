@@ -111,8 +111,12 @@ def _check_grads(dtype, bb, pr, what, pr_unrouted=None, grad_rel=None):
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
                   residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True, fp8=False, fraction_inside=FRACTION_INSIDE,
-                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None):
-    """one compute_loss + backward through the HIP path and through the oracle on the same inputs"""
+                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None, hidden_dropout=0.0, varlen=None):
+    """one compute_loss + backward through the HIP path and through the oracle on the same inputs.
+    hidden_dropout > 0: the three hidden-dropout sites (embeddings, attention output, feed-forward output) run with that
+    probability on the device and the oracle gets the SAME masks (exported through sm_dropout_bwd(ones), DropMasks); the
+    attention-probability dropout stays off (its keep bits are per (document, head) and have no export entry point; its forward /
+    backward consistency is test_e2e_gpu's directional-derivative test).  varlen: False = the dense [B, S] layout."""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
     from scripts.model.sparse_encoders import SparseModel
@@ -121,7 +125,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     from sparse_hip.encoder import BertConfigLite, HipBertMLM
     L, H, A, I = shape
     cfg = BertConfigLite(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A, intermediate_size=I,
-                         max_position_embeddings=512, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+                         max_position_embeddings=512, hidden_dropout_prob=hidden_dropout, attention_probs_dropout_prob=0.0)
     oc = O.BertShape(V, H, L, A, I, 512)
     p = O.init_params(oc, seed=seed, std=std)
     g = torch.Generator().manual_seed(seed + 100)
@@ -133,6 +137,8 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32, fp8=fp8)
     assert bb.fp8 == bool(fp8)
     bb.load_hf_state_dict(p)
+    if varlen is not None:
+        bb.varlen = bool(varlen)
     idf = torch.exp(torch.rand(V, generator=g) * 6.6 - 3.9)  # log-uniform in [0.02, 15.6] like idf.json
     use_l0 = bool(recipe.get("use_l0", False))
     model = SparseModel(bb, idf=idf, use_l0=use_l0)
@@ -155,9 +161,16 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     inp = trainer._prepare_inputs(batch)
     trainer.zero_grad()
     bb._argmax_log = []
+    drop_seed0 = 0xC0FFEE + seed
+    bb.set_dropout_seed(drop_seed0)
     loss, out = trainer.compute_loss(trainer.model, inp, return_outputs=True)
     loss.backward()
     torch.cuda.synchronize()
+    masks = (lambda: None)
+    if hidden_dropout > 0:
+        assert not grad_cache_chunk
+        site_masks = _export_hidden_masks(bb, inp, hidden_dropout, drop_seed0, nq * k, S, L)
+        masks = lambda: O.DropMasks(site_masks)
     if grad_cache_chunk:  # the first pass logs one entry per chunk (the second pass repeats them bit for bit)
         nchunks = -(-nq * k // grad_cache_chunk)
         assert len(bb._argmax_log) == 2 * nchunks, len(bb._argmax_log)
@@ -170,7 +183,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
                       flops_d_T=recipe["flops_d_T"], flops_threshold=recipe.get("flops_threshold"))
     q, d = batch["query"][0], batch["docs"][0]
     t0 = time.time()
-    logits = O.bert_mlm_logits(pr, d["input_ids"], d["attention_mask"], oc)
+    logits = O.bert_mlm_logits(pr, d["input_ids"], d["attention_mask"], oc, hidden_dropout, masks())
     oq = O.encode_inf_free(q["input_ids"], idf, SPECIAL)
     with torch.no_grad():  # what the outputs are compared with: the oracle's own maxima
         od_free = O.sparse_activation(logits, d["attention_mask"], use_l0)
@@ -184,7 +197,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
         if dtype != torch.float32 and unrouted_grads:  # ... and, reported beside it, with the oracle's own routing
             del logits, od
             pr_unrouted = _round_like_staged(p, dtype)
-            lg = O.bert_mlm_logits(pr_unrouted, d["input_ids"], d["attention_mask"], oc)
+            lg = O.bert_mlm_logits(pr_unrouted, d["input_ids"], d["attention_mask"], oc, hidden_dropout, masks())
             O.total_loss(oq, O.sparse_activation(lg, d["attention_mask"], use_l0), batch.get("scores"), lc, step, 1)[0].backward()
             logits = lg
             del lg
@@ -192,7 +205,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     od_identical = oloss_identical = None
     if dtype != torch.float32:  # IDENTICAL INPUTS: the same fp32 checkpoint, multiplied unrounded (the reference's CPU path)
         with torch.no_grad():
-            lg = O.bert_mlm_logits(p, d["input_ids"], d["attention_mask"], oc)
+            lg = O.bert_mlm_logits(p, d["input_ids"], d["attention_mask"], oc, hidden_dropout, masks())
             od_identical = O.sparse_activation(lg, d["attention_mask"], use_l0)
             del lg
             oloss_identical = O.total_loss(oq, od_identical, batch.get("scores"), lc, step, 1)[0]
@@ -205,6 +218,40 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     if ret is not None:
         ret.update(d_rep=out["d_rep"].detach().float().cpu(), docs=d, params=p, oracle_rep=od_identical, shape=oc)
     return trainer, bb
+
+
+def _export_hidden_masks(bb, inp, p_drop, drop_seed0, n_docs, S, layers):
+    """keep * scale of the device's hidden-dropout sites, as [B, S, H] tensors in the oracle's call order (embeddings; per layer:
+    None for the attention probabilities, attention output, feed-forward output).  The device indexes an element by
+    (row of ITS layout) * H + column: dense rows are b * S + s, ragged rows doc_off[b] + s (rows a ragged document does not have
+    are padding positions, which never influence a valid one: mask 1 there)."""
+    from sparse_hip import lib as L
+    from sparse_hip import ops
+    from sparse_hip.encoder import _Site
+    H = bb.config.hidden_size
+    packed = inp["docs"][0].get("packed")
+    rag = getattr(packed, "rag", None)
+    Sp = bb.padded_len(S)
+    rows = rag.rows if rag is not None else n_docs * Sp
+    seed = (drop_seed0 * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF  # HipBertMLM.encode: the first invocation after set_dropout_seed
+    ones = torch.ones(rows, H, dtype=torch.float32, device="cuda")
+
+    def site(layer, kind):
+        m = ops.dropout_bwd(ones, L.dropout(p_drop, seed, layer * 4 + kind)).cpu()
+        assert 0.05 < float((m == 0).float().mean()) < 0.16, "the exported mask does not look like dropout 0.1"
+        if rag is None:
+            return m.view(n_docs, Sp, H)[:, :S].contiguous()
+        off = rag.doc_off.cpu().tolist()
+        out = torch.ones(n_docs, S, H)
+        for b in range(n_docs):
+            n = min(off[b + 1] - off[b], S)
+            out[b, :n] = m[off[b]:off[b] + n]
+        return out
+
+    masks = [site(0, _Site.EMB)]
+    for l in range(layers):
+        masks += [None, site(l + 1, _Site.HID1), site(l + 1, _Site.HID2)]
+    return masks
 
 
 def _detach(pr):
@@ -238,6 +285,27 @@ def test_c2_slice_with_all_bf16_activation_storage():
 def test_c3_config_l0_recipe_on_the_c2_slice():
     """BASELINE.json configs[2] (single rank): use_l0 + flops_threshold=150 + lambda 0.08 on the c2 slice"""
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=L0, seed=3, what="c3 slice")
+
+
+@pytest.mark.parametrize("varlen", [True, False])
+def test_c2_slice_with_hidden_dropout_on_the_same_masks_in_the_oracle(varlen):
+    """the bench step's DROPOUT paths against the oracle (GPUTEST_r03: no oracle test ran with p > 0): hidden dropout 0.1 at the
+    three hidden sites of every layer -- the GEMM / fused feed-forward epilogues that apply it, the fused GEMM + LayerNorm-backward
+    kernels that apply its backward (dx_drop, dy_drop) -- with the device's own masks fed to the oracle.  Ragged layout: a row
+    count that is a multiple of 16 only; dense: 16 384 rows (not a multiple of 192)."""
+    _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=6, what=f"c2 slice, hidden dropout 0.1, varlen={varlen}",
+                  hidden_dropout=0.1, varlen=varlen, unrouted_grads=False)
+
+
+@pytest.mark.parametrize("varlen", [True, False])
+def test_c2_full_batch_32x16x128_both_layouts(varlen):
+    """BASELINE.json configs[1] IN FULL -- 32 queries x 16 documents x seq 128, the bench's batch -- against the oracle, in the
+    layout the headline `value` is measured on (dense: 65 536 rows, two-round 192-row tiles, the weight-stationary GEMM at
+    M >= 8192, the dense fused head) and in the ragged one: every sparse activation within 1e-2 (1 + |ref|) of the fp32 oracle on
+    the UNROUNDED weights, the loss, and the routed gradients of the six GRAD_NAMES (sparse_encoders.py:107-119, loss.py:86-107).
+    About a minute of host time per layout."""
+    _student_step(MINI, torch.bfloat16, nq=32, k=16, S=128, Sq=32, recipe=INFONCE, seed=8, what=f"c2 FULL batch, varlen={varlen}",
+                  varlen=varlen, unrouted_grads=False)
 
 
 def test_c5_kd_precomputed_scores_bert_base_seq512_gradient_caching():

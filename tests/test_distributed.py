@@ -49,6 +49,101 @@ def test_gradient_slices_tile_the_flat_buffer():
     assert tr._slices[1][0] == o
 
 
+def test_overlapped_slice_all_reduce_is_ordered_after_its_producers(monkeypatch):
+    """the N > 1 branch of the step driver with a FAKE process group and fake HIP streams / events (no GPU, no rendezvous): every
+    slice of the flat gradient is all-reduced exactly once, on the communication stream, behind an event recorded on the main
+    stream after the slice's backward kernels were enqueued AND behind the weight-gradient stream's marker; the optimiser runs
+    only after every collective was waited for.  (RCCL itself has never run in this project -- no box with two GPUs: this pins
+    the ordering logic the RCCL run will rely on.)"""
+    import torch.distributed as dist
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train import trainer as T
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    log, cur = [], []
+
+    class FakeStream:
+        def __init__(self, device=None, name="comm"):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(("wait_event", self.name, ev.id))
+
+    main = FakeStream(name="main")
+    cur.append(main)
+
+    class FakeEvent:
+        n = 0
+
+        def __init__(self, *a, **k):
+            FakeEvent.n += 1
+            self.id = FakeEvent.n
+
+        def record(self, stream=None):
+            log.append(("record", (stream or cur[-1]).name, self.id))
+
+    class stream_ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            cur.append(self.s)
+
+        def __exit__(self, *exc):
+            cur.pop()
+
+    class FakeWork:
+        def __init__(self, i):
+            self.i = i
+
+        def wait(self):
+            log.append(("wait", self.i))
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        assert async_op and op == dist.ReduceOp.SUM
+        log.append(("all_reduce", cur[-1].name, t.data_ptr(), t.numel()))
+        return FakeWork(len(log) - 1)
+
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "stream", stream_ctx)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda *a: 0)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, max_position_embeddings=32)
+    bb = HipBertMLM(cfg, device="cpu", init_seed=None)
+    tr = T.SparseModelTrainer(model_args=ModelArguments(model_name_or_path="x", inf_free=True), data_args=DataTrainingArguments(),
+                              model=SparseModel(bb, use_l0=False), args=TrainingArguments(), loss_functions=[])
+    assert tr.accelerator.num_processes == 2 and bb._layer_hook is not None
+    # what _EncodeFn.backward does: the head's slice, then the layers from the last to the first, each with the weight-gradient marker
+    wg = {}
+    for key in ("head", 1, 0):
+        wg[key] = FakeEvent()
+        bb._layer_hook(key, wg[key])
+    log.append(("optimizer-would-run-here-if-unsynchronised",))
+    tr._finish_grad_reduce()
+    log.append(("optimizer",))
+    reduces = [(i, e) for i, e in enumerate(log) if e[0] == "all_reduce"]
+    assert [e[1] for _, e in reduces] == ["comm"] * 4, "every slice collective is issued on the communication stream"
+    base = bb.flat_grad.data_ptr()
+    spans = sorted(((e[2] - base) // 4, (e[2] - base) // 4 + e[3]) for _, e in reduces)
+    assert spans[0][0] == 0 and spans[-1][1] == bb.n_flat and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), spans
+    for (i, e), key in zip(reduces, ("head", 1, 0, "emb")):
+        a, b = tr._slices[key]
+        assert ((e[2] - base) // 4, e[3]) == (a, b - a), key
+        before = log[:i]
+        rec = max(j for j, x in enumerate(before) if x[0] == "record" and x[1] == "main")  # the event recorded for THIS slice
+        assert ("wait_event", "comm", log[rec][2]) in before[rec:], f"slice {key}: the communication stream does not wait for the main stream"
+        if key != "emb":
+            assert ("wait_event", "comm", wg[key].id) in before[rec:], f"slice {key}: no wait for the weight-gradient stream's marker"
+    opt = log.index(("optimizer",))
+    waited = {e[1] for e in log[:opt] if e[0] == "wait"}
+    assert waited == {i for i, _ in reduces}, "the optimiser must run behind every collective's wait()"
+    assert tr._pending == []
+
+
 WORKER = r"""
 import faulthandler, os, sys
 faulthandler.dump_traceback_later(90, exit=True)  # a stalled rank prints every thread's stack and dies
