@@ -209,7 +209,8 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
             od_identical = O.sparse_activation(lg, d["attention_mask"], use_l0)
             del lg
             oloss_identical = O.total_loss(oq, od_identical, batch.get("scores"), lc, step, 1)[0]
-    rows = inp["docs"][0]["packed"].rag.rows if inp["docs"][0].get("packed") is not None else nq * k * S
+    rag_ = getattr(inp["docs"][0].get("packed"), "rag", None)  # (a DenseHints object travels in the same slot: dense layout)
+    rows = rag_.rows if rag_ is not None else nq * k * S
     print(f"[{what}] oracle {time.time() - t0:.1f} s, {rows} token rows on the device")
     _check_outputs(dtype, loss, oloss, out, oq, od_free, what, elementwise=elementwise, od_identical=od_identical,
                    oloss_identical=oloss_identical, fraction_inside=fraction_inside, frob=frob, loss_tol=loss_tol)
