@@ -447,16 +447,18 @@ def main():
         barrier()
         if kt is not None:
             kt.enabled = True
-        losses = []
+        losses, totals = [], []
         t0 = time.perf_counter()
         for i in range(args.steps):
-            losses.append(trainer.training_step(bs_[i % len(bs_)]))
-        barrier()
+            totals.append(trainer.training_step(bs_[i % len(bs_)]))
+            losses.append(trainer._last.get("ranking", totals[-1]))  # device scalar of the step just enqueued (the FLOPS term's weight is still warming up:
+        barrier()                                    # the TOTAL loss grows with it; the ranking loss is what shows the model is alive)
         el = time.perf_counter() - t0
         bb_ = trainer.model.sparse_model.backbone
         ls = [float(x) for x in torch.stack([l.reshape(()) for l in losses]).float().cpu()]
-        live[layout] = {"loss_first": ls[0], "loss_last": ls[-1], "loss_min": min(ls), "loss_max": max(ls),
-                        "distinct_losses": len(set(ls)),
+        tt = [float(x) for x in torch.stack([l.reshape(()) for l in totals]).float().cpu()]
+        live[layout] = {"loss_first": ls[0], "loss_last": ls[-1], "loss_min": min(ls), "loss_max": max(ls), "total_loss_first": tt[0],
+                        "total_loss_last": tt[-1], "distinct_losses": len(set(ls)),
                         "finite": bool(all(l == l and abs(l) != float("inf") for l in ls)) and bool(torch.isfinite(bb_.flat_param).all())
                         and not bb_.nonfinite_report(grad=False)}
         if kt is not None:
@@ -515,7 +517,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic MS-MARCO-shaped triples, random-init weights",
         "value_layout": args.layout,
-        # liveness of the timed region itself (all ranks' own values on rank 0's line are rank 0's)
+        # liveness of the timed region itself: the RANKING loss of the first / last timed step on rank 0
         "loss_first": live[args.layout]["loss_first"], "loss_last": live[args.layout]["loss_last"],
         "finite": live[args.layout]["finite"] and live[args.layout]["distinct_losses"] > min(2, args.steps - 1),
         "liveness": live,
