@@ -132,6 +132,11 @@ int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* B, int ldb,
  * optionally colsum[N] += sum_m A[m,:] (the bias gradient).  Backward of every nn.Linear. */
 int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                    int M, int N, int Kc, float* colsum, void* stream);
+/* the same product (bf16, N % 128 == 0, Kc % 128 == 0) with A and / or B in the block-column-major layout of sm_ffn_pc_bwd's
+ * dF1 / gelu(f1) outputs: [rows / 32][cols / 8][32][8], whole 32-row blocks allocated; a row-major operand is dense (lda = N,
+ * ldb = Kc) */
+int sm_gemm_tn_acc_bcm(const void* A, int a_bcm, const void* B, int b_bcm, float* C, int ldc, int M, int N, int Kc, float* colsum,
+                       void* stream);
 
 /* ---- fused feed-forward block, hidden size 384, fp32 residual stream (hf:334-351: intermediate.dense -> GELU ->
  * output.dense -> dropout -> + residual -> LayerNorm, together with the attention-output LayerNorm hf:293 in front of it) in
@@ -157,6 +162,18 @@ int sm_ffn_pc_stage(int op_f16, const float* w1, const float* w2, long layer_str
 int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, const float* ln1_b, float eps, const void* w1f, const float* bias1,
                   const void* w2f, const float* bias2, const float* ln2_g, const float* ln2_b, const sm_dropout* drop, void* x1,
                   float* m1, float* r1, void* f1, float* z2, void* x2, float* m2, float* r2, int T, int H, int I, void* stream);
+/* backward of the block (bf16 operands), one launch for what the unfused path runs as the dF1 GEMM + the GEMM fused with the
+ * LayerNorm-1 backward: dF1 = (dy W2) * gelu'(f1) and ga = gelu(f1), both [T, I] ROW-major, written once for the two
+ * weight-gradient GEMMs (dF1 is not read back: the second GEMM consumes it on the chip);  dx1 = dF1 W1 + dres;
+ * dz1 = LN'(dx1 | z1, ln1_g, m1, r1), dz1d = dropout_bwd(dz1; drop) (NULL: not wanted); dgamma / dbeta accumulated (atomics).
+ * The dF1 / ga buffers must hold WHOLE 128-row blocks (ceil(T / 128) * 128 rows): the kernel stores the rows past T as well.
+ * partials: NULL, or ceil(T / 128) * 768 floats of scratch -- the workgroups' gamma / beta column sums, reduced by a second small
+ * launch instead of float atomics on the 768 shared addresses.
+ * dy = the gradient w.r.t. the block's output behind its dropout backward, dres (may be NULL) the residual branch's;
+ * f1 = the tile-major tensor of sm_ffn_pc_fwd; w2tf / w1tf = one layer's slices of sm_ffn_pc_stage. */
+int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, const void* w2tf, const void* w1tf, const float* z1,
+                  const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
+                  void* dz1d, float* dgamma, float* dbeta, float* partials, int T, int H, int I, void* stream);
 
 /* ---- LayerNorm (hf:106, :293, :351, :479) ---------------------------------------- */
 int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,

@@ -600,6 +600,432 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   PC_STAMP(0, 7);
 }
 
+// =====================================================================================================================
+// BACKWARD of the same block in the same producer / consumer form (hf:334-351 backward + the LayerNorm-1 backward hf:293):
+//
+//   dG  = dy W2            dF1 = dG * gelu'(f1)        ga = gelu(f1)        dx1 = dF1 W1 + dres        dz1 = LN1'(dx1 | z1)
+//
+// dy = gradient w.r.t. the feed-forward output AFTER its dropout backward (what the LayerNorm-2 backward hands over as dx_drop),
+// dres = the gradient of the residual branch (its dx).  One launch replaces the dF1 GEMM (gemm_ws<EPI 1>) and the fused
+// GEMM + LayerNorm-backward launch (gemm_nt192_kernel<true>) of a layer: dF1 is written once for the W1 weight gradient but
+// never read back (the second GEMM consumes it from LDS), ga once for the W2 weight gradient.
+//   producer (waves 0-3): dy^T of its 32 tokens resident as B fragments; per chunk of 32 intermediate columns
+//                         dG^T = W2^T_c . dy^T (24 MFMAs 32x32x16, A = the fragment-major rows of W2^T: w2tf), then value and
+//                         derivative of the forward's sigmoid-form GELU from the forward's tile-major f1 (the lane's 16 accumulator
+//                         registers <-> 32 contiguous bytes), dF1 / ga to memory (row-major: the weight-gradient GEMMs read
+//                         them through LDS-DMA panels) and the two B fragments of dF1^T to the consumer through LDS;
+//   consumer (waves 4-7): dx1^T [384 x 32 tokens] += W1^T_c . dF1^T (A = w1tf, k permuted like the forward's W2), all LDS-DMA;
+//   epilogue:             the consumers write the bf16 image of dx1 [128 rows][384] into the idle rings; all eight waves run the
+//                         LayerNorm backward on it, a row per 16 lanes (+ dres, statistics from the forward, dropout backward of
+//                         the attention-output dropout for the copy the attention-output weight gradient multiplies), gamma / beta
+//                         gradients reduced through LDS and added with one atomic per column and workgroup.
+// Synchronisation is the forward's (same barriers, same rings, same counted vmcnt of the consumer); every load whose destination
+// is a REGISTER is a plain load the compiler waits for itself (see bias_issue above).
+struct FfnPcBwdArgs {
+  const bf16* dy;       // [T, H]
+  const bf16* dres;     // [T, H], may be NULL
+  const bf16* f1;       // tile-major f1 of sm_ffn_pc_fwd
+  const void* w2tf;     // [I / 32][24][64][8] bf16
+  const void* w1tf;     // [I / 32][12][2][64][8] bf16
+  const float* z1;      // [T, H] fp32: LayerNorm-1 input
+  const float *ln1_g, *m1, *r1;
+  DropCfg drop;         // attention-output dropout (applied to dz1 for dz1d)
+  bf16 *df1, *ga;       // [ceil(T / 128) * 128, I] out, block-column-major (see the producer)
+  float* partials;      // [gridDim.x][2][384] fp32 scratch: the workgroups' gamma / beta column sums (NULL: float atomics on dgamma / dbeta)
+  bf16 *dz1, *dz1d;     // [T, H] out (dz1d may be NULL)
+  float *dgamma, *dbeta;
+  int T, I;
+};
+
+__global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
+  using OP = PcOp<false>;
+  using V = bf16x8;
+  extern __shared__ __attribute__((aligned(1024))) char pc_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tok = lane & 31, hh = lane >> 5;
+  const int T = a.T, I = a.I, NC = I / PC_IC;
+  const int t = w & 3;
+  const int blk_row0 = blockIdx.x * PC_TOK;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)pc_smem;
+  const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
+  PC_STAMP(w >> 2, 0);
+
+  // ---- prologue: dy rows of the workgroup -> the producers' B-fragment order in LDS (row-major, coalesced 16-byte loads) ----
+  {
+    const int sl = lane & 15, sub = lane >> 4;
+    bf16x8 din[4][3];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const bf16* dr = a.dy + (size_t)min(blk_row0 + it * 32 + w * 4 + sub, T - 1) * PC_H;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) din[it][i] = *reinterpret_cast<const bf16x8*>(dr + (sl + 16 * i) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 32 + w * 4 + sub;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ch = sl + 16 * i;
+        const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
+        pc_lds_write<V>(fa, din[it][i]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // A
+  asm volatile("" ::: "memory");
+  PC_STAMP(w >> 2, 1);
+
+  // ---- LayerNorm backward over the bf16 image dx1[128][384] at lds0 (row stride 768 B, 16-byte chunks XOR-swizzled with row & 7):
+  //      the row pass of gemm.hip's ln_bwd_tile_epilogue for a 128-row tile (8 waves x 16 rows, a row per 16 lanes) ----
+  auto ln_rows = [&]() __attribute__((always_inline)) {
+    const int sl = lane & 15, sub = lane >> 4;
+    float dg[3][8], db[3][8], gm[3][8];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      *reinterpret_cast<f32x4*>(gm[u]) = *reinterpret_cast<const f32x4*>(a.ln1_g + (sl + 16 * u) * 8);
+      *reinterpret_cast<f32x4*>(gm[u] + 4) = *reinterpret_cast<const f32x4*>(a.ln1_g + (sl + 16 * u) * 8 + 4);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { dg[u][q] = 0.f; db[u][q] = 0.f; }
+    }
+#pragma unroll 2
+    for (int it = 0; it < 4; ++it) {
+      const int trow = w * 16 + it * 4 + sub, row = blk_row0 + trow;
+      const bool live = row < T;
+      const int rr = min(row, T - 1);
+      V raw[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) raw[u] = pc_lds_read<V, 0>(lds0 + (uint32_t)(trow * 768 + (((sl + 16 * u) ^ (trow & 7)) << 4)));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : : "memory");
+      const float mu = a.m1[rr], rs = a.r1[rr];
+      float dy[3][8], xn[3][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const size_t off = (size_t)rr * PC_H + (sl + 16 * u) * 8;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.z1 + off), x1v = *reinterpret_cast<const f32x4*>(a.z1 + off + 4);
+        bf16x8 rv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rv[q] = (bf16)0.f;
+        if (a.dres) rv = *reinterpret_cast<const bf16x8*>(a.dres + off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float xv = q < 4 ? x0[q] : x1v[q - 4];
+          dy[u][q] = live ? (float)(bf16)((float)raw[u][q] + (float)rv[q]) : 0.f;  // (the un-fused path stores dx1 in bf16 before its LayerNorm backward)
+          xn[u][q] = live ? (xv - mu) * rs : 0.f;
+          const float dyg = dy[u][q] * gm[u][q];
+          s1 += dyg;
+          s2 += dyg * xn[u][q];
+          dg[u][q] += dy[u][q] * xn[u][q];
+          db[u][q] += dy[u][q];
+        }
+      }
+      s1 = pc_lanes_sum<16>(s1);
+      s2 = pc_lanes_sum<16>(s2);
+      const float c1 = s1 * (1.f / PC_H), c2 = s2 * (1.f / PC_H);
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int col = (sl + 16 * u) * 8;
+          const size_t off = (size_t)row * PC_H + col;
+          float gx[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) gx[q] = rs * (dy[u][q] * gm[u][q] - c1 - xn[u][q] * c2);
+          *reinterpret_cast<bf16x8*>(a.dz1 + off) = OP::pack(gx);
+          if (a.dz1d) {
+            if (a.drop.thresh16) drop_apply8(a.drop, (uint64_t)row * PC_H + col, gx);
+            *reinterpret_cast<bf16x8*>(a.dz1d + off) = OP::pack(gx);
+          }
+        }
+      }
+    }
+    PC_STAMP(w >> 2, 5);
+    // gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, ONE global atomic per column and workgroup
+    const uint32_t colsum = lds0 + 128 * 768;  // [2][384] fp32 behind the image
+    __builtin_amdgcn_s_barrier();  // every wave has read its image rows
+    for (int c = tid; c < 2 * PC_H; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float x = dg[u][q], y = db[u][q];
+        x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+        y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
+        if (sub == 0) {
+          const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
+          asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(x) : "memory");
+          asm volatile("ds_add_f32 %0, %1" ::"v"(ca + PC_H * 4), "v"(y) : "memory");
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = tid; c < 2 * PC_H; c += 512) {
+      float v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
+      // (768 addresses shared by every workgroup: 256 workgroups' atomics on them took 27 k cycles per workgroup)
+      if (a.partials) a.partials[(size_t)blockIdx.x * (2 * PC_H) + c] = v;
+      else atomicAdd(c < PC_H ? a.dgamma + c : a.dbeta + (c - PC_H), v);
+    }
+    PC_STAMP(w >> 2, 7);
+  };
+
+  if (w >= 4) {
+    // =================================================================== consumer
+    const int cw = w - 4;
+    const char* r1f = reinterpret_cast<const char*>(a.w2tf) + cw * 6 * 1024 + lane * 16;  // ring 1: the producers' operand
+    const char* r2f = reinterpret_cast<const char*>(a.w1tf) + cw * 6 * 1024 + lane * 16;  // ring 2: this role's operand
+    char* d1 = pc_smem + PC_W1_OFF + cw * 6 * 1024;
+    char* d2 = pc_smem + PC_W2_OFF + cw * 6 * 1024;
+    auto dma = [&](const char* src, char* dst) __attribute__((always_inline)) { __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0); };
+    __builtin_amdgcn_s_barrier();  // B
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      dma(r1f + u * 1024, d1 + u * 1024);
+      dma(r1f + (size_t)min(1, NC - 1) * PC_CHUNK + u * 1024, d1 + PC_CHUNK + u * 1024);
+      dma(r1f + (size_t)min(2, NC - 1) * PC_CHUNK + u * 1024, d1 + 2 * PC_CHUNK + u * 1024);
+      dma(r2f + u * 1024, d2 + u * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // P0
+    __builtin_amdgcn_s_barrier();  // P1
+    asm volatile("" ::: "memory");
+    PC_STAMP(1, 2);
+    f32x16 acc[PC_NT];
+#pragma unroll
+    for (int n = 0; n < PC_NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    auto piece = [&](int st, int u) __attribute__((always_inline)) {
+      if (u < 6) dma(r2f + (size_t)min(st + 1, NC - 1) * PC_CHUNK + u * 1024, d2 + ((st + 1) % 3) * PC_CHUNK + u * 1024);
+      else dma(r1f + (size_t)min(st + 3, NC - 1) * PC_CHUNK + (u - 6) * 1024, d1 + (st % 3) * PC_CHUNK + (u - 6) * 1024);
+    };
+    auto gemm2 = [&](int c, int st) __attribute__((always_inline)) {
+      const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
+      V g0 = pc_lds_read<V, 0>(gb), g1 = pc_lds_read<V, 1024>(gb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1) : : "memory");
+      pc_stream24<V>(lbase + PC_W2_OFF + (uint32_t)((c % 3) * PC_CHUNK),
+                     [&](auto kc, V fr) __attribute__((always_inline)) {
+                       constexpr int k = decltype(kc)::value;
+                       acc[k >> 1] = OP::mma(fr, (k & 1) ? g1 : g0, acc[k >> 1]);
+                     },
+                     [&](auto kc) __attribute__((always_inline)) {
+                       constexpr int k = decltype(kc)::value;
+                       if constexpr (k & 1) {
+                         if (st >= 0) piece(st, k >> 1);
+                       }
+                     });
+    };
+    auto step_end = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // every batch of the previous steps has landed (twelve pieces per step, nothing else)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+#pragma unroll
+    for (int u = 0; u < 12; ++u) piece(0, u);
+    step_end();
+    for (int st = 1; st < NC; ++st) {
+      gemm2(st - 1, st);
+      PC_STAMP(1, 8 + 2 * st);
+      step_end();
+      PC_STAMP(1, 9 + 2 * st);
+    }
+    gemm2(NC - 1, -1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PC_STAMP(1, 3);
+    __builtin_amdgcn_s_barrier();  // E1: the rings are idle (every wave past its last read, every LDS-DMA landed)
+    asm volatile("" ::: "memory");
+    // the bf16 image of dx1: tile n, register 4 q + k of lane (tok, hh) is column 32 n + 8 q + 4 hh + k of token 32 t + tok
+    {
+      const int trow = t * 32 + tok;
+      const uint32_t rowa = lds0 + (uint32_t)(trow * 768 + 8 * hh);
+#pragma unroll
+      for (int n = 0; n < PC_NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          union { bf16x4 v; unsigned long long u; } pk;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pk.v[k] = (bf16)acc[n][4 * q + k];
+          asm volatile("ds_write_b64 %0, %1" ::"v"(rowa + (uint32_t)((((4 * n + q) ^ (trow & 7)) << 4))), "v"(pk.u) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // E2: the image is complete
+    asm volatile("" ::: "memory");
+    PC_STAMP(1, 4);
+    ln_rows();
+    return;
+  }
+
+  // ===================================================================== producer
+  V xb[PC_KS];
+  {
+    const uint32_t fb = lbase + (uint32_t)(t * PC_KS * 1024);
+    pc_static_for<0, PC_KS>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(kc)::value;
+      xb[ks] = pc_lds_read<V, ks * 1024>(fb);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]), "+v"(xb[7]), "+v"(xb[8]), "+v"(xb[9]),
+                   "+v"(xb[10]), "+v"(xb[11]), "+v"(xb[12]), "+v"(xb[13]), "+v"(xb[14]), "+v"(xb[15]), "+v"(xb[16]), "+v"(xb[17]), "+v"(xb[18]),
+                   "+v"(xb[19]), "+v"(xb[20]), "+v"(xb[21]), "+v"(xb[22]), "+v"(xb[23])
+                 :
+                 : "memory");
+  }
+  __builtin_amdgcn_s_barrier();  // B
+  __builtin_amdgcn_s_barrier();  // P0
+  asm volatile("" ::: "memory");
+
+  const bf16* const f1lane = a.f1 + ((size_t)(blockIdx.x * 4 + t) * NC * 64 + lane) * 16;
+  // (rows past T included: the dF1 / ga buffers are whole 128-row blocks like f1 -- the stores are UNCONDITIONAL, so that every
+  //  path through a step issues the same vector-memory operations and the compiler's wait for the f1 words is vmcnt(8), not a
+  //  drain of the step's stores: with `if (row < T)` around them it was vmcnt(0), ~2 k cycles per step)
+  // Layout of dF1 / ga: BLOCK-COLUMN-MAJOR [T / 32][I / 8][32 tokens][8 columns] -- the lane's 4 values of a (chunk, q) are half of
+  // one 16-byte unit, and the 64 lanes of a store instruction write 512 CONTIGUOUS bytes.  (Row-major, the same instruction wrote
+  // 32 pieces of 16 bytes 3 KiB apart: 256 cache-line visits per wave and step, and a step took 4.75 k cycles against the
+  // forward's 2.6 k.)  The weight-gradient GEMM reads the layout directly (sm_gemm_tn_acc_bcm: a lane's LDS-DMA piece is one unit).
+  const size_t bcm0 = ((size_t)(blockIdx.x * 4 + t) * (I >> 3) * 32 + tok) * 8 + 4 * hh;
+  bf16* const df1row = a.df1 + bcm0;
+  bf16* const garow = a.ga + bcm0;
+  auto f1_issue = [&](int c, bf16x8(&f)[2]) __attribute__((always_inline)) {
+    const bf16x8* fp = reinterpret_cast<const bf16x8*>(f1lane + (size_t)c * (64 * 16));
+    f[0] = fp[0];
+    f[1] = fp[1];
+  };
+  // dF1 = dG * gelu'(f1) and ga = gelu(f1) of one chunk behind the MFMAs of the next chunk's GEMM, the forward's sigmoid-form GELU
+  // (gelu_sig_both of common.h) cut into FOUR stages spread over gaps e .. e + 3 -- (A) x^2, both polynomials, the exponent;
+  // (B) exp2 and 1 + e; (C) rcp; (D) value, derivative, product -- so that every gap carries four independent chains of a few
+  // instructions instead of one of sixteen with two transcendentals in it (a dependent vector instruction waits ~8 cycles for its
+  // operand, a transcendental more).  Then the two B fragments of dF1^T for the consumer and the row-major stores
+  // (register 4 q + k <-> column 32 c + 8 q + 4 hh + k of the lane's token).
+  float o[16], og[16], s_bu[4], s_du[4], s_e[4], s_r[4];
+  V glo, ghi;
+  auto fin_piece = [&](auto kc, const f32x16& X, const bf16x8(&f)[2], int c) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k >= 3 && k <= 18) {  // (D) element k - 3
+      constexpr int e = k - 3;
+      const float x = (float)f[e >> 3][e & 7], r = s_r[e & 3];
+      const float g = x * r;
+      const float gp = fmaf(fmaf(-g, r, g), s_du[e & 3], r);  // r + g (1 - r) u'
+      o[e] = X[e] * gp;
+      og[e] = g;
+      asm volatile("" : "+v"(o[e]), "+v"(og[e]));
+    }
+    if constexpr (k >= 2 && k <= 17) {  // (C) element k - 2
+      s_r[(k - 2) & 3] = __builtin_amdgcn_rcpf(s_e[(k - 2) & 3]);
+      asm volatile("" : "+v"(s_r[(k - 2) & 3]));
+    }
+    if constexpr (k >= 1 && k <= 16) {  // (B) element k - 1
+      s_e[(k - 1) & 3] = 1.0f + __builtin_amdgcn_exp2f(s_bu[(k - 1) & 3]);
+      asm volatile("" : "+v"(s_e[(k - 1) & 3]));
+    }
+    if constexpr (k < 16) {             // (A) element k
+      const float x = (float)f[k >> 3][k & 7];
+      const float x2 = fminf(x * x, 81.0f);
+      float p = fmaf(x2, 1.01426436e-3f, -1.06775740e-1f);
+      p = fmaf(p, x2, -2.30112135f);
+      float du = fmaf(x2, -3.51517452e-3f, 2.22033902e-1f);
+      s_du[k & 3] = fmaf(du, x2, 1.59501576f);
+      s_bu[k & 3] = x * p;
+      asm volatile("" : "+v"(s_du[k & 3]), "+v"(s_bu[k & 3]));
+    }
+    if constexpr (k == 19) {
+      float lo8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lo8[j] = o[j];
+      glo = OP::pack(lo8);
+      asm volatile("" : "+v"(glo));
+    } else if constexpr (k == 20) {
+      float hi8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hi8[j] = o[8 + j];
+      ghi = OP::pack(hi8);
+      asm volatile("" : "+v"(ghi));
+    }
+    if constexpr (k >= 19 && k <= 22) {
+      constexpr int q = k - 19;
+      bf16x4 d, g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = (bf16)o[4 * q + j]; g[j] = (bf16)og[4 * q + j]; }
+      *reinterpret_cast<bf16x4*>(df1row + (size_t)(4 * c + q) * 256) = d;
+      *reinterpret_cast<bf16x4*>(garow + (size_t)(4 * c + q) * 256) = g;
+    }
+  };
+  auto hand_over = [&](int c) __attribute__((always_inline)) {
+    const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
+    pc_lds_write<V>(gb, glo);
+    pc_lds_write<V>(gb + 1024, ghi);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  bf16x8 fc[2], fn[2];
+  f1_issue(0, fc);
+  f32x16 X;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) X[r] = 0.f;
+  pc_stream24<V>(lbase + PC_W1_OFF,
+                 [&](auto kc, V fr) __attribute__((always_inline)) {
+                   constexpr int k = decltype(kc)::value;
+                   X = OP::mma(fr, xb[k], X);
+                 },
+                 [&](auto) __attribute__((always_inline)) {});
+  // (a use here: the compiler waits for the first chunk's f1 before the loop, see ffn_pc_fwd_kernel)
+  asm volatile("" : "+v"(fc[0]), "+v"(fc[1]));
+  __builtin_amdgcn_s_barrier();  // P1
+  asm volatile("" ::: "memory");
+  PC_STAMP(0, 2);
+  for (int s = 0; s + 1 < NC; ++s) {
+    f32x16 Xn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xn[r] = 0.f;
+    pc_stream24<V>(lbase + PC_W1_OFF + (uint32_t)(((s + 1) % 3) * PC_CHUNK),
+                   [&](auto kc, V fr) __attribute__((always_inline)) {
+                     constexpr int k = decltype(kc)::value;
+                     Xn = OP::mma(fr, xb[k], Xn);
+                   },
+                   [&](auto kc) __attribute__((always_inline)) {
+                     constexpr int k = decltype(kc)::value;
+                     if constexpr (k == 0) f1_issue(s + 1, fn);  // consumed one step from now
+                     fin_piece(kc, X, fc, s);
+                   });
+    PC_STAMP(0, 10 + 2 * s);
+    hand_over(s);
+    PC_STAMP(0, 11 + 2 * s);
+    X = Xn;
+    fc[0] = fn[0];
+    fc[1] = fn[1];
+  }
+  pc_static_for<0, 23>([&](auto kc) __attribute__((always_inline)) { fin_piece(kc, X, fc, NC - 1); });
+  hand_over(NC - 1);
+  PC_STAMP(0, 3);
+  __builtin_amdgcn_s_barrier();  // E1
+  __builtin_amdgcn_s_barrier();  // E2
+  asm volatile("" ::: "memory");
+  PC_STAMP(0, 4);
+  ln_rows();
+}
+
+// dgamma / dbeta += the workgroups' column sums (partials [nblk][2][384])
+__global__ __launch_bounds__(256) void ffn_pc_colsum_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * PC_H) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += partials[(size_t)b * (2 * PC_H) + c];
+    s1 += partials[(size_t)(b + 1) * (2 * PC_H) + c];
+    s2 += partials[(size_t)(b + 2) * (2 * PC_H) + c];
+    s3 += partials[(size_t)(b + 3) * (2 * PC_H) + c];
+  }
+  for (; b < nblk; ++b) s0 += partials[(size_t)b * (2 * PC_H) + c];
+  atomicAdd(c < PC_H ? dgamma + c : dbeta + (c - PC_H), (s0 + s1) + (s2 + s3));
+}
+
 // ---- fragment-major weight staging for the kernels above (one launch for all layers: the layers of the flat parameter buffer
 //      are equally spaced).  e = ((c * 24 + piece) * 64 + lane) * 8 + j, lane = (kg, r) = (lane >> 5, lane & 31)
 //   w1f  [L][I/32][24 ks][64][8]        W1[32 c + r][16 ks + 8 kg + j]                               (forward GEMM 1, operand type)
@@ -673,6 +1099,30 @@ extern "C" int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, co
   return SM_OK;
 }
 
+
+extern "C" int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, const void* w2tf, const void* w1tf, const float* z1,
+                             const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
+                             void* dz1d, float* dgamma, float* dbeta, float* partials, int T, int H, int I, void* stream) {
+  if (H != PC_H || I % PC_IC != 0 || I < 4 * PC_IC || T % 16 != 0 || T <= 0 || (long)T * I * 2 >= (1L << 32)) return 1;
+  SM_REQUIRE(dy && f1 && w2tf && w1tf && z1 && ln1_g && m1 && r1 && df1 && ga && dz1 && dgamma && dbeta, "sm_ffn_pc_bwd: null argument");
+  const uintptr_t al = (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)f1 | (uintptr_t)w2tf | (uintptr_t)w1tf | (uintptr_t)z1 | (uintptr_t)ln1_g |
+                       (uintptr_t)df1 | (uintptr_t)ga | (uintptr_t)dz1 | (uintptr_t)dz1d;
+  SM_REQUIRE((al % 16) == 0, "sm_ffn_pc_bwd: pointers must be 16-byte aligned");
+  FfnPcBwdArgs a;
+  a.dy = (const bf16*)dy; a.dres = (const bf16*)dres; a.f1 = (const bf16*)f1; a.w2tf = w2tf; a.w1tf = w1tf; a.z1 = z1; a.ln1_g = ln1_g;
+  a.m1 = m1; a.r1 = r1; a.drop = make_drop(drop); a.df1 = (bf16*)df1; a.ga = (bf16*)ga; a.dz1 = (bf16*)dz1; a.dz1d = (bf16*)dz1d;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.partials = partials; a.T = T; a.I = I;
+  hipStream_t st = (hipStream_t)stream;
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_pc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+  const int blocks = sm_cdiv(T, PC_TOK);
+  hipLaunchKernelGGL(ffn_pc_bwd_kernel, dim3(blocks), dim3(512), PC_LDS, st, a);
+  SM_LAUNCH_CHECK();
+  if (partials) {
+    hipLaunchKernelGGL(ffn_pc_colsum_reduce_kernel, dim3(3), dim3(256), 0, st, partials, blocks, dgamma, dbeta);
+    SM_LAUNCH_CHECK();
+  }
+  return SM_OK;
+}
 
 #ifdef PC_STAMPS
 extern "C" int sm_pc_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pc_stamps), sizeof(pc_stamps)); }

@@ -1121,6 +1121,12 @@ __global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict_
   if (mbeg >= mend) return;
   const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nst = (mend - mbeg + TG_BKM - 1) / TG_BKM;  // the last stage may be partial: its missing rows read zeros
+  // A NEGATIVE leading dimension marks an operand in the block-column-major layout of the fused feed-forward backward
+  // (sm_gemm_tn_acc_bcm): [rows / 32][cols / 8][32 rows][8 cols], i.e. element (r, c) at (((r >> 5) (cols >> 3) + (c >> 3)) 32 +
+  // (r & 31)) 8 + (c & 7) -- a lane's 16-byte piece (one row, 8 columns) is one unit of it, a 32-row stage is 32 * cols elements
+  // further, exactly as in the row-major layout (splits start at multiples of 32 rows)
+  const bool a_bcm = lda < 0, b_bcm = ldb < 0;
+  const size_t astage = a_bcm ? (size_t)TG_BKM * N : (size_t)TG_BKM * lda, bstage = b_bcm ? (size_t)TG_BKM * Kc : (size_t)TG_BKM * ldb;
   if (w8 >= 4) {
     // ---------------- loader waves ----------------
     const int w = w8 - 4;
@@ -1132,8 +1138,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict_
       const int cphys = lane & 15;
       const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
       lrow[p] = mbeg + row;
-      aoff[p] = (size_t)(mbeg + row) * lda + n0 + clog;
-      boff[p] = (size_t)(mbeg + row) * ldb + k0 + clog;
+      aoff[p] = a_bcm ? ((size_t)(mbeg >> 5) * (N >> 3) + ((n0 + clog) >> 3)) * 256 + row * 8 : (size_t)(mbeg + row) * lda + n0 + clog;
+      boff[p] = b_bcm ? ((size_t)(mbeg >> 5) * (Kc >> 3) + ((k0 + clog) >> 3)) * 256 + row * 8 : (size_t)(mbeg + row) * ldb + k0 + clog;
     }
     const bf16* const zsrc = reinterpret_cast<const bf16*>(&g_tn_zero16);
     auto issue = [&](int st) {
@@ -1142,8 +1148,8 @@ __global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict_
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const bool in = lrow[p] + st * TG_BKM < mend;
-        const bf16* pa = in ? A + aoff[p] + (size_t)st * TG_BKM * lda : zsrc;
-        const bf16* pb = in ? B + boff[p] + (size_t)st * TG_BKM * ldb : zsrc;
+        const bf16* pa = in ? A + aoff[p] + (size_t)st * astage : zsrc;
+        const bf16* pb = in ? B + boff[p] + (size_t)st * bstage : zsrc;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)pa, (lds_void_t*)(da + p * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)pb, (lds_void_t*)(db + p * 1024), 16, 0, 0);
       }
@@ -1717,6 +1723,7 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
   if constexpr (sizeof(T) == 2) {
     if (tn_glds && N % 128 == 0 && Kc % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
       plan(tn_blocks, TG_BKM, nsplit, rows_per_split);
+      SM_REQUIRE((lda > 0 && ldb > 0) || rows_per_split % 32 == 0, "sm_gemm_tn_acc_bcm: a split must start at a multiple of 32 rows");
       auto launch = [&](auto kern, int nstg, int nthr = NTHREADS) {
         const int lds = 2 * nstg * TG_STAGE;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1729,6 +1736,7 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
       return 0;
     }
   }
+  SM_REQUIRE(lda > 0 && ldb > 0, "sm_gemm_tn_acc_bcm: block-column-major operands need bf16, N %% 128 == 0 and Kc %% 128 == 0 (N=%d Kc=%d)", N, Kc);
   plan(tn_blocks, BKM, nsplit, rows_per_split);
   hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(nblocks(nsplit)), dim3(NTHREADS), 0, st, (const T*)A, lda, (const T*)B, ldb, C, ldc, M, N, Kc,
                      rows_per_split, colsum, tn_xcd ? nsplit : -nsplit);
@@ -1849,9 +1857,23 @@ extern "C" int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, 
   SM_REQUIRE((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "sm_gemm_tn_acc: lda/ldb rows must be 16-byte aligned");
   SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_tn_acc: A/B must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SM_BF16) launch_gemm_tn<bf16>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
-  else if (dtype == SM_F32) launch_gemm_tn<float>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
+  int rc = 0;
+  if (dtype == SM_BF16) rc = launch_gemm_tn<bf16>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
+  else if (dtype == SM_F32) rc = launch_gemm_tn<float>(A, lda, B, ldb, C, ldc, M, N, Kc, colsum, st);
   else SM_REQUIRE(false, "sm_gemm_tn_acc: bad dtype %d", dtype);
+  if (rc != 0) return rc;
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
+// the same product with operands in the BLOCK-COLUMN-MAJOR layout sm_ffn_pc_bwd writes its dF1 / gelu(f1) in (a_bcm / b_bcm != 0;
+// a row-major operand is dense: lda = N, ldb = Kc): bf16, N % 128 == 0, Kc % 128 == 0
+extern "C" int sm_gemm_tn_acc_bcm(const void* A, int a_bcm, const void* B, int b_bcm, float* C, int ldc, int M, int N, int Kc, float* colsum,
+                                  void* stream) {
+  SM_REQUIRE(M > 0 && N > 0 && Kc > 0 && N % 128 == 0 && Kc % 128 == 0, "sm_gemm_tn_acc_bcm: N=%d and Kc=%d must be multiples of 128", N, Kc);
+  SM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sm_gemm_tn_acc_bcm: A/B must be 16-byte aligned");
+  const int rc = launch_gemm_tn<bf16>(A, a_bcm ? -N : N, B, b_bcm ? -Kc : Kc, C, ldc, M, N, Kc, colsum, (hipStream_t)stream);
+  if (rc != 0) return rc;
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

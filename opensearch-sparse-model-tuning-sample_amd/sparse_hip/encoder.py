@@ -201,6 +201,9 @@ class HipBertMLM(torch.nn.Module):
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
         self.pc_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
                        and cfg.intermediate_size >= 128 and os.environ.get("SM_PC_FFN", "1") == "1")
+        # ... and its BACKWARD in the same form (one launch for the dF1 GEMM + the GEMM fused with the LayerNorm-1 backward: dF1 is
+        # consumed on the chip by the second GEMM instead of being read back); SM_PC_FFN_BWD=0 keeps the two launches
+        self.pc_ffn_bwd = self.pc_ffn and os.environ.get("SM_PC_FFN_BWD", "1") == "1"
         # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
         # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
         # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
@@ -429,11 +432,14 @@ class HipBertMLM(torch.nn.Module):
             if "pc_w1f" not in st:
                 st["pc_w1f"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=op, device=dev)
                 st["pc_w2f"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=op, device=dev)
+                if self.pc_ffn_bwd:  # the backward's operands (bf16)
+                    st["pc_w2tf"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=torch.bfloat16, device=dev)
+                    st["pc_w1tf"] = torch.empty((nl, I // 32, 24, 64, 8), dtype=torch.bfloat16, device=dev)
             n0 = "bert.encoder.layer.0."
             stride = (self._offsets["bert.encoder.layer.1.intermediate.dense.weight"][0]
                       - self._offsets[n0 + "intermediate.dense.weight"][0]) if nl > 1 else 0
             ops.ffn_pc_stage(self.view(n0 + "intermediate.dense.weight"), self.view(n0 + "output.dense.weight"), stride, nl,
-                             st["pc_w1f"], st["pc_w2f"], None, None)
+                             st["pc_w1f"], st["pc_w2f"], st.get("pc_w2tf"), st.get("pc_w1tf"))
         if self.fp8:  # e4m3 copies of the encoder linears' weights (and of their transposes, for the input gradients) + scales
             for l in range(cfg.num_hidden_layers):
                 for k in ("qkv", "o", "w1", "w2"):
@@ -813,7 +819,17 @@ class _EncodeFn(torch.autograd.Function):
                                               d_h2, want_drop=d_h2 is not None)
             a2 = dz2d if d_h2 is not None else dz2
             fused = None
-            if ga is not None:
+            if ga is None and model.pc_ffn_bwd and f1.dim() == 4:  # the fused feed-forward's backward: dF1, gelu(f1), dz1 from one launch
+                fb = ops.ffn_pc_bwd(a2, dz2, f1, st["pc_w2tf"][l], st["pc_w1tf"][l], z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+                                    d_h1, g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
+                                    want_drop=d_h1 is not None)
+                if fb is not None:
+                    df1, ga, dz1, dz1d = fb
+                    fused = (dz1, dz1d)
+                    wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+            if fused is not None:
+                pass
+            elif ga is not None:
                 wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
                 df1 = model._lin(a2, f"w2T{l}", grad=True, gelu_grad_of=f1)
             else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
@@ -823,7 +839,8 @@ class _EncodeFn(torch.autograd.Function):
             wg.run(df1, x1, g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"))
             # FFN-up input gradient + residual, fused with the LayerNorm backward that consumes it where the kernel
             # takes the shape (hidden 384, long K): the [T, H] gradient in between never goes to HBM
-            fused = None if model.fp8 else ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
+            if fused is None:
+                fused = None if model.fp8 else ops.gemm_nt_ln_bwd(df1, st[f"w1T{l}"], dz2, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                        g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"),
                                        d_h1, want_drop=d_h1 is not None)
             if fused is not None:

@@ -85,8 +85,33 @@ def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, 
     return (dx, dx_drop) if ok else None
 
 
-def gemm_tn_acc(A: Tensor, B: Tensor, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
-    """out[N,Kc] += A[M,N]^T @ B[M,Kc] (fp32 accumulate); colsum[N] += A.sum(0)."""
+class Bcm:
+    """A [rows, cols] bf16 matrix in the BLOCK-COLUMN-MAJOR layout of the fused feed-forward backward's dF1 / gelu(f1) outputs
+    (include/sparse_hip.h, sm_ffn_pc_bwd): buf [ceil(rows / 128) * 4][cols / 8][32][8].  Only gemm_tn_acc reads it."""
+
+    def __init__(self, buf: Tensor, rows: int, cols: int):
+        self.buf, self.shape = buf, (int(rows), int(cols))
+
+    def record_stream(self, stream):
+        self.buf.record_stream(stream)
+
+    def rows(self) -> Tensor:
+        """row-major copy (tests)"""
+        r, c = self.shape
+        return self.buf.permute(0, 2, 1, 3).reshape(-1, c)[:r].contiguous()
+
+
+def gemm_tn_acc(A, B, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
+    """out[N,Kc] += A[M,N]^T @ B[M,Kc] (fp32 accumulate); colsum[N] += A.sum(0).  A / B: tensors, or Bcm objects."""
+    if isinstance(A, Bcm) or isinstance(B, Bcm):
+        M, N = A.shape
+        Kc = B.shape[1]
+        assert B.shape[0] == M and out.dtype == torch.float32 and tuple(out.shape) == (N, Kc) and out.is_contiguous()
+        ta, tb = (A.buf if isinstance(A, Bcm) else A), (B.buf if isinstance(B, Bcm) else B)
+        assert ta.dtype == torch.bfloat16 and tb.dtype == torch.bfloat16 and ta.is_contiguous() and tb.is_contiguous()
+        L.call("sm_gemm_tn_acc_bcm", L.ptr(ta), int(isinstance(A, Bcm)), L.ptr(tb), int(isinstance(B, Bcm)), L.ptr(out), out.stride(0), M, N, Kc,
+               L.ptr(colsum), L.stream_ptr())
+        return out
     M, N = A.shape
     Kc = B.shape[1]
     assert B.shape[0] == M and out.dtype == torch.float32 and tuple(out.shape) == (N, Kc)
@@ -140,6 +165,25 @@ def ffn_pc_fwd(z1: Tensor, ln1_g: Tensor, ln1_b: Tensor, eps: float, w1f: Tensor
                          L.ptr(bias1), L.ptr(w2f), L.ptr(bias2), L.ptr(ln2_g), L.ptr(ln2_b), _drop_ref(drop), L.ptr(x1), L.ptr(m1),
                          L.ptr(r1), L.ptr(f1), L.ptr(z2), L.ptr(x2), L.ptr(m2), L.ptr(r2), T, H, I, L.stream_ptr())
     return (x1, m1, r1, f1, z2, x2, m2, r2) if ok else None
+
+
+def ffn_pc_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2tf: Tensor, w1tf: Tensor, z1: Tensor, ln1_g: Tensor, m1: Tensor,
+               r1: Tensor, drop: Optional[L.SmDropout], dgamma: Tensor, dbeta: Tensor, want_drop: bool):
+    """(df1, ga, dz1, dz1d) of the fused block's backward (f1: the tile-major tensor of ffn_pc_fwd), or None when the kernel does
+    not take the shape; df1 / ga are Bcm objects (block-column-major: what gemm_tn_acc reads them as)"""
+    T, H = dy.shape
+    I = f1.shape[1] * 32 if f1.dim() == 4 else 0
+    if dy.dtype != torch.bfloat16 or f1.dim() != 4 or H != 384 or T % 16 or z1.dtype != torch.float32 or not dy.is_contiguous():
+        return None
+    nblk = (T + 127) // 128  # the kernel stores whole 128-row blocks (its stores are unconditional)
+    df1, ga = (Bcm(_new((4 * nblk, I // 8, 32, 8), torch.bfloat16, dy), T, I) for _ in range(2))
+    partials = _new((nblk, 2 * H), torch.float32, dy)
+    dz1 = torch.empty_like(dy)
+    dz1d = torch.empty_like(dy) if want_drop else None
+    ok = L.call_optional("sm_ffn_pc_bwd", L.ptr(dy), L.ptr(dres), L.ptr(f1), L.ptr(w2tf), L.ptr(w1tf), L.ptr(z1), L.ptr(ln1_g), L.ptr(m1),
+                         L.ptr(r1), _drop_ref(drop), L.ptr(df1.buf), L.ptr(ga.buf), L.ptr(dz1), L.ptr(dz1d), L.ptr(dgamma), L.ptr(dbeta),
+                         L.ptr(partials), T, H, I, L.stream_ptr())
+    return (df1, ga, dz1, dz1d) if ok else None
 
 
 # ---------------------------------------------------------------- LayerNorm / embeddings

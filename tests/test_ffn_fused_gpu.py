@@ -263,3 +263,107 @@ def test_ffn_pc_forward_other_intermediate_sizes(ops, inter):
     assert float((_f1_rows(out[3], T).float() - f1).abs().max() / (1 + f1.abs().max())) < 1e-2
     assert float((out[4] - z2).abs().max() / (1 + z2.abs().max())) < 4e-3
     assert float((out[5].float() - x2).abs().max() / (1 + x2.abs().max())) < 1e-2
+
+
+# ------------------------------------------------------------------ the backward in the same form (ffn_pc_bwd_kernel)
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [16, 112, 128, 1008, 4096 + 48, 6160 + 16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_ffn_pc_backward_matches_torch_and_the_unfused_launches(ops, T, with_res):
+    """dF1 = (dy W2) * gelu'(f1), ga = gelu(f1), dz1 = LayerNorm-1'(dF1 W1 + dres), its dropout-masked copy and the gamma / beta
+    gradients from ONE launch, against (a) plain torch fp32 autograd on the same operands (hf:334-351 + hf:293 backward; exact-erf
+    GELU: the kernel's sigmoid form differs by <= 2e-4 in the derivative) and (b) the launches it replaces (sm_gemm_nt with the
+    tile-major dF1 epilogue, then sm_gemm_nt_ln_bwd / sm_gemm_nt + sm_layernorm_bwd_res32).  Token counts that end inside a
+    workgroup (T % 128 != 0) included."""
+    from sparse_hip import lib
+    bf = torch.bfloat16
+    w1, w2 = _weights(seed=20)
+    _, _, w2tf, w1tf = _stage_pc(ops, w1, w2, torch.float16)
+    dy = (_rnd(T, H, seed=21) * 0.5).to(bf)
+    dres = (_rnd(T, H, seed=22) * 0.5).to(bf) if with_res else None
+    f1 = _rnd(T, I, seed=23).to(bf)
+    z1 = _rnd(T, H, seed=24, scale=1.5) + 0.3
+    gamma, beta = 1.0 + 0.1 * _rnd(H, seed=25), 0.1 * _rnd(H, seed=26)
+    _, _, m1, r1 = ops.layernorm_fwd_res32(z1, gamma, beta, 1e-12, bf, want_y32=False)
+    drop = lib.dropout(0.1, 31, 6)
+    dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    got = ops.ffn_pc_bwd(dy, dres, _f1_tiles(f1, I), w2tf[0], w1tf[0], z1, gamma, m1, r1, drop, dg, db, want_drop=True)
+    assert got is not None, "the fused backward must take this shape"
+    df1_b, ga_b, dz1, dz1d = got
+    df1, ga = df1_b.rows(), ga_b.rows()  # block-column-major -> row-major
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(x.float()).all() for x in (df1, ga, dz1, dz1d, dg, db))
+    # (a) torch fp32 on the values the kernel multiplies (weights rounded to bf16 by the staging)
+    w1b, w2b = w1[0].to(bf).float(), w2[0].to(bf).float()
+    x = f1.float().requires_grad_(True)
+    gelu = 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    (gp,) = torch.autograd.grad(gelu.sum(), x)
+    df1_ref = (dy.float() @ w2b) * gp
+    _close(df1, df1_ref, 1e-2, "dF1 vs torch")
+    _close(ga, gelu.detach(), 1e-2, "gelu(f1) vs torch")
+    dx1 = df1.float() @ w1b + (dres.float() if with_res else 0.0)  # (from the kernel's own bf16 dF1: isolates the second half)
+    zr = z1.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(zr, (H,), gr, br, 1e-12).backward(dx1.to(bf).float())
+    _close(dz1, zr.grad, 1.5e-2, "dz1 vs torch")
+    fro = lambda a, b: float((a.float() - b.float()).norm() / max(1e-12, float(b.float().norm())))
+    assert fro(dg, gr.grad) <= 1e-2 and fro(db, br.grad) <= 1e-2, (fro(dg, gr.grad), fro(db, br.grad))
+    # the dropout-masked copy: exactly the mask dropout_bwd regenerates for the same (seed, site)
+    mask = ops.dropout_bwd(torch.ones(T, H, dtype=bf, device="cuda"), drop).float()
+    assert torch.equal(dz1d.float() != 0, (mask != 0) & (dz1.float() != 0) | ((dz1d.float() != 0) & (dz1.float() == 0)))
+    kept = mask != 0
+    assert float((dz1d.float()[kept] - (dz1.float() * mask)[kept]).abs().max()) <= 2e-2 * float(dz1.float().abs().max())
+    # (b) the launches it replaces
+    ga0 = torch.empty(T, I, dtype=bf, device="cuda")
+    df0 = ops.gemm_nt(dy, w2[0].t().contiguous().to(bf), gelu_grad_of=_f1_tiles(f1, I), gelu_out=ga0, gelu_grad_tiled=True)
+    assert fro(df1, df0) <= 4e-3 and fro(ga, ga0) <= 4e-3, (fro(df1, df0), fro(ga, ga0))
+    dg0, db0 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    dx0 = ops.gemm_nt(df0, w1[0].t().contiguous().to(bf), residual=dres)
+    dz0, dzd0 = ops.layernorm_bwd(dx0, z1, gamma, m1, r1, dg0, db0, drop, want_drop=True)
+    assert fro(dz1, dz0) <= 1e-2 and fro(dz1d, dzd0) <= 1e-2 and fro(dg, dg0) <= 1e-2 and fro(db, db0) <= 1e-2, \
+        (fro(dz1, dz0), fro(dz1d, dzd0), fro(dg, dg0), fro(db, db0))
+    # without the dropout copy
+    dg2, db2 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    got2 = ops.ffn_pc_bwd(dy, dres, _f1_tiles(f1, I), w2tf[0], w1tf[0], z1, gamma, m1, r1, None, dg2, db2, want_drop=False)
+    assert got2[3] is None and torch.equal(got2[2], dz1) and torch.equal(got2[0].rows(), df1)
+    # the weight-gradient GEMM on the block-column-major operands == on their row-major copies (both operand slots)
+    x1 = _rnd(T, H, seed=27).to(bf)
+    for A, B, Ar, Br in ((df1_b, x1, df1, x1), (dy, ga_b, dy, ga)):
+        n, kc = Ar.shape[1], Br.shape[1]
+        o0, o1 = torch.zeros(n, kc, device="cuda"), torch.zeros(n, kc, device="cuda")
+        c0, c1 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ops.gemm_tn_acc(Ar, Br, o0, colsum=c0)
+        ops.gemm_tn_acc(A, B, o1, colsum=c1)
+        assert fro(o1, o0) <= 1e-5 and fro(c1, c0) <= 1e-5, (fro(o1, o0), fro(c1, c0))
+
+
+@pytest.mark.gpu
+def test_encoder_with_the_fused_ffn_backward_matches_the_two_launch_backward(monkeypatch):
+    """the whole encoder, dropout on: SM_PC_FFN_BWD=1 (default) against 0 -- same forward, same masks, gradients within the bf16
+    bound of two differently-ordered bf16 evaluations"""
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    cfg = BertConfigLite(vocab_size=3000, hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1536,
+                         max_position_embeddings=128, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1000, 3000, (12, 64), generator=g)
+    mask = torch.ones(12, 64, dtype=torch.long)
+    mask[3, 40:] = 0
+    mask[7, 17:] = 0
+    up = torch.randn(12, 3000, generator=g).cuda() * 1e-2
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SM_PC_FFN_BWD", mode)
+        bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=3)
+        assert bb.pc_ffn and bb.pc_ffn_bwd == (mode == "1")
+        bb.train()
+        bb.set_dropout_seed(99)
+        rep = bb.encode(ids.cuda(), mask.cuda())
+        (rep * up).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (rep.detach().clone(), bb.flat_grad.clone())
+    assert torch.equal(res["1"][0], res["0"][0]), "the forward is the same launch sequence"
+    assert torch.isfinite(res["1"][1]).all()
+    rel = float((res["1"][1] - res["0"][1]).norm() / res["0"][1].norm())
+    print(f"[fused vs two-launch FFN backward] flat gradient rel Frobenius {rel:.2e}")
+    assert rel <= 2e-2, rel
