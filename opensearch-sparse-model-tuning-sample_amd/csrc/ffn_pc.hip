@@ -142,6 +142,7 @@ template <int N> __device__ __forceinline__ float pc_lanes_sum(float v) {  // su
   for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+constexpr int PC_NPART = 16;  // copies of the backward's gamma / beta column sums (sm_ffn_pc_bwd's `partials`)
 constexpr int PC_EROW = 192 * 4 + 16;  // epilogue staging: row stride of a [128 rows][192 columns] fp32 half tile (bank-spreading pad)
 
 template <bool F16, bool SAVE_F1>
@@ -631,7 +632,7 @@ struct FfnPcBwdArgs {
   const float *ln1_g, *m1, *r1;
   DropCfg drop;         // attention-output dropout (applied to dz1 for dz1d)
   bf16 *df1, *ga;       // [ceil(T / 128) * 128, I] out, block-column-major (see the producer)
-  float* partials;      // [gridDim.x][2][384] fp32 scratch: the workgroups' gamma / beta column sums (NULL: float atomics on dgamma / dbeta)
+  float* partials;      // [PC_NPART][2][384] fp32 scratch, zeroed: copies of the gamma / beta column sums (NULL: float atomics on dgamma / dbeta)
   bf16 *dz1, *dz1d;     // [T, H] out (dz1d may be NULL)
   float *dgamma, *dbeta;
   int T, I;
@@ -764,8 +765,9 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
     for (int c = tid; c < 2 * PC_H; c += 512) {
       float v;
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
-      // (768 addresses shared by every workgroup: 256 workgroups' atomics on them took 27 k cycles per workgroup)
-      if (a.partials) a.partials[(size_t)blockIdx.x * (2 * PC_H) + c] = v;
+      // (768 addresses shared by every workgroup: 256 workgroups' atomics on them took 27 k cycles per workgroup; PC_NPART copies
+      //  of the 768 sums, a workgroup adds into copy blockIdx.x % PC_NPART, a second small launch folds the copies)
+      if (a.partials) atomicAdd(a.partials + (size_t)(blockIdx.x % PC_NPART) * (2 * PC_H) + c, v);
       else atomicAdd(c < PC_H ? a.dgamma + c : a.dbeta + (c - PC_H), v);
     }
     PC_STAMP(w >> 2, 7);
@@ -1009,21 +1011,18 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
   ln_rows();
 }
 
-// dgamma / dbeta += the workgroups' column sums (partials [nblk][2][384])
-__global__ __launch_bounds__(256) void ffn_pc_colsum_reduce_kernel(const float* __restrict__ partials, int nblk, float* __restrict__ dgamma,
+// dgamma / dbeta += the PC_NPART copies of the workgroups' column sums (partials [PC_NPART][2][384])
+__global__ __launch_bounds__(256) void ffn_pc_colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= 2 * PC_H) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += partials[(size_t)b * (2 * PC_H) + c];
-    s1 += partials[(size_t)(b + 1) * (2 * PC_H) + c];
-    s2 += partials[(size_t)(b + 2) * (2 * PC_H) + c];
-    s3 += partials[(size_t)(b + 3) * (2 * PC_H) + c];
-  }
-  for (; b < nblk; ++b) s0 += partials[(size_t)b * (2 * PC_H) + c];
-  atomicAdd(c < PC_H ? dgamma + c : dbeta + (c - PC_H), (s0 + s1) + (s2 + s3));
+  float v[PC_NPART];
+#pragma unroll
+  for (int b = 0; b < PC_NPART; ++b) v[b] = partials[(size_t)b * (2 * PC_H) + c];
+  float s0 = 0.f;
+#pragma unroll
+  for (int b = 0; b < PC_NPART; ++b) s0 += v[b];
+  atomicAdd(c < PC_H ? dgamma + c : dbeta + (c - PC_H), s0);
 }
 
 // ---- fragment-major weight staging for the kernels above (one launch for all layers: the layers of the flat parameter buffer
@@ -1115,10 +1114,11 @@ extern "C" int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, c
   hipStream_t st = (hipStream_t)stream;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_pc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
   const int blocks = sm_cdiv(T, PC_TOK);
+  if (partials) SM_HIP_CHECK(hipMemsetAsync(partials, 0, (size_t)PC_NPART * 2 * PC_H * sizeof(float), st));
   hipLaunchKernelGGL(ffn_pc_bwd_kernel, dim3(blocks), dim3(512), PC_LDS, st, a);
   SM_LAUNCH_CHECK();
   if (partials) {
-    hipLaunchKernelGGL(ffn_pc_colsum_reduce_kernel, dim3(3), dim3(256), 0, st, partials, blocks, dgamma, dbeta);
+    hipLaunchKernelGGL(ffn_pc_colsum_reduce_kernel, dim3(3), dim3(256), 0, st, partials, dgamma, dbeta);
     SM_LAUNCH_CHECK();
   }
   return SM_OK;

@@ -177,7 +177,7 @@ def ffn_pc_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2tf: Tensor, w1t
         return None
     nblk = (T + 127) // 128  # the kernel stores whole 128-row blocks (its stores are unconditional)
     df1, ga = (Bcm(_new((4 * nblk, I // 8, 32, 8), torch.bfloat16, dy), T, I) for _ in range(2))
-    partials = _new((nblk, 2 * H), torch.float32, dy)
+    partials = _new((16, 2 * H), torch.float32, dy)
     dz1 = torch.empty_like(dy)
     dz1d = torch.empty_like(dy) if want_drop else None
     ok = L.call_optional("sm_ffn_pc_bwd", L.ptr(dy), L.ptr(dres), L.ptr(f1), L.ptr(w2tf), L.ptr(w1tf), L.ptr(z1), L.ptr(ln1_g), L.ptr(m1),
