@@ -11,31 +11,45 @@ namespace {
 
 template <typename T> __device__ __forceinline__ float fp8_in(const T* p, long i) { return to_f32<T>(p[i]); }
 
+// running maximum of |v| that REMEMBERS a NaN / Inf: fmaxf drops a NaN operand, so a tensor that went non-finite would be
+// quantised against the maximum of its finite part and come out finite (saturated) -- the non-finite value laundered away.  A
+// non-finite element makes the maximum NaN (as a bit pattern it orders above every finite float: atomicMax keeps it), the
+// scale derived from it is NaN and the GEMM that multiplies by the scale returns NaN: the failure surfaces where it happened.
+__device__ __forceinline__ void amax_acc(float& m, bool& bad, float v) {
+  const float a = fabsf(v);
+  bad = bad || !(a <= 3.4028234e38f);
+  m = fmaxf(m, a);
+}
+__device__ __forceinline__ float amax_final(float m, bool bad) { return bad ? __uint_as_float(0x7FC00000u) : m; }
+__device__ __forceinline__ float amax_join(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7FC00000u) : fmaxf(a, b); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long n, float* __restrict__ amax) {
   float m = 0.f;
+  bool bad = false;
   const long n8 = n / 8;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n8; v += (long)gridDim.x * 256) {
     if constexpr (sizeof(T) == 2) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + v * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf((float)a[k]));
+      for (int k = 0; k < 8; ++k) amax_acc(m, bad, (float)a[k]);
     } else {
       const f32x4 a = *reinterpret_cast<const f32x4*>(x + v * 8), b = *reinterpret_cast<const f32x4*>(x + v * 8 + 4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(fabsf(a[k]), fabsf(b[k])));
+      for (int k = 0; k < 4; ++k) { amax_acc(m, bad, a[k]); amax_acc(m, bad, b[k]); }
     }
   }
   if (blockIdx.x == 0)
-    for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(fp8_in<T>(x, i)));
+    for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) amax_acc(m, bad, fp8_in<T>(x, i));
+  m = amax_final(m, bad);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  for (int o = 32; o > 0; o >>= 1) m = amax_join(m, __shfl_xor(m, o));
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    // non-negative floats order like their bit patterns
+    m = amax_join(amax_join(wm[0], wm[1]), amax_join(wm[2], wm[3]));
+    // non-negative floats order like their bit patterns (and the NaN pattern above all of them)
     atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
   }
 }
@@ -54,15 +68,19 @@ template <bool E5M2> __device__ __forceinline__ uint32_t pack4(float a, float b,
 }
 
 // amax_next != NULL (delayed scaling): the scale comes from an EARLIER pass over this tensor site (*amax, e.g. the previous training
-// step's maximum) and this pass records the tensor's own maximum into *amax_next for the next one -- one pass over x instead of two;
-// values past the stale maximum saturate.
+// step's maximum) and this pass records the tensor's own maximum into *amax_next for the next one -- one pass over x instead of two.
+// The stale maximum is taken with a MARGIN of 2 (the format is floating point: one binade of head room costs no precision, only
+// the lowest subnormal binade): a tensor may double from one step to the next before values saturate.  A NaN maximum (a
+// non-finite element in the pass that measured it) gives a NaN scale: the GEMM returns NaN instead of a laundered finite value.
 template <typename T, bool E5M2>
 __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, long n, const float* __restrict__ amax,
                                                        uint8_t* __restrict__ q, float* __restrict__ scale, float* __restrict__ amax_next) {
   constexpr float FMAX = E5M2 ? 57344.f : 448.f;
-  const float am = fmaxf(*amax, 1e-30f);
+  const float a0 = *amax;
+  const float am = a0 != a0 ? a0 : fmaxf(a0, 1e-30f) * (amax_next != nullptr ? 2.0f : 1.0f);
   const float mul = FMAX / am;
   float seen = 0.f;
+  bool bad = false;
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale = am / FMAX;  // dequantisation scale: x ~ q * scale
   const long n8 = n / 8;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n8; v += (long)gridDim.x * 256) {
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
       for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) seen = fmaxf(seen, fabsf(f[k]));
+    for (int k = 0; k < 8; ++k) amax_acc(seen, bad, f[k]);
     // (|x| <= amax, so |x * mul| <= FMAX up to one rounding: the clamp keeps the conversion away from its overflow encoding)
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(f[k] * mul, -FMAX), FMAX);
@@ -89,18 +107,19 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
   if (blockIdx.x == 0)
     for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) {
       const float v = fp8_in<T>(x, i);
-      seen = fmaxf(seen, fabsf(v));
+      amax_acc(seen, bad, v);
       const float f = fminf(fmaxf(v * mul, -FMAX), FMAX);
       q[i] = (uint8_t)(pack4<E5M2>(f, 0.f, 0.f, 0.f) & 0xff);
     }
   if (amax_next != nullptr) {  // (uniform)
+    seen = amax_final(seen, bad);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) seen = fmaxf(seen, __shfl_xor(seen, o));
+    for (int o = 32; o > 0; o >>= 1) seen = amax_join(seen, __shfl_xor(seen, o));
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = seen;
     __syncthreads();
     if (threadIdx.x == 0)
-      atomicMax(reinterpret_cast<unsigned int*>(amax_next), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+      atomicMax(reinterpret_cast<unsigned int*>(amax_next), __float_as_uint(amax_join(amax_join(wm[0], wm[1]), amax_join(wm[2], wm[3]))));
   }
 }
 

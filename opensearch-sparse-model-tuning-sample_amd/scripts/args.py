@@ -63,6 +63,13 @@ class ModelArguments:
     # extension: fp8 operands (e4m3 forward / e5m2 gradient, per-tensor scales) for the encoder linears of a bf16 run -- what
     # BASELINE configs[4] names "fp8 MFMA"; None = the SM_FP8 environment switch (default off)
     fp8: Optional[bool] = None
+    # extensions: the two default-on numerics choices of a bf16 run that differ from the reference's arithmetic -- the fused
+    # feed-forward block (a fitted sigmoid-form GELU, |err| <= 2.6e-5, instead of the exact-erf one; hidden size 384 only) and fp16
+    # FORWARD operands for the head / feed-forward GEMMs (11 significant bits instead of bf16's 8; values beyond 65504 would
+    # overflow: LayerNorm outputs and GELU values of a BERT are orders of magnitude below).  false = the bf16 / exact-erf launches;
+    # None = on (or the SM_PC_FFN / SM_FWD_F16 environment switches).  Both are logged at start-up.
+    fused_ffn: Optional[bool] = None
+    fwd_f16: Optional[bool] = None
 
     def __post_init__(self):
         if self.tokenizer_name is None:

@@ -182,7 +182,8 @@ class HipBertMLM(torch.nn.Module):
 
     def __init__(self, cfg: BertConfigLite, compute_dtype: torch.dtype = torch.bfloat16,
                  device: Optional[torch.device] = None, init_seed: Optional[int] = 0, with_head: bool = True,
-                 residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None):
+                 residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None, fused_ffn: Optional[bool] = None,
+                 fwd_f16: Optional[bool] = None):
         super().__init__()
         self.config = cfg
         self.compute_dtype = compute_dtype
@@ -198,9 +199,12 @@ class HipBertMLM(torch.nn.Module):
         # residual stream at hidden size 384; the backward stays unfused and reads the kernel's tile-major f1 in the dF1 epilogue.
         # ffn_f16: its operands are fp16 instead of bf16 (same MFMA rate, three more mantissa bits; gradients stay bf16).
         # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_fused_gpu.py).
+        # Both numerics-relevant defaults are constructor arguments (ModelArguments.fused_ffn / fwd_f16, logged at start-up); the
+        # environment switches remain for A/B runs and are overridden by an explicit argument.
         self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
+        want_pc = (os.environ.get("SM_PC_FFN", "1") == "1") if fused_ffn is None else bool(fused_ffn)
         self.pc_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
-                       and cfg.intermediate_size >= 128 and os.environ.get("SM_PC_FFN", "1") == "1")
+                       and cfg.intermediate_size >= 128 and want_pc)
         # ... and its BACKWARD in the same form (one launch for the dF1 GEMM + the GEMM fused with the LayerNorm-1 backward: dF1 is
         # consumed on the chip by the second GEMM instead of being read back); SM_PC_FFN_BWD=0 keeps the two launches
         self.pc_ffn_bwd = self.pc_ffn and os.environ.get("SM_PC_FFN_BWD", "1") == "1"
@@ -211,7 +215,8 @@ class HipBertMLM(torch.nn.Module):
         # ffn_fwd_f16: also the feed-forward GEMMs -- by default for deep models only (>= 10 layers: 12-layer bert-base is outside
         # 1e-2 without it, the 6-layer model is inside), because the backward then has to re-create gelu(f1) in bf16 (one more
         # [T, I] write).  SM_FWD_F16=0 / SM_FFN_FWD_F16=0|1 override.
-        self.fwd_f16 = compute_dtype == torch.bfloat16 and self.residual_fp32 and os.environ.get("SM_FWD_F16", "1") != "0"
+        want_f16 = (os.environ.get("SM_FWD_F16", "1") != "0") if fwd_f16 is None else bool(fwd_f16)
+        self.fwd_f16 = compute_dtype == torch.bfloat16 and self.residual_fp32 and want_f16
         deep = cfg.num_hidden_layers >= 10
         # fp8: the four encoder linears of every layer (QKV, attention output, FFN up / down) take fp8 operands -- e4m3 x e4m3 forward,
         # e5m2 x e4m3 for their input gradients, per-tensor just-in-time scales (csrc/fp8.hip) -- as BASELINE configs[4] asks
@@ -322,9 +327,11 @@ class HipBertMLM(torch.nn.Module):
 
     @classmethod
     def from_pretrained(cls, model_dir: str, compute_dtype=torch.bfloat16, device=None, with_head=True,
-                        residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None) -> "HipBertMLM":
+                        residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None, fused_ffn: Optional[bool] = None,
+                        fwd_f16: Optional[bool] = None) -> "HipBertMLM":
         cfg = BertConfigLite.from_json(os.path.join(model_dir, "config.json"))
-        model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head, residual_fp32=residual_fp32, fp8=fp8)
+        model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head, residual_fp32=residual_fp32, fp8=fp8,
+                    fused_ffn=fused_ffn, fwd_f16=fwd_f16)
         st = os.path.join(model_dir, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file

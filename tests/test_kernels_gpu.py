@@ -716,12 +716,25 @@ def test_quantize_fp8_matches_the_torch_conversion(ops, dtype, e5m2):
         assert float(amax) == 17.5 and abs(float(scale) - 17.5 / fmax) < 1e-9
         ref = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(17.5))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
         assert torch.equal(q.cpu().view(torch.uint8), ref.view(torch.uint8))
-        # delayed scaling: scale from a given (stale, here smaller) maximum, values past it saturate; this pass's maximum is recorded
+        # delayed scaling: scale from a given (stale, here smaller) maximum taken with a margin of 2 (a tensor may double from one
+        # step to the next), values past it saturate; this pass's maximum is recorded
         stale, nxt = torch.full((1,), 4.0, device="cuda"), torch.zeros(1, device="cuda")
         q2, scale2, _ = ops.quantize_fp8(x, e5m2=e5m2, amax=stale, amax_next=nxt)
-        assert float(nxt) == 17.5 and abs(float(scale2) - 4.0 / fmax) < 1e-9
-        ref2 = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(4.0))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
+        assert float(nxt) == 17.5 and abs(float(scale2) - 8.0 / fmax) < 1e-9
+        ref2 = (x.float().cpu() * (torch.tensor(fmax) / torch.tensor(8.0))).clamp(-fmax, fmax).to(torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn)
         assert torch.equal(q2.cpu().view(torch.uint8), ref2.view(torch.uint8))
+    # a non-finite element is NOT laundered into a finite value: the measured maximum is NaN, the scale derived from it is NaN (the GEMM
+    # multiplies by the scale), and under delayed scaling the recorded maximum is NaN so the NEXT step's scale is
+    for poison in (float("nan"), float("inf")):
+        x = (torch.randn(4099, device="cuda", generator=g) * 3).to(dtype)
+        x[1234] = poison
+        q, scale, amax = ops.quantize_fp8(x, e5m2=e5m2)
+        assert float(amax) != float(amax) and float(scale) != float(scale)
+        nxt = torch.zeros(1, device="cuda")
+        ops.quantize_fp8(x, e5m2=e5m2, amax=torch.full((1,), 4.0, device="cuda"), amax_next=nxt)
+        assert float(nxt) != float(nxt)
+        _, scale3, _ = ops.quantize_fp8(torch.ones(64, device="cuda", dtype=dtype), e5m2=e5m2, amax=nxt, amax_next=torch.zeros(1, device="cuda"))
+        assert float(scale3) != float(scale3)
 
 
 @pytest.mark.gpu
