@@ -741,12 +741,10 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
       }
     }
     PC_STAMP(w >> 2, 5);
-    // gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, ONE global atomic per column and workgroup
-    const uint32_t colsum = lds0 + 128 * 768;  // [2][384] fp32 behind the image
+    // gamma / beta gradients: the wave's 4 row groups by shuffles, then every wave WRITES its 768 sums into its own slot behind the
+    // image (plain stores: 6 144 LDS float atomics on 768 addresses took ~20 k cycles), one barrier, 512 threads fold the 8 slots
+    const uint32_t colsum = lds0 + 128 * 768;  // [8 waves][2][384] fp32 behind the image
     __builtin_amdgcn_s_barrier();  // every wave has read its image rows
-    for (int c = tid; c < 2 * PC_H; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -754,17 +752,27 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
         float x = dg[u][q], y = db[u][q];
         x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
         y += __shfl_xor(y, 16, 64); y += __shfl_xor(y, 32, 64);
-        if (sub == 0) {
-          const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
-          asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(x) : "memory");
-          asm volatile("ds_add_f32 %0, %1" ::"v"(ca + PC_H * 4), "v"(y) : "memory");
-        }
+        dg[u][q] = x;
+        db[u][q] = y;
       }
+    if (sub == 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const uint32_t ca = colsum + (uint32_t)(w * (2 * PC_H) + (sl + 16 * u) * 8) * 4;
+        pc_lds_write<f32x4>(ca, f32x4{dg[u][0], dg[u][1], dg[u][2], dg[u][3]});
+        pc_lds_write<f32x4>(ca + 16, f32x4{dg[u][4], dg[u][5], dg[u][6], dg[u][7]});
+        pc_lds_write<f32x4>(ca + PC_H * 4, f32x4{db[u][0], db[u][1], db[u][2], db[u][3]});
+        pc_lds_write<f32x4>(ca + PC_H * 4 + 16, f32x4{db[u][4], db[u][5], db[u][6], db[u][7]});
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int c = tid; c < 2 * PC_H; c += 512) {
-      float v;
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
+      float p8[8];
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) asm volatile("ds_read_b32 %0, %1" : "=v"(p8[ww]) : "v"(colsum + (uint32_t)(ww * (2 * PC_H) + c) * 4) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p8[0]), "+v"(p8[1]), "+v"(p8[2]), "+v"(p8[3]), "+v"(p8[4]), "+v"(p8[5]), "+v"(p8[6]), "+v"(p8[7]) : : "memory");
+      const float v = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
       // (768 addresses shared by every workgroup: 256 workgroups' atomics on them took 27 k cycles per workgroup; PC_NPART copies
       //  of the 768 sums, a workgroup adds into copy blockIdx.x % PC_NPART, a second small launch folds the copies)
       if (a.partials) atomicAdd(a.partials + (size_t)(blockIdx.x % PC_NPART) * (2 * PC_H) + c, v);

@@ -1416,12 +1416,12 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
       }
     }
   }
-  // (3) gamma / beta gradients: the wave's 4 row groups by shuffles, the 8 waves through LDS adds, then ONE global
-  //     atomic per column and workgroup (768 hot addresses shared by every workgroup: per-wave atomics cost 4 ms)
-  const uint32_t colsum = sbase + NB_LDS;  // [2][384] fp32 behind the dy image
-  for (int c = tid; c < 2 * NB_C; c += 512) asm volatile("ds_write_b32 %0, %1" ::"v"(colsum + c * 4), "v"(0.f) : "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  // (3) gamma / beta gradients: the wave's 4 row groups by shuffles, then every wave WRITES its 768 sums into its own slot of the
+  //     (now idle) image -- plain 16-byte stores; the 6 144 LDS float atomics on 768 addresses this replaces took ~20 k cycles
+  //     (tools/ffn_pc_bwd_stamps.py: the same pattern in ffn_pc_bwd_kernel) -- one barrier, 512 threads fold the 8 slots, then ONE
+  //     global atomic per column and workgroup (768 hot addresses shared by every workgroup: per-wave atomics cost 4 ms)
+  const uint32_t colsum = sbase;  // [8 waves][2][384] fp32 over the image
+  __builtin_amdgcn_s_barrier();   // every wave has read its image rows
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -1429,17 +1429,27 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
       float a = dg[u][q], b = db[u][q];
       a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (sub == 0) {
-        const uint32_t ca = colsum + ((sl + 16 * u) * 8 + q) * 4;
-        asm volatile("ds_add_f32 %0, %1" ::"v"(ca), "v"(a) : "memory");
-        asm volatile("ds_add_f32 %0, %1" ::"v"(ca + NB_C * 4), "v"(b) : "memory");
-      }
+      dg[u][q] = a;
+      db[u][q] = b;
     }
+  if (sub == 0) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const uint32_t ca = colsum + (uint32_t)(w * (2 * NB_C) + (sl + 16 * u) * 8) * 4;
+      lds_w128f(ca, f32x4{dg[u][0], dg[u][1], dg[u][2], dg[u][3]});
+      lds_w128f(ca + 16, f32x4{dg[u][4], dg[u][5], dg[u][6], dg[u][7]});
+      lds_w128f(ca + NB_C * 4, f32x4{db[u][0], db[u][1], db[u][2], db[u][3]});
+      lds_w128f(ca + NB_C * 4 + 16, f32x4{db[u][4], db[u][5], db[u][6], db[u][7]});
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int c = tid; c < 2 * NB_C; c += 512) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(colsum + c * 4) : "memory");
+    float p8[8];
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) asm volatile("ds_read_b32 %0, %1" : "=v"(p8[ww]) : "v"(colsum + (uint32_t)(ww * (2 * NB_C) + c) * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p8[0]), "+v"(p8[1]), "+v"(p8[2]), "+v"(p8[3]), "+v"(p8[4]), "+v"(p8[5]), "+v"(p8[6]), "+v"(p8[7]) : : "memory");
+    const float v = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     atomicAdd(c < NB_C ? ln.dgamma + c : ln.dbeta + (c - NB_C), v);
   }
 }
