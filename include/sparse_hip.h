@@ -167,13 +167,11 @@ int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, const float* 
  * weight-gradient GEMMs (dF1 is not read back: the second GEMM consumes it on the chip);  dx1 = dF1 W1 + dres;
  * dz1 = LN'(dx1 | z1, ln1_g, m1, r1), dz1d = dropout_bwd(dz1; drop) (NULL: not wanted); dgamma / dbeta accumulated (atomics).
  * The dF1 / ga buffers must hold WHOLE 128-row blocks (ceil(T / 128) * 128 rows): the kernel stores the rows past T as well.
- * partials: NULL, or 16 * 768 floats of scratch (zeroed by the call) -- 16 copies of the gamma / beta column sums, a workgroup
- * adds into one of them and a second small launch folds them, instead of every workgroup's float atomics on 768 shared addresses.
  * dy = the gradient w.r.t. the block's output behind its dropout backward, dres (may be NULL) the residual branch's;
  * f1 = the tile-major tensor of sm_ffn_pc_fwd; w2tf / w1tf = one layer's slices of sm_ffn_pc_stage. */
 int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, const void* w2tf, const void* w1tf, const float* z1,
                   const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
-                  void* dz1d, float* dgamma, float* dbeta, float* partials, int T, int H, int I, void* stream);
+                  void* dz1d, float* dgamma, float* dbeta, int T, int H, int I, void* stream);
 
 /* ---- LayerNorm (hf:106, :293, :351, :479) ---------------------------------------- */
 int sm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,

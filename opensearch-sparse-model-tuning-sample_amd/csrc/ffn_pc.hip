@@ -142,7 +142,6 @@ template <int N> __device__ __forceinline__ float pc_lanes_sum(float v) {  // su
   for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-constexpr int PC_NPART = 16;  // copies of the backward's gamma / beta column sums (sm_ffn_pc_bwd's `partials`)
 constexpr int PC_EROW = 192 * 4 + 16;  // epilogue staging: row stride of a [128 rows][192 columns] fp32 half tile (bank-spreading pad)
 
 template <bool F16, bool SAVE_F1>
@@ -632,7 +631,6 @@ struct FfnPcBwdArgs {
   const float *ln1_g, *m1, *r1;
   DropCfg drop;         // attention-output dropout (applied to dz1 for dz1d)
   bf16 *df1, *ga;       // [ceil(T / 128) * 128, I] out, block-column-major (see the producer)
-  float* partials;      // [PC_NPART][2][384] fp32 scratch, zeroed: copies of the gamma / beta column sums (NULL: float atomics on dgamma / dbeta)
   bf16 *dz1, *dz1d;     // [T, H] out (dz1d may be NULL)
   float *dgamma, *dbeta;
   int T, I;
@@ -773,10 +771,9 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
       for (int ww = 0; ww < 8; ++ww) asm volatile("ds_read_b32 %0, %1" : "=v"(p8[ww]) : "v"(colsum + (uint32_t)(ww * (2 * PC_H) + c) * 4) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p8[0]), "+v"(p8[1]), "+v"(p8[2]), "+v"(p8[3]), "+v"(p8[4]), "+v"(p8[5]), "+v"(p8[6]), "+v"(p8[7]) : : "memory");
       const float v = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
-      // (768 addresses shared by every workgroup: 256 workgroups' atomics on them took 27 k cycles per workgroup; PC_NPART copies
-      //  of the 768 sums, a workgroup adds into copy blockIdx.x % PC_NPART, a second small launch folds the copies)
-      if (a.partials) atomicAdd(a.partials + (size_t)(blockIdx.x % PC_NPART) * (2 * PC_H) + c, v);
-      else atomicAdd(c < PC_H ? a.dgamma + c : a.dbeta + (c - PC_H), v);
+      // (768 addresses shared by every workgroup.  Sixteen scratch copies of the sums + a fold launch were built and measured:
+      //  the stamped workgroup's tail went from 27 k to 10 k cycles, the step did not move -- A/B 13.75 / 13.76 against 13.81 / 13.72 ms)
+      atomicAdd(c < PC_H ? a.dgamma + c : a.dbeta + (c - PC_H), v);
     }
     PC_STAMP(w >> 2, 7);
   };
@@ -1019,20 +1016,6 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
   ln_rows();
 }
 
-// dgamma / dbeta += the PC_NPART copies of the workgroups' column sums (partials [PC_NPART][2][384])
-__global__ __launch_bounds__(256) void ffn_pc_colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * PC_H) return;
-  float v[PC_NPART];
-#pragma unroll
-  for (int b = 0; b < PC_NPART; ++b) v[b] = partials[(size_t)b * (2 * PC_H) + c];
-  float s0 = 0.f;
-#pragma unroll
-  for (int b = 0; b < PC_NPART; ++b) s0 += v[b];
-  atomicAdd(c < PC_H ? dgamma + c : dbeta + (c - PC_H), s0);
-}
-
 // ---- fragment-major weight staging for the kernels above (one launch for all layers: the layers of the flat parameter buffer
 //      are equally spaced).  e = ((c * 24 + piece) * 64 + lane) * 8 + j, lane = (kg, r) = (lane >> 5, lane & 31)
 //   w1f  [L][I/32][24 ks][64][8]        W1[32 c + r][16 ks + 8 kg + j]                               (forward GEMM 1, operand type)
@@ -1109,7 +1092,7 @@ extern "C" int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, co
 
 extern "C" int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, const void* w2tf, const void* w1tf, const float* z1,
                              const float* ln1_g, const float* m1, const float* r1, const sm_dropout* drop, void* df1, void* ga, void* dz1,
-                             void* dz1d, float* dgamma, float* dbeta, float* partials, int T, int H, int I, void* stream) {
+                             void* dz1d, float* dgamma, float* dbeta, int T, int H, int I, void* stream) {
   if (H != PC_H || I % PC_IC != 0 || I < 4 * PC_IC || T % 16 != 0 || T <= 0 || (long)T * I * 2 >= (1L << 32)) return 1;
   SM_REQUIRE(dy && f1 && w2tf && w1tf && z1 && ln1_g && m1 && r1 && df1 && ga && dz1 && dgamma && dbeta, "sm_ffn_pc_bwd: null argument");
   const uintptr_t al = (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)f1 | (uintptr_t)w2tf | (uintptr_t)w1tf | (uintptr_t)z1 | (uintptr_t)ln1_g |
@@ -1118,17 +1101,12 @@ extern "C" int sm_ffn_pc_bwd(const void* dy, const void* dres, const void* f1, c
   FfnPcBwdArgs a;
   a.dy = (const bf16*)dy; a.dres = (const bf16*)dres; a.f1 = (const bf16*)f1; a.w2tf = w2tf; a.w1tf = w1tf; a.z1 = z1; a.ln1_g = ln1_g;
   a.m1 = m1; a.r1 = r1; a.drop = make_drop(drop); a.df1 = (bf16*)df1; a.ga = (bf16*)ga; a.dz1 = (bf16*)dz1; a.dz1d = (bf16*)dz1d;
-  a.dgamma = dgamma; a.dbeta = dbeta; a.partials = partials; a.T = T; a.I = I;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.T = T; a.I = I;
   hipStream_t st = (hipStream_t)stream;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)ffn_pc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
   const int blocks = sm_cdiv(T, PC_TOK);
-  if (partials) SM_HIP_CHECK(hipMemsetAsync(partials, 0, (size_t)PC_NPART * 2 * PC_H * sizeof(float), st));
   hipLaunchKernelGGL(ffn_pc_bwd_kernel, dim3(blocks), dim3(512), PC_LDS, st, a);
   SM_LAUNCH_CHECK();
-  if (partials) {
-    hipLaunchKernelGGL(ffn_pc_colsum_reduce_kernel, dim3(3), dim3(256), 0, st, partials, dgamma, dbeta);
-    SM_LAUNCH_CHECK();
-  }
   return SM_OK;
 }
 

@@ -65,7 +65,7 @@ SIGNATURES = {
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_ffn_pc_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],
     "sm_ffn_pc_fwd": [_i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "sm_ffn_pc_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "sm_ffn_pc_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_gemm_tn_acc_bcm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],

@@ -177,12 +177,11 @@ def ffn_pc_bwd(dy: Tensor, dres: Optional[Tensor], f1: Tensor, w2tf: Tensor, w1t
         return None
     nblk = (T + 127) // 128  # the kernel stores whole 128-row blocks (its stores are unconditional)
     df1, ga = (Bcm(_new((4 * nblk, I // 8, 32, 8), torch.bfloat16, dy), T, I) for _ in range(2))
-    partials = _new((16, 2 * H), torch.float32, dy)
     dz1 = torch.empty_like(dy)
     dz1d = torch.empty_like(dy) if want_drop else None
     ok = L.call_optional("sm_ffn_pc_bwd", L.ptr(dy), L.ptr(dres), L.ptr(f1), L.ptr(w2tf), L.ptr(w1tf), L.ptr(z1), L.ptr(ln1_g), L.ptr(m1),
                          L.ptr(r1), _drop_ref(drop), L.ptr(df1.buf), L.ptr(ga.buf), L.ptr(dz1), L.ptr(dz1d), L.ptr(dgamma), L.ptr(dbeta),
-                         L.ptr(partials), T, H, I, L.stream_ptr())
+                         T, H, I, L.stream_ptr())
     return (df1, ga, dz1, dz1d) if ok else None
 
 

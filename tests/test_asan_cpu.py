@@ -44,7 +44,7 @@ run("sm_gemm_tn_acc", L.SM_F32, P(10), 72, P(11), 136, P(12), 136, 300, 72, 136,
 run("sm_gemm_tn_acc_bcm", P(10), 1, P(11), 0, P(12), H, 43904, I, H, P(13), None)
 run("sm_ffn_pc_stage", 1, P(10), P(11), 1000000, 6, H, I, P(12), P(13), P(14), P(15), None)
 run("sm_ffn_pc_fwd", 1, P(10), P(11), P(12), 1e-12, P(13), P(14), P(15), P(16), P(17), P(18), C.byref(drop), P(19), P(20), P(21), P(22), P(23), P(24), P(25), P(26), 43904, H, I, None)
-run("sm_ffn_pc_bwd", P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), P(18), C.byref(drop), P(19), P(20), P(21), P(22), P(23), P(24), None, 43904, H, I, None)
+run("sm_ffn_pc_bwd", P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), P(18), C.byref(drop), P(19), P(20), P(21), P(22), P(23), P(24), 43904, H, I, None)
 run("sm_layernorm_fwd_res32", L.SM_BF16, P(10), P(11), P(12), P(13), None, P(14), P(15), T, H, 1e-12, P(16), None)
 run("sm_layernorm_bwd_res32", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), P(15), P(16), C.byref(drop), P(17), P(18), T, H, None)
 run("sm_embed_fwd_res32", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), P(18), P(19), P(20), 43904, 1, H, 1e-12, C.byref(drop), C.byref(rag), None)

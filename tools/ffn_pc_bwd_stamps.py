@@ -30,8 +30,7 @@ dz1, dz1d = torch.empty(T, H, dtype=bf, device="cuda"), torch.empty(T, H, dtype=
 dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
 drop = L.dropout(0.1, 5, 6)
 P = lambda t: C.c_void_p(L.ptr(t))
-partials = torch.empty(16, 768, device="cuda")
-args = [P(dy), P(dres), P(f1), P(w2tf), P(w1tf), P(z1), P(gamma), P(m1), P(r1), C.byref(drop), P(df1), P(ga), P(dz1), P(dz1d), P(dg), P(db), P(partials),
+args = [P(dy), P(dres), P(f1), P(w2tf), P(w1tf), P(z1), P(gamma), P(m1), P(r1), C.byref(drop), P(df1), P(ga), P(dz1), P(dz1d), P(dg), P(db),
         C.c_int(T), C.c_int(H), C.c_int(I), C.c_void_p(torch.cuda.current_stream().cuda_stream)]
 for _ in range(3):
     assert dbg.sm_ffn_pc_bwd(*args) == 0
