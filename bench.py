@@ -169,6 +169,8 @@ class GemmRoofline:
         self._wrap("gemm_tn_acc", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
         # the fused feed-forward forward (LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2): its two GEMMs' FLOPs
         self._wrap("ffn_pc_fwd", lambda z1, g1, b1, eps, w1f, bias1, *a, **k: 4.0 * z1.shape[0] * z1.shape[1] * bias1.shape[0])
+        # ... and its backward (dF1 GEMM + FFN-up input gradient, with GELU', the LayerNorm-1 backward and the residual gradient)
+        self._wrap("ffn_pc_bwd", lambda dy, dres, f1, *a, **k: 4.0 * dy.shape[0] * dy.shape[1] * f1.shape[1] * 32)
         return self
 
     def __exit__(self, *exc):
@@ -549,7 +551,7 @@ def main():
         fl = sum(g["gflop_per_step"] for g in gemm_lines)
         ms = sum(g["ms_per_step"] for g in gemm_lines)
         result["roofline"] = {"kernel": "encoder GEMMs, in-step (all launches of sm_gemm_nt / sm_gemm_nt_ln_bwd / sm_gemm_tn_acc / "
-                                        "sm_ffn_pc_fwd of one training step)",
+                                        "sm_ffn_pc_fwd / sm_ffn_pc_bwd of one training step)",
                               "bound": "mfma", "achieved": fl / ms, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / ms * 1e12 / peak,
                               "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines}
         if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":

@@ -9,7 +9,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "config", "roofline", "value_layout", "value_dense_layout", "value_ragged_layout"}
+            "dtype", "data", "config", "roofline", "value_layout", "value_dense_layout", "value_ragged_layout",
+            "loss_first", "loss_last", "finite"}  # (the last three: liveness of the timed region, GPUTEST_r03)
 
 
 def _run(cmd, env=None, timeout=240):
@@ -65,6 +66,7 @@ def test_bench_one_gpu_line():
     # the roofline object is the step's dominant kernel class, the encoder GEMMs in-step; the head forward rides beside it
     assert rf["kernel"].startswith("encoder GEMMs, in-step") and 0 < rf["one_queue"]["frac"] < 1 and len(rf["per_op"]) >= 3
     assert j["value_layout"] == "dense" and abs(j["value"] - j["value_dense_layout"]) < 1e-9
+    assert j["finite"] is True and j["loss_first"] == j["loss_first"] and j["loss_first"] != j["loss_last"]  # the timed region trained
     hd = j["roofline_head_fwd"]
     assert hd["bound"] == "mfma" and 0 < hd["frac"] < 1
 
@@ -80,4 +82,4 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
-    assert "cpu_baseline" not in j and j["value"] > 0
+    assert "cpu_baseline" not in j and j["value"] > 0 and j["finite"] is True
