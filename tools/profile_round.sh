@@ -5,7 +5,7 @@
 #   3. PMC passes (FETCH_SIZE, WRITE_SIZE, SQ set), each in its own run with --kernel-trace only
 #      -> gpurun_out/<tag>/pmc_traffic.json, pmc_mfma_util.txt
 # The caller copies what it wants judged into profiles/.
-tag=${1:-r3}; git=${2:-unknown}
+tag=${1:-r4}; git=${2:-${SM_GIT_REV:-unknown}}   # (the box has no .git: pass the revision, e.g. $(git rev-parse --short HEAD) expanded on the submitting side)
 out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 B="bench.py --steps 2 --warmup 1 --only-value-layout --no-cpu-baseline --no-gemm-roofline"
