@@ -27,6 +27,8 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver supports dmabuf IPC only: without it RCCL's
+                                                            # hipIpcGetMemHandle fails (multi-process GPU work)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it (multi-process GPU work)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
