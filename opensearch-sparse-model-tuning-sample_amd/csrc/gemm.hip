@@ -1054,20 +1054,6 @@ __device__ __forceinline__ void wait_vm_dyn4(int younger) {
   }
 }
 
-// (the same for stages of 2 loads each)
-__device__ __forceinline__ void wait_vm_dyn2(int younger) {
-  switch (younger) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<2>(); break;
-    case 2: wait_vm<4>(); break;
-    case 3: wait_vm<6>(); break;
-    case 4: wait_vm<8>(); break;
-    case 5: wait_vm<10>(); break;
-    case 6: wait_vm<12>(); break;
-    default: wait_vm<14>(); break;
-  }
-}
-
 // Transposing LDS read issued as inline assembly.  The compiler's wait-count pass makes every LDS read
 // it knows about wait for ALL outstanding LDS-DMA loads (vmcnt(0)) -- it cannot tell which ring stage a
 // read touches -- which would drain the ring at every stage; reads it cannot see leave the counted
@@ -1119,10 +1105,8 @@ __device__ __forceinline__ void tg_wait_all(TgFrag (&fa)[4], TgFrag (&fb)[4]) {
 
 __device__ uint4 g_tn_zero16;  // zero-initialised: source of LDS-DMA lanes whose token row is past the end
 
-// NLD = loader waves: 4 (two pieces of each panel per wave and stage) or 8 (one piece each: tools/lds_dma_probe.py measured 21-31 B/clk
-// per CU with four waves issuing LDS-DMA and 35-46 with eight)
-template <int TG_NST, int NLD = 4>
-__global__ __launch_bounds__(256 + 64 * NLD) void gemm_tn_pc_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+template <int TG_NST>
+__global__ __launch_bounds__(512) void gemm_tn_pc_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                          float* __restrict__ C, int ldc, int M, int N, int Kc, int rows_per_split,
                                                          float* __restrict__ colsum, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1146,12 +1130,11 @@ __global__ __launch_bounds__(256 + 64 * NLD) void gemm_tn_pc_kernel(const bf16* 
   if (w8 >= 4) {
     // ---------------- loader waves ----------------
     const int w = w8 - 4;
-    constexpr int PPW = 8 / NLD;  // pieces of each panel per loader wave and stage
-    size_t aoff[PPW], boff[PPW];
-    int lrow[PPW];
+    size_t aoff[2], boff[2];
+    int lrow[2];
 #pragma unroll
-    for (int p = 0; p < PPW; ++p) {
-      const int row = (w * PPW + p) * 4 + (lane >> 4);
+    for (int p = 0; p < 2; ++p) {
+      const int row = (w * 2 + p) * 4 + (lane >> 4);
       const int cphys = lane & 15;
       const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
       lrow[p] = mbeg + row;
@@ -1160,10 +1143,10 @@ __global__ __launch_bounds__(256 + 64 * NLD) void gemm_tn_pc_kernel(const bf16* 
     }
     const bf16* const zsrc = reinterpret_cast<const bf16*>(&g_tn_zero16);
     auto issue = [&](int st) {
-      char* da = sA + (st % TG_NST) * TG_STAGE + w * (PPW * 1024);
-      char* db = sB + (st % TG_NST) * TG_STAGE + w * (PPW * 1024);
+      char* da = sA + (st % TG_NST) * TG_STAGE + w * 2048;
+      char* db = sB + (st % TG_NST) * TG_STAGE + w * 2048;
 #pragma unroll
-      for (int p = 0; p < PPW; ++p) {
+      for (int p = 0; p < 2; ++p) {
         const bool in = lrow[p] + st * TG_BKM < mend;
         const bf16* pa = in ? A + aoff[p] + (size_t)st * astage : zsrc;
         const bf16* pb = in ? B + boff[p] + (size_t)st * bstage : zsrc;
@@ -1176,9 +1159,8 @@ __global__ __launch_bounds__(256 + 64 * NLD) void gemm_tn_pc_kernel(const bf16* 
       if (s < nst) issue(s);
     for (int st = 0; st < nst; ++st) {
       const int younger = min(TG_NST - 2, nst - 1 - st);
-      if (younger >= TG_NST - 2) wait_vm<2 * PPW * (TG_NST - 2)>();
-      else if constexpr (PPW == 2) wait_vm_dyn4(younger);
-      else wait_vm_dyn2(younger);
+      if (younger >= TG_NST - 2) wait_vm<4 * (TG_NST - 2)>();
+      else wait_vm_dyn4(younger);
       __builtin_amdgcn_s_barrier();  // stage st landed for everyone; the slot of stage st-1 is drained
       asm volatile("" ::: "memory");
       if (st + TG_NST - 1 < nst) issue(st + TG_NST - 1);
@@ -1758,12 +1740,8 @@ int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int
         hipLaunchKernelGGL(kern, dim3(nblocks(nsplit)), dim3(nthr), lds, st, (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, Kc,
                            rows_per_split, colsum, tn_xcd ? nsplit : -nsplit);
       };
-#ifndef SM_TN_LOADERS
-#define SM_TN_LOADERS 4
-#endif
       if (tn_glds >= 8) launch(gemm_tn_pc_kernel<8>, 8, 512);
       else if (tn_glds >= 6) launch(gemm_tn_pc_kernel<6>, 6, 512);
-      else if (SM_TN_LOADERS == 8) launch(gemm_tn_pc_kernel<4, 8>, 4, 768);
       else launch(gemm_tn_pc_kernel<4>, 4, 512);
       return 0;
     }
