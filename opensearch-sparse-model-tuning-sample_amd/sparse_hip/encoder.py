@@ -19,6 +19,7 @@ Memory layout in HBM
 """
 from __future__ import annotations
 
+import collections
 import json
 import math
 import os
@@ -262,6 +263,13 @@ class HipBertMLM(torch.nn.Module):
         self._weights_dirty = True
         self._drop_seed = 0x5EED
         self._invocation = 0
+        # Inference encodes (eval mode, no grad, dense layout) of at most graph_tokens padded tokens are launch-bound (about 45 launches
+        # of a few microseconds each): they replay one captured HIP graph per (documents, padded length) bucket.  SM_ENCODE_GRAPH=0
+        # switches it off; tools/encode_bench.py measures both.
+        self.pc_infer_min_rows = int(os.environ.get("SM_PC_INFER_MIN_ROWS", "6144"))
+        self.graph_encode = os.environ.get("SM_ENCODE_GRAPH", "1") == "1"
+        self.graph_tokens = int(os.environ.get("SM_ENCODE_GRAPH_TOKENS", "8192"))
+        self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
 
@@ -416,7 +424,8 @@ class HipBertMLM(torch.nn.Module):
             self._cast_key = (self.flat_param.data_ptr(), len(st))
         self._cast_table.run()
         if self.fwd_f16:  # fp16 copies of the forward operands (a second table: one launch per storage type)
-            key16 = (self.flat_param.data_ptr(), self.ffn_fwd_f16)
+            ffn16 = self.ffn_fwd_f16 or (self.pc_ffn and self.ffn_f16)  # (the second: small no-grad forwards, see _forward_impl)
+            key16 = (self.flat_param.data_ptr(), ffn16)
             if self._cast_table16 is None or self._cast_key16 != key16:
                 def buf16(k, shape):
                     if k not in st:
@@ -425,7 +434,7 @@ class HipBertMLM(torch.nn.Module):
                 vpad = (V + 127) // 128 * 128
                 ent = [(self.view("bert.embeddings.word_embeddings.weight"), buf16("E16", (vpad, H)), None),
                        (self.view("cls.predictions.transform.dense.weight"), buf16("t16", (H, H)), None)]
-                if self.ffn_fwd_f16:
+                if ffn16:
                     for l in range(cfg.num_hidden_layers):
                         p = f"bert.encoder.layer.{l}."
                         ent.append((self.view(p + "intermediate.dense.weight"), buf16(f"w1h{l}", (I, H)), None))
@@ -536,7 +545,10 @@ class HipBertMLM(torch.nn.Module):
             z1 = self._lin(ctx, f"o{l}", bias=v(p + "attention.output.dense.bias"), drop=d_h1, residual=x32 if r32 else x, out_f32=r32,
                              residual_ln=res_ln)
             fused = None
-            if self.pc_ffn and z1.shape[0] % 16 == 0:
+            # (a no-grad forward of fewer than pc_infer_min_rows token rows takes the unfused launches: one fused workgroup walks all
+            # of W1 / W2 for its 128 rows -- 69 us per layer however few rows there are -- where the plain GEMMs spread the columns
+            # over the chip: 397 us against 597 us for a single 32-token query, level at about 6 k rows; profiles/r4_encode_latency.txt)
+            if self.pc_ffn and z1.shape[0] % 16 == 0 and (save or z1.shape[0] >= self.pc_infer_min_rows):
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
                 g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
                 fused = ops.ffn_pc_fwd(z1, g1, b1, eps, st["pc_w1f"][l], v(p + "intermediate.dense.bias"), st["pc_w2f"][l],
@@ -550,7 +562,9 @@ class HipBertMLM(torch.nn.Module):
                     saved["layers"].append((x, qkv, ctx, lse, z1, m1, r1, x1, f1, None, z2, m2, r2))
                 x = x2
                 continue
-            f16_ffn = self.ffn_fwd_f16
+            # fp16 feed-forward operands: where the model asks for them, and in the small no-grad forwards that bypass the fused
+            # kernel above (whose operands are fp16 too: the precision of an inference does not depend on the batch size)
+            f16_ffn = self.ffn_fwd_f16 or (not save and self.pc_ffn and self.ffn_f16 and self.fwd_f16)
             x1h = None
             if r32:
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
@@ -609,9 +623,28 @@ class HipBertMLM(torch.nn.Module):
         rag = packed.rag if packed is not None else None
         need_grad = torch.is_grad_enabled()
         training = self.training and (need_grad or self._dropout_without_grad)
+        if (self.graph_encode and not need_grad and not training and rag is None and not self.fp8 and self._argmax_log is None
+                and B * S <= self.graph_tokens and not torch.cuda.is_current_stream_capturing()):
+            return self._encode_graphed(ids, mask, B, S, bool(use_l0), prune_ratio)
         self._invocation += 1
         seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._invocation) & 0xFFFFFFFFFFFFFFFF
         return _EncodeFn.apply(self._anchor, self, ids, mask, B, S, bool(use_l0), prune_ratio, training, seed, need_grad, rag, hints)
+
+    def _encode_graphed(self, ids: Tensor, mask: Tensor, B: int, S: int, use_l0: bool, prune_ratio) -> Tensor:
+        """Replay (capturing it on first use) the HIP graph of the no-grad forward for this (B, S) bucket.  The graph reads its
+        inputs from two static buffers and the weights from the staged copies, which sync_weights() refreshes in place -- so a graph
+        stays valid across optimiser steps, and is dropped only if the flat parameter buffer itself moves."""
+        self.sync_weights()  # outside the graph: a no-op unless the weights changed since the last call
+        key = (B, S, use_l0, prune_ratio, self.flat_param.data_ptr(), self.pc_infer_min_rows)
+        g = self._graphs.get(key)
+        if g is None:
+            g = _EncodeGraph(self, B, S, use_l0, prune_ratio)
+            self._graphs[key] = g
+            while len(self._graphs) > 16:  # every bucket keeps its activations: bound them
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        return g.run(ids, mask)
 
     def encode_cached(self, chunks: List[Tuple[Tensor, Tensor, Optional[PackedDocs]]], use_l0: bool = False,
                       prune_ratio: Optional[float] = None) -> Tensor:
@@ -730,6 +763,34 @@ class _WgradStream:
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return ev
+
+
+class _EncodeGraph:
+    """One captured HIP graph of the inference forward (embedding ... sparse head) for a fixed (documents, padded length)."""
+
+    def __init__(self, model: "HipBertMLM", B: int, S: int, use_l0: bool, prune_ratio):
+        dev = model.device
+        self.ids = torch.zeros((B, S), dtype=torch.int64, device=dev)
+        self.mask = torch.ones((B, S), dtype=torch.uint8, device=dev)
+
+        def forward():
+            return _EncodeFn.apply(model._anchor, model, self.ids, self.mask, B, S, use_l0, prune_ratio, False, 0, False, None, None)
+
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():  # one eager pass first: first-use work (attribute calls, staging) stays out of the capture
+            forward()
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.rep = forward()
+
+    def run(self, ids: Tensor, mask: Tensor) -> Tensor:
+        self.ids.copy_(ids)
+        self.mask.copy_(mask)
+        self.graph.replay()
+        return self.rep.clone()  # the graph's output buffer is overwritten by the next replay
 
 
 class _EncodeFn(torch.autograd.Function):

@@ -730,6 +730,60 @@ def test_inference_postprocessor_matches_reference_golden_and_oracle():
     assert int(enc.count_tensor[1:].sum()) == sum(len(d) for d in out)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_graphed_inference_encode_equals_the_eager_forward(dtype):
+    """small inference batches replay one captured HIP graph per (documents, padded length) bucket: same bits as the eager launches,
+    on new inputs, on a second bucket, and after the weights changed (the graph reads the staged copies, restaged in place)"""
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    cfg = BertConfigLite(vocab_size=30522, hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1536)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=3).eval()
+    assert bb.graph_encode
+    gen = torch.Generator().manual_seed(11)
+
+    def batch(B, S):
+        ids = torch.randint(1000, cfg.vocab_size, (B, S), generator=gen)
+        lens = torch.randint(3, S + 1, (B,), generator=gen)
+        mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+        return (ids * mask).cuda(), mask.cuda()
+
+    def both(ids, mask, **kw):
+        with torch.no_grad():
+            got = bb.encode(ids, mask, **kw)
+            bb.graph_encode = False
+            want = bb.encode(ids, mask, **kw)
+            bb.graph_encode = True
+        assert torch.equal(got, want), float((got - want).abs().max())
+        return got
+
+    a = both(*batch(8, 50))            # captures the (8, 64) bucket
+    b = both(*batch(8, 61))            # replays it on other documents
+    assert not torch.equal(a, b) and len(bb._graphs) == 1
+    both(*batch(5, 20))                # a second bucket
+    both(*batch(8, 64), use_l0=True)   # the activation is part of the key
+    assert len(bb._graphs) == 3
+    with torch.no_grad():              # an optimiser step's worth of change
+        bb.flat_param.mul_(1.01)
+    bb.mark_weights_dirty()
+    c = both(*batch(8, 50))
+    assert len(bb._graphs) == 3 and bool(torch.isfinite(c).all())
+    if dtype == torch.bfloat16:
+        # rows below pc_infer_min_rows take the unfused launches (fp16 feed-forward operands like the fused kernel's): same result
+        # within rounding as the fused kernel on the same batch
+        assert bb.pc_ffn and bb.pc_infer_min_rows > 8 * 64
+        ids, mask = batch(8, 50)
+        with torch.no_grad():
+            small = bb.encode(ids, mask)
+            bb.pc_infer_min_rows = 0
+            fused = bb.encode(ids, mask)  # (a new graph: the threshold is read at capture)
+        err = float(((small - fused).abs() / (1 + fused.abs())).max())
+        assert err <= 2e-3, err
+    # with grad enabled (or in training mode) the autograd path runs: nothing is captured
+    ids, mask = batch(8, 50)
+    n = len(bb._graphs)
+    rep = bb.encode(ids, mask)
+    assert rep.requires_grad and len(bb._graphs) == n
+
+
 def test_dense_layout_embedding_backward_with_host_sorted_rows():
     """dense [B, S] batches carry host-sorted row lists (DenseHints) so that the embedding backward sums runs of equal token ids
     instead of scattering one atomic row per token row: same gradients as the scatter kernel (bf16 rows, fp32 sums: the order of

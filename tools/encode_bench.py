@@ -19,6 +19,20 @@ with torch.no_grad():
     for _ in range(10): rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print(f"forward (no grad), 512 docs x seq 128: {dt*1e3:.2f} ms = {512/dt:.0f} docs/s")
+# small batches are launch-bound: one captured HIP graph per (documents, padded length) bucket against the eager launches
+for nb, sl in ((1, 32), (8, 64), (32, 128)):
+    ids_s, mask_s = ids[:nb, :sl].contiguous(), mask[:nb, :sl].contiguous()
+    res = {}
+    for graphed in (True, False):
+        bb.graph_encode = graphed
+        with torch.no_grad():
+            for _ in range(5): m(inf_free=False, input_ids=ids_s, attention_mask=mask_s)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(200): m(inf_free=False, input_ids=ids_s, attention_mask=mask_s)
+            torch.cuda.synchronize(); res[graphed] = (time.perf_counter() - t0) / 200
+    bb.graph_encode = True
+    print(f"forward (no grad), {nb} docs x seq {sl}: HIP graph {res[True]*1e6:.0f} us, eager launches {res[False]*1e6:.0f} us "
+          f"({res[False]/res[True]:.2f}x) = {nb/res[True]:.0f} docs/s")
 # extraction on a trained-model-like representation: ~200 non-zeros per document
 g = torch.Generator(device=dev).manual_seed(1)
 sp = torch.rand(512, cfg.vocab_size, device=dev, generator=g)
