@@ -2174,215 +2174,6 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// dE += G^T . t (and dbias += column sums of G) on the matrix pipe, the mirror image of head_dt192_kernel:
-// one 8-wave workgroup owns [128 vocab rows x 384 hidden columns] of dE (waves 2 x 4, 64 x 96 each) and walks
-// ALL token rows in 32-row steps (k = token row).  B operand: the t tile [32 rows][384] through the same
-// LDS-DMA panel ring + transposing reads as E above.  A operand: the G^T slice [128 vocab][32 rows], built per
-// step by 256 owner threads -- (16-row block of the step) x (vocab column): a block belongs to one document
-// (documents are 16-row aligned), and the document's single non-zero of that column lies in the block iff
-// argmax - 16 * (block's index inside the document) is in [0, 16).  Block -> (document, index) comes from a
-// table the workgroup builds in LDS first.  239 workgroups for V = 30522: one round, no atomics on dE (a
-// workgroup owns its rows), 33.7 MB of t re-read per workgroup from L2 instead of 15.6 M row gathers.
-// ---------------------------------------------------------------------------------------
-constexpr int DE_VT = 128, DE_G = DE_VT * 64, DE_MAXBLK = 4096;
-constexpr int DE_LDS = DT_NST * DT_ESTAGE + 2 * DE_G + DT_NST * DT_CSLOT + DE_MAXBLK * 4;
-
-__global__ __launch_bounds__(512) void head_de128_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
-                                                         const uint16_t* __restrict__ argmax, const bf16* __restrict__ t,
-                                                         float* __restrict__ dE, float* __restrict__ dbias, int Bdocs, int S, int H,
-                                                         int V, int use_l0, const int32_t* __restrict__ doc_off,
-                                                         const int32_t* __restrict__ blk_doc, int rag_rows) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) char lds_char;
-  char* const sT = smem;
-  char* const sG = smem + DT_NST * DT_ESTAGE;
-  char* const sC = sG + 2 * DE_G;
-  uint32_t* const sTab = reinterpret_cast<uint32_t*>(sC + DT_NST * DT_CSLOT);
-  const bool ragged = doc_off != nullptr;
-  const int Ttot = ragged ? rag_rows : Bdocs * S;
-  const int nblk = Ttot / 16, nk = (nblk + 1) / 2;
-  const int v0 = blockIdx.y * DE_VT, n0 = blockIdx.x * DT_C;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wn = w & 3, g = lane >> 4, li = lane & 15;
-  const uint32_t gbase = (uint32_t)(uintptr_t)(lds_char*)sG, tbase = (uint32_t)(uintptr_t)(lds_char*)sT;
-  const uint32_t cbase = (uint32_t)(uintptr_t)(lds_char*)sC, tabbase = (uint32_t)(uintptr_t)(lds_char*)sTab;
-
-  // block table and zeroed G images, before any DMA is in flight
-  for (int bi = tid; bi < nblk; bi += 512) {
-    const int doc = ragged ? blk_doc[bi] : (bi * 16) / S;
-    const int row0 = ragged ? doc_off[doc] : doc * S;
-    sTab[bi] = (uint32_t)doc | ((uint32_t)((bi * 16 - row0) >> 4) << 16);
-  }
-  for (int i = tid; i < 2 * DE_G / 16; i += 512) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-
-  // ---- t loader: 24 one-KiB pieces per stage, 3 per wave ----
-  const bf16* tsrc[3];
-  int trow[3];
-  uint32_t tdst[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const int piece = w * 3 + p, panel = piece >> 3, pp = piece & 7;
-    const int row = pp * 4 + (lane >> 4), cphys = lane & 15;
-    const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
-    trow[p] = row;
-    tsrc[p] = t + n0 + panel * 128 + clog;
-    tdst[p] = panel * TG_STAGE + pp * 1024;
-  }
-  auto issue_t = [&](int k) {
-    const int kc = min(k, nk - 1);
-    char* d = sT + (k % DT_NST) * DT_ESTAGE;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const int r = min(kc * 32 + trow[p], Ttot - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tsrc[p] + (size_t)r * H), (lds_void_t*)(d + tdst[p]), 16, 0, 0);
-    }
-  };
-  // owners: (block slot of the step, vocab column); threads 256.. mirror the loads for a uniform vmcnt sequence
-  const int slot = (tid >> 7) & 1, vv = tid & 127;
-  const bool owner = tid < 256 && v0 + vv < V;
-  const int vcol = min(v0 + vv, V - 1);
-  auto issue_cols = [&](int k) {
-    const int bi = min(2 * k + slot, nblk - 1);
-    uint32_t e = lds_r32(tabbase + bi * 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e) : : "memory");
-    const size_t o = (size_t)(e & 0xFFFFu) * V + vcol;
-    char* d = sC + (k % DT_NST) * DT_CSLOT + w * 256;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(grad_rep + o), (lds_void_t*)(d), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(rep + o), (lds_void_t*)(d + 2048), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(argmax + (o & ~(size_t)1)), (lds_void_t*)(d + 4096), 4, 0, 0);
-  };
-  int prev0 = -1, prev1 = -1;
-  float bsum = 0.f;
-  auto write_g = [&](int k) {  // landed words of step k -> G^T image k & 1
-    const int bi = 2 * k + slot;
-    const uint32_t ca0 = cbase + (k % DT_NST) * DT_CSLOT + w * 256 + lane * 4;
-    uint32_t e = lds_r32(tabbase + min(bi, nblk - 1) * 4);
-    uint32_t ug = lds_r32(ca0), ur = lds_r32(ca0 + 2048), ua = lds_r32(ca0 + 4096);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e), "+v"(ug), "+v"(ur), "+v"(ua) : : "memory");
-    int off = -1;
-    uint32_t val = 0;
-    if (owner && bi < nblk) {
-      const size_t o = (size_t)(e & 0xFFFFu) * V + vcol;
-      const uint32_t ca = (o & 1) ? (ua >> 16) : (ua & 0xFFFFu);
-      const float gr = __uint_as_float(ug) * head_fprime(__uint_as_float(ur), use_l0);
-      const int pos16 = (int)ca - (int)(e >> 16) * 16;
-      if (gr != 0.f && pos16 >= 0 && pos16 < 16) {
-        const int kidx = slot * 16 + pos16;
-        off = vv * 64 + ((((kidx >> 3) ^ ((0 - (vv >> 2)) & 3))) << 4) + (kidx & 7) * 2;
-        union { bf16 h; uint16_t u; } cv;
-        cv.h = (bf16)gr;
-        val = cv.u;
-        bsum += gr;
-      }
-    }
-    const uint32_t base = gbase + (k & 1) * DE_G;
-    int& prev = (k & 1) ? prev1 : prev0;
-    if (prev >= 0) lds_w16(base + prev, 0u);
-    if (off >= 0) lds_w16(base + off, val);
-    prev = off;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-
-  uint32_t gaddr[4], eaddr[6][2];
-  {
-    const int q = li >> 2, pq = li & 3;
-    const int r0 = 8 * g + q, r1 = r0 + 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wm * 64 + i * 16 + li;
-      gaddr[i] = gbase + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int c = wn * 96 + j * 16, panel = c >> 7, cb = (c & 127) * 2 + 8 * pq;
-      eaddr[j][0] = tbase + panel * TG_STAGE + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
-      eaddr[j][1] = tbase + panel * TG_STAGE + r1 * 256 + ((((cb >> 5) ^ tg_f(r1)) << 5) | (cb & 31));
-    }
-  }
-  f32x4 acc[4][6];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue / main loop: same load order and vmcnt arithmetic as head_dt192_kernel ----
-  issue_t(0);
-  issue_t(1);
-  issue_cols(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  write_g(0);
-  issue_cols(1);
-  issue_t(2);
-  for (int k = 0; k < nk; ++k) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_cols(k + 2);
-    issue_t(k + 3);
-    const uint32_t so = (uint32_t)((k % DT_NST) * DT_ESTAGE), go = (uint32_t)((k & 1) * DE_G);
-    bf16x8 fa[4];
-    TgFrag fb[6];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = lds_b128(gaddr[i] + go);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      fb[j].s.lo = lds_tr16(eaddr[j][0] + so);
-      fb[j].s.hi = lds_tr16(eaddr[j][1] + so);
-    }
-    // first half of the MFMAs as soon as fa and fb[0..2] are here; the reads of fb[3..5] land underneath them
-    asm volatile("s_waitcnt lgkmcnt(6)"
-                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0].v), "+v"(fb[1].v), "+v"(fb[2].v)
-                 :
-                 : "memory");
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v) : : "memory");
-#pragma unroll
-    for (int j = 3; j < 6; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    write_g(k + 1);
-  }
-  // ---- epilogue: lane = (vocab row li, hidden columns 4g..4g+3) of each tile; this workgroup owns the rows ----
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = v0 + wm * 64 + i * 16 + li;
-    if (v < V) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        f32x4* p = reinterpret_cast<f32x4*>(dE + (size_t)v * H + n0 + wn * 96 + j * 16 + 4 * g);
-        *p = *p + acc[i][j];
-      }
-    }
-  }
-  if (owner && blockIdx.x == 0 && bsum != 0.f) atomicAdd(dbias + v0 + vv, bsum);
-}
-
-int sm_head_de_eligible(int dtype, const void* t, const float* dE, int B, int S, int H, int V, const sm_ragged* rag) {
-  constexpr int de128 = 1;
-  const long T = rag ? rag->rows : (long)B * S;
-  return de128 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && B <= 65535 && T % 16 == 0 && T / 16 <= DE_MAXBLK &&
-         ((uintptr_t)t % 16) == 0 && ((uintptr_t)dE % 16) == 0 && (rag || S % 16 == 0);
-}
-
-// dE / dbias on the matrix pipe when the shapes allow it; returns 1 when launched, 0 to let the caller use
-// the gather kernel (sparse_head.hip), < 0 on error
-int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t, float* dE,
-                      float* dbias, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st) {
-  if (!sm_head_de_eligible(dtype, t, dE, B, S, H, V, rag)) return 0;
-  SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_de128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DE_LDS));
-  hipLaunchKernelGGL(head_de128_kernel, dim3(H / DT_C, sm_cdiv(V, DE_VT)), dim3(512), DE_LDS, st, grad_rep, rep, argmax, (const bf16*)t, dE, dbias,
-                     B, S, H, V, use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0);
-  SM_LAUNCH_CHECK();
-  return 1;
-}
-
 // dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
 // the fused form of the dt half: LayerNorm' and GELU' of the head transform in the epilogue (1 = shape not eligible)
 int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dft,

@@ -8,13 +8,10 @@
 
 int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dt,
                       int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
-int sm_head_de_eligible(int dtype, const void* t, const float* dE, int B, int S, int H, int V, const sm_ragged* rag);
-int sm_head_de_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t, float* dE,
-                      float* dbias, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, hipStream_t st);
 
 namespace {
 
-// ---- backward of the fused head, gather form (fallback of head_de128_kernel in gemm.hip):
+// ---- backward of the fused head, gather form for any dtype and width (the bf16 training path runs head_de_rows_kernel below):
 // dE[v,:] += sum_b g[b,v] t[b, argmax[b,v], :],  dbias[v] += sum_b g[b,v] ----
 // block = 16 vocab rows (4 per wave); g / argmax tiles for 256 documents at a time in LDS.
 template <typename T, int NC>
@@ -442,6 +439,116 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ s
 
 }  // namespace
 
+// ---- the same product for bf16 rows, as batched row gathers (the kernel the training step runs) ----
+// G has ONE non-zero per (document, vocabulary row) -- the arg-max position -- so dE[v, :] is a sum of B scaled rows of t: 2 B V H
+// flops instead of the 2 T V H of the matrix form (rounds 2 - 4 ran head_de128_kernel, G^T . t on the matrix pipe: 1.73 ms for
+// 512 x 128 rows and G rounded to bf16; this kernel: 0.6 ms, exact products in fp32; profiles/r4_head_de_rows.txt).
+// A workgroup owns 8 x RPW vocabulary rows; a wave owns RPW of them with the whole [RPW x H] fp32 sum in registers (lane = NC
+// consecutive columns, so ONE 2 NC-byte load per lane covers a row of t).  The 64 lanes fetch the (gradient, rep, arg-max) words of
+// 64 / RPW documents x RPW rows at once, two such groups ahead.  Per document the wave then issues its RPW row loads back to back
+// (scalar base + 32-bit offset) and consumes them in the same block: RPW x 2 H bytes in flight per wave, no LDS, no barrier, no
+// atomics (the workgroup owns its rows of dE and dbias), every summation order fixed.  Rows without a gradient load the
+// document's first row (a hit) and add nothing; a document in which none of the wave's rows has a gradient is skipped -- the usual
+// case once the model is sparse (1 % of the entries alive: 0.17 ms).
+// No row register lives across a back-edge: loop-carried row tuples made the register allocator copy them right behind the loads
+// (= wait for them there), and two documents in flight spill (a 12-byte load occupies a 4-register tuple).
+template <int NC>
+struct __attribute__((packed, aligned(4))) DeRow { uint32_t w[NC / 2]; };
+
+template <int NC, int RPW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_de_rows_kernel(
+    const float* __restrict__ grad_rep, const float* __restrict__ rep, const uint16_t* __restrict__ argmax, const bf16* __restrict__ t,
+    float* __restrict__ dE, float* __restrict__ dbias, int B, int S, int V, int use_l0, const int32_t* __restrict__ doc_off) {
+  constexpr int H = 64 * NC, G = 64 / RPW;  // G documents per group of column words
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int v0 = (blockIdx.x * 8 + w) * RPW;
+  if (v0 >= V) return;
+  const int lrow = lane % RPW, ldoc = lane / RPW;
+  const bool vok = v0 + lrow < V;
+  const int vr = min(v0 + lrow, V - 1);
+  const uint32_t loff = lane * (2 * NC);
+  float acc[RPW][NC];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.f;
+  float bsum = 0.f;
+
+  struct Cols { float g, r; uint32_t a; int row0; };
+  // three independent loads per group (+ the document's first row), issued BEFORE the row loads of the documents in between: the
+  // counter is in order, so they have landed once those rows have
+  auto cols_issue = [&](int q, Cols& c) {
+    const int d = min(q * G + ldoc, B - 1);
+    const size_t o = (size_t)d * V + vr;
+    c.g = grad_rep[o];
+    c.r = rep[o];
+    c.a = argmax[o];
+    c.row0 = doc_off ? doc_off[d] : d * S;
+  };
+  // -> (gradient through the activation, byte offset of the routed row of t; the document's first row where there is no gradient)
+  auto cols_finish = [&](int q, const Cols& c, float& gv, uint32_t& ov) {
+    float gr = c.g * head_fprime(c.r, use_l0);
+    if (!vok || q * G + ldoc >= B) gr = 0.f;
+    gv = gr;
+    ov = (uint32_t)(c.row0 + (gr != 0.f ? (int)c.a : 0)) * (uint32_t)(2 * H);  // (the launcher checks that t is below 4 GiB)
+  };
+
+  const int nq = (B + G - 1) / G;
+  Cols c0, c1;
+  cols_issue(0, c0);
+  cols_issue(1, c1);
+  auto group = [&](int q, Cols& c) {
+    float gv;
+    uint32_t ov;
+    cols_finish(q, c, gv, ov);
+    cols_issue(q + 2, c);
+    bsum += gv;
+    const unsigned long long alive = __builtin_amdgcn_ballot_w64(gv != 0.f);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (((alive >> (j * RPW)) & ((1ull << RPW) - 1)) != 0) {  // (wave-uniform)
+        DeRow<NC> rows[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)ov, j * RPW + r) + loff;
+          rows[r] = *reinterpret_cast<const DeRow<NC>*>(reinterpret_cast<const char*>(t) + off);
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), j * RPW + r));
+#pragma unroll
+          for (int k = 0; k < NC / 2; ++k) {
+            const uint32_t u = rows[r].w[k];
+            acc[r][2 * k] = fmaf(g, __uint_as_float(u << 16), acc[r][2 * k]);
+            acc[r][2 * k + 1] = fmaf(g, __uint_as_float(u & 0xFFFF0000u), acc[r][2 * k + 1]);
+          }
+        }
+      }
+    }
+  };
+  for (int q = 0; q < nq; q += 2) {
+    group(q, c0);
+    if (q + 1 < nq) group(q + 1, c1);
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (v0 + r < V) {
+      float* o = dE + (size_t)(v0 + r) * H + lane * NC;
+#pragma unroll
+      for (int c = 0; c < NC; c += 2) {
+        float2* q = reinterpret_cast<float2*>(o + c);
+        float2 x = *q;
+        x.x += acc[r][c];
+        x.y += acc[r][c + 1];
+        *q = x;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= RPW; off >>= 1) bsum += __shfl_down(bsum, off);
+  if (lane < RPW && vok) dbias[v0 + lane] += bsum;
+}
+
 extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t,
                                   const void* E, void* dt, float* dE, float* dbias, int B, int S, int H, int V, int use_l0,
                                   const sm_ragged* rag, void* stream) {
@@ -458,8 +565,25 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     SM_REQUIRE(dt != nullptr, "sm_sparse_head_bwd: dt and dE are both NULL");
     return sm_head_dt_launch(dtype, grad_rep, rep, argmax, E, dt, B, S, H, V, use_l0, rag, st);
   }
-  const int de_rc = sm_head_de_launch(dtype, grad_rep, rep, argmax, t, dE, dbias, B, S, H, V, use_l0, rag, st_de);
-  if (de_rc < 0) return de_rc;
+  bool rows_done = false;
+  if (dtype == SM_BF16 && (rag ? (long)rag->rows : (long)B * S) * H * 2 < (1L << 32) &&
+      (H == 128 || H == 256 || H == 384 || H == 512 || H == 768 || H == 1024) && ((uintptr_t)t % 4) == 0 && ((uintptr_t)dE % 8) == 0) {
+    const int32_t* doc_off = rag ? rag->doc_off : nullptr;
+#define LAUNCH_ROWS(NC, RPW)                                                                                                         \
+  hipLaunchKernelGGL((head_de_rows_kernel<NC, RPW>), dim3(sm_cdiv(V, 8 * RPW)), dim3(512), 0, st_de, grad_rep, rep, argmax, (const bf16*)t, dE, \
+                     dbias, B, S, V, use_l0, doc_off)
+    switch (H / 64) {
+      case 2: LAUNCH_ROWS(2, 16); break;
+      case 4: LAUNCH_ROWS(4, 16); break;
+      case 6: LAUNCH_ROWS(6, 16); break;
+      case 8: LAUNCH_ROWS(8, 8); break;
+      case 12: LAUNCH_ROWS(12, 8); break;
+      default: LAUNCH_ROWS(16, 4); break;
+    }
+#undef LAUNCH_ROWS
+    SM_LAUNCH_CHECK();
+    rows_done = true;
+  }
   const int nc = H / 64;
   dim3 grid(sm_cdiv(V, 16));
 #define LAUNCH_DE(T, NC) \
@@ -475,7 +599,7 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     case 16: LAUNCH_DE(T, 16); break;                                          \
     default: SM_REQUIRE(false, "sm_sparse_head_bwd: H=%d unsupported", H);     \
   }
-  if (de_rc == 0) {
+  if (!rows_done) {
     if (dtype == SM_BF16) { DISPATCH_NC(bf16) } else { DISPATCH_NC(float) }
   }
 #undef DISPATCH_NC

@@ -416,6 +416,43 @@ def test_sparse_head_fwd_bwd(ops, dtype, B, S, H, V, use_l0):
     close(dbias, br.grad, tol * 2, "dbias")
 
 
+@pytest.mark.parametrize("H,B,S,V", [(128, 7, 32, 333), (256, 5, 64, 1000), (384, 9, 128, 30522), (384, 1, 16, 130), (512, 6, 48, 257),
+                                     (768, 11, 128, 2100), (1024, 18, 16, 515)])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_head_de_row_gathers_are_the_routed_sum_in_fp32(ops, H, B, S, V, ragged):
+    """dE / dbias half of the head backward for bf16 rows (head_de_rows_kernel): dE[v] += sum_d g[d, v] t[row(d) + argmax[d, v]] with
+    exact bf16 x fp32 products -- equal to a float64 evaluation up to fp32 summation; every width the kernel is instantiated for,
+    group tails (B not a multiple of 64 / RPW), vocabulary tails, documents and rows without any gradient, accumulation into dE"""
+    g = torch.Generator().manual_seed(H + B)
+    if ragged:
+        lens = (torch.randint(1, S // 16 + 1, (B,), generator=g) * 16).tolist()
+        _, off_np, rows, row_doc, pos, _ = _ragged(lens)
+        rag = ops.Ragged(dev(off_np.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, S)
+        off = off_np.tolist()
+    else:
+        lens, off, rag = [S] * B, [i * S for i in range(B + 1)], None
+    T = off[-1]
+    t = torch.randn(T, H, generator=g).to(torch.bfloat16)
+    rep = torch.rand(B, V, generator=g) + 0.05
+    rep[torch.rand(B, V, generator=g) < 0.4] = 0.0
+    rep[B // 2] = 0.0                     # a document without any gradient
+    rep[:, V // 3] = 0.0                  # a vocabulary row without any gradient
+    grad = torch.randn(B, V, generator=g)
+    am = torch.stack([torch.randint(0, lens[b], (V,), generator=g) for b in range(B)]).to(torch.int16)
+    dE0 = torch.randn(V, H, generator=g)
+    db0 = torch.randn(V, generator=g)
+    dE, db = dev(dE0.clone()), dev(db0.clone())
+    ops.sparse_head_bwd(dev(grad), dev(rep), dev(am).view(torch.uint16), dev(t, torch.bfloat16), None, dE, db, B, S, V, False, rag, part="de")
+    gr = (grad.double() * torch.where(rep > 0, torch.exp(-rep.double()), torch.zeros(B, V, dtype=torch.float64)))
+    want = dE0.double()
+    for b in range(B):
+        want += gr[b][:, None] * t[off[b] + am[b].long()].double()
+    scale = float(want.abs().max())
+    assert float((dE.cpu().double() - want).abs().max()) <= 2e-6 * scale
+    wb = db0.double() + gr.sum(0)
+    assert float((db.cpu().double() - wb).abs().max()) <= 2e-6 * float(wb.abs().max())
+
+
 def test_prune_rows(ops):
     rep = torch.relu(rnd(7, 333, seed=1))
     out = ops.prune_rows(dev(rep.clone()), 0.1)
