@@ -70,6 +70,9 @@ class ModelArguments:
     # None = on (or the SM_PC_FFN / SM_FWD_F16 environment switches).  Both are logged at start-up.
     fused_ffn: Optional[bool] = None
     fwd_f16: Optional[bool] = None
+    # extension: kernel-selection switches that do not change the arithmetic class (sparse_hip.encoder.KERNEL_OPTIONS: fused feed-forward
+    # backward, weight-gradient side stream, HIP-graph inference encodes, ...), e.g. {"wgrad_stream": false}; logged at start-up
+    kernel_options: Optional[dict] = None
 
     def __post_init__(self):
         if self.tokenizer_name is None:

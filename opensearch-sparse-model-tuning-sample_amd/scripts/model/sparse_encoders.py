@@ -69,18 +69,19 @@ class SparseModel(torch.nn.Module):
     def __init__(self, model_id, idf=None, tokenizer_id=None, idf_requires_grad=False, prune_ratio=None,
                  preprocess_func=None, use_l0=True, compute_dtype: Optional[torch.dtype] = None, device=None,
                  residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None, fused_ffn: Optional[bool] = None,
-                 fwd_f16: Optional[bool] = None):
+                 fwd_f16: Optional[bool] = None, kernel_options: Optional[dict] = None):
         super().__init__()
         compute_dtype = compute_dtype or torch.bfloat16
         if isinstance(model_id, HipBertMLM):
             self.backbone = model_id
         else:
             self.backbone = HipBertMLM.from_pretrained(model_id, compute_dtype=compute_dtype, device=device, residual_fp32=residual_fp32,
-                                                       fp8=fp8, fused_ffn=fused_ffn, fwd_f16=fwd_f16)
+                                                       fp8=fp8, fused_ffn=fused_ffn, fwd_f16=fwd_f16, kernel_options=kernel_options)
         bb = self.backbone
         logger.info("numerics: compute dtype %s, fp32 residual stream %s, fused feed-forward (sigmoid-form GELU, |err| <= 2.6e-5) %s, "
                     "fp16 forward operands in the head %s / feed-forward %s, fp8 encoder linears %s", bb.compute_dtype, bb.residual_fp32,
                     bb.pc_ffn, bb.fwd_f16, bb.ffn_fwd_f16 or (bb.pc_ffn and bb.ffn_f16), bb.fp8)
+        logger.info("kernel options (sparse_hip.encoder.KERNEL_OPTIONS): %s", bb.kernel_options())
         if tokenizer_id is None and not isinstance(model_id, HipBertMLM):
             tokenizer_id = model_id
         self.tokenizer = _load_tokenizer(tokenizer_id)

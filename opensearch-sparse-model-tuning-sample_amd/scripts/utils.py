@@ -39,4 +39,4 @@ def get_model(model_args, compute_dtype=None, device=None):
     return SparseModel(model_args.model_name_or_path, idf=idf, tokenizer_id=model_args.tokenizer_name,
                        compute_dtype=compute_dtype, device=device, residual_fp32=getattr(model_args, "residual_fp32", None),
                        fp8=getattr(model_args, "fp8", None), fused_ffn=getattr(model_args, "fused_ffn", None),
-                       fwd_f16=getattr(model_args, "fwd_f16", None), **kw)
+                       fwd_f16=getattr(model_args, "fwd_f16", None), kernel_options=getattr(model_args, "kernel_options", None), **kw)

@@ -178,14 +178,44 @@ class _Site:
     EMB, ATTN, HID1, HID2 = 0, 1, 2, 3
 
 
+# Kernel-selection switches of HipBertMLM that are not numerics choices (those are constructor arguments of their own: residual_fp32,
+# fp8, fused_ffn, fwd_f16).  One table: name -> (environment switch, default, type).  An entry of the constructor's `kernel_options`
+# dict wins over the environment switch, which wins over the default; HipBertMLM.kernel_options() returns the values in force and
+# SparseModel logs them at start-up.  The environment forms exist for A/B runs on one box (tools/ab_env.sh).
+KERNEL_OPTIONS = {
+    "ffn_f16": ("SM_FFN_F16", True, bool),                    # fp16 (not bf16) operands inside the fused feed-forward forward
+    "pc_ffn_bwd": ("SM_PC_FFN_BWD", True, bool),              # fused feed-forward backward (one launch) instead of the two GEMM launches
+    "ffn_fwd_f16": ("SM_FFN_FWD_F16", None, bool),            # fp16 operands of the UNFUSED feed-forward forward; None: models of >= 10 layers
+    "fp8_delayed": ("SM_FP8_DELAYED", True, bool),            # fp8 runs: previous step's maxima as scales from step 2 on
+    "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
+    "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
+    "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
+    "pc_infer_min_rows": ("SM_PC_INFER_MIN_ROWS", 6144, int),  # no-grad forwards below this many rows: unfused feed-forward launches
+}
+
+
+def _kernel_option(explicit: Optional[dict], name: str):
+    env, default, kind = KERNEL_OPTIONS[name]
+    if explicit is not None and explicit.get(name) is not None:
+        return kind(explicit[name])
+    raw = os.environ.get(env)
+    if raw is None:
+        return default
+    return (raw != "0") if kind is bool else kind(raw)
+
+
 class HipBertMLM(torch.nn.Module):
     """BertForMaskedLM-shaped module whose math runs in libsparse_hip.so."""
 
     def __init__(self, cfg: BertConfigLite, compute_dtype: torch.dtype = torch.bfloat16,
                  device: Optional[torch.device] = None, init_seed: Optional[int] = 0, with_head: bool = True,
                  residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None, fused_ffn: Optional[bool] = None,
-                 fwd_f16: Optional[bool] = None):
+                 fwd_f16: Optional[bool] = None, kernel_options: Optional[dict] = None):
         super().__init__()
+        unknown = set(kernel_options or ()) - set(KERNEL_OPTIONS)
+        if unknown:
+            raise L.SparseHipError(f"unknown kernel_options {sorted(unknown)}; known: {sorted(KERNEL_OPTIONS)}")
+        opt = lambda name: _kernel_option(kernel_options, name)  # noqa: E731
         self.config = cfg
         self.compute_dtype = compute_dtype
         # bf16 runs keep the RESIDUAL STREAM in fp32 by default (pre-LayerNorm sums and LayerNorm outputs on the residual path;
@@ -202,13 +232,13 @@ class HipBertMLM(torch.nn.Module):
         # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_fused_gpu.py).
         # Both numerics-relevant defaults are constructor arguments (ModelArguments.fused_ffn / fwd_f16, logged at start-up); the
         # environment switches remain for A/B runs and are overridden by an explicit argument.
-        self.ffn_f16 = os.environ.get("SM_FFN_F16", "1") != "0"
+        self.ffn_f16 = opt("ffn_f16")
         want_pc = (os.environ.get("SM_PC_FFN", "1") == "1") if fused_ffn is None else bool(fused_ffn)
         self.pc_ffn = (compute_dtype == torch.bfloat16 and self.residual_fp32 and H == 384 and cfg.intermediate_size % 64 == 0
                        and cfg.intermediate_size >= 128 and want_pc)
         # ... and its BACKWARD in the same form (one launch for the dF1 GEMM + the GEMM fused with the LayerNorm-1 backward: dF1 is
         # consumed on the chip by the second GEMM instead of being read back); SM_PC_FFN_BWD=0 keeps the two launches
-        self.pc_ffn_bwd = self.pc_ffn and os.environ.get("SM_PC_FFN_BWD", "1") == "1"
+        self.pc_ffn_bwd = self.pc_ffn and opt("pc_ffn_bwd")
         # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
         # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
         # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
@@ -228,12 +258,12 @@ class HipBertMLM(torch.nn.Module):
         # gradient) is scaled by the maximum it showed during the PREVIOUS step (all calls of the step: both passes of gradient
         # caching, every chunk) and records this step's maximum in the same pass -- one pass over the tensor instead of two; the
         # first step (and inference) measures just in time.  SM_FP8_DELAYED=0 keeps just-in-time scaling throughout.
-        self._fp8_delayed = os.environ.get("SM_FP8_DELAYED", "1") != "0"
+        self._fp8_delayed = opt("fp8_delayed")
         self._fp8_sites, self._fp8_cur, self._fp8_next, self._fp8_ready = {}, None, None, set()
         if self.fp8:
             self.pc_ffn = False
-        self.ffn_fwd_f16 = (self.fwd_f16 and not self.pc_ffn and not self.fp8
-                            and os.environ.get("SM_FFN_FWD_F16", "1" if deep else "0") == "1")
+        want_ffn16 = opt("ffn_fwd_f16")
+        self.ffn_fwd_f16 = self.fwd_f16 and not self.pc_ffn and not self.fp8 and (deep if want_ffn16 is None else want_ffn16)
         if H % 64 or H > 1024 or (H % 128 and H != 64):
             raise L.SparseHipError(f"hidden_size={H} unsupported (64 or a multiple of 128, <= 1024)")
         if H // cfg.num_attention_heads not in (32, 64):
@@ -266,9 +296,10 @@ class HipBertMLM(torch.nn.Module):
         # Inference encodes (eval mode, no grad, dense layout) of at most graph_tokens padded tokens are launch-bound (about 45 launches
         # of a few microseconds each): they replay one captured HIP graph per (documents, padded length) bucket.  SM_ENCODE_GRAPH=0
         # switches it off; tools/encode_bench.py measures both.
-        self.pc_infer_min_rows = int(os.environ.get("SM_PC_INFER_MIN_ROWS", "6144"))
-        self.graph_encode = os.environ.get("SM_ENCODE_GRAPH", "1") == "1"
-        self.graph_tokens = int(os.environ.get("SM_ENCODE_GRAPH_TOKENS", "8192"))
+        self.pc_infer_min_rows = opt("pc_infer_min_rows")
+        self.graph_encode = opt("encode_graph")
+        self.graph_tokens = opt("encode_graph_tokens")
+        self.wgrad_stream = opt("wgrad_stream")
         self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
@@ -336,10 +367,10 @@ class HipBertMLM(torch.nn.Module):
     @classmethod
     def from_pretrained(cls, model_dir: str, compute_dtype=torch.bfloat16, device=None, with_head=True,
                         residual_fp32: Optional[bool] = None, fp8: Optional[bool] = None, fused_ffn: Optional[bool] = None,
-                        fwd_f16: Optional[bool] = None) -> "HipBertMLM":
+                        fwd_f16: Optional[bool] = None, kernel_options: Optional[dict] = None) -> "HipBertMLM":
         cfg = BertConfigLite.from_json(os.path.join(model_dir, "config.json"))
         model = cls(cfg, compute_dtype, device, init_seed=None, with_head=with_head, residual_fp32=residual_fp32, fp8=fp8,
-                    fused_ffn=fused_ffn, fwd_f16=fwd_f16)
+                    fused_ffn=fused_ffn, fwd_f16=fwd_f16, kernel_options=kernel_options)
         st = os.path.join(model_dir, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
@@ -396,6 +427,12 @@ class HipBertMLM(torch.nn.Module):
         return out
 
     # ------------------------------------------------------------------ staging copies
+    def kernel_options(self) -> dict:
+        """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
+        return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "encode_graph": self.graph_encode,
+                "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
+
     def sync_weights(self) -> None:
         """Refresh the compute-dtype copies (and transposes) of every GEMM weight."""
         if not self._weights_dirty:
@@ -717,9 +754,9 @@ class _WgradStream:
     packet between two kernels of the backward chain costs it ~12 us (step timeline: 34 us gaps where two forks sat between two
     GEMMs) -- one fork per layer instead of one per weight gradient."""
 
-    def __init__(self, device):
+    def __init__(self, device, enabled: bool = True):
         self.stream = torch.cuda.Stream(device=device)
-        self.enabled = os.environ.get("SM_WGRAD_STREAM", "1") != "0"
+        self.enabled = enabled
         self.pending = []  # (fn, operands)
 
     def run(self, a: Tensor, b: Tensor, out: Tensor, colsum: Optional[Tensor]):
@@ -841,7 +878,7 @@ class _EncodeFn(torch.autograd.Function):
         c = "cls.predictions."
         e = "bert.embeddings."
         if model._wgrad is None:
-            model._wgrad = _WgradStream(model.device)
+            model._wgrad = _WgradStream(model.device, model.wgrad_stream)
         wg = model._wgrad
         grad_rep = grad_rep.contiguous().float()
         # the head backward's two halves: dE / dbias are weight gradients (side stream, like every other one),

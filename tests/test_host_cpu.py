@@ -93,6 +93,27 @@ def test_yaml_configs_parse_into_the_three_argument_groups():
     assert targs.compute_dtype == torch.bfloat16  # fp16: true in the reference maps to bf16 here
 
 
+def test_kernel_options_table_resolves_argument_over_environment_over_default(monkeypatch):
+    """sparse_hip.encoder.KERNEL_OPTIONS: one table for the kernel-selection switches; explicit dict > SM_* environment > default,
+    unknown names are refused (checked before anything touches a device)"""
+    from sparse_hip import encoder as enc
+    from sparse_hip.lib import SparseHipError
+    for name, (env, default, kind) in enc.KERNEL_OPTIONS.items():
+        monkeypatch.delenv(env, raising=False)
+        assert enc._kernel_option(None, name) == default
+        assert enc._kernel_option({name: None}, name) == default
+    monkeypatch.setenv("SM_WGRAD_STREAM", "0")
+    monkeypatch.setenv("SM_PC_INFER_MIN_ROWS", "100")
+    assert enc._kernel_option(None, "wgrad_stream") is False and enc._kernel_option(None, "pc_infer_min_rows") == 100
+    assert enc._kernel_option({"wgrad_stream": True, "pc_infer_min_rows": 7}, "wgrad_stream") is True
+    assert enc._kernel_option({"pc_infer_min_rows": 7}, "pc_infer_min_rows") == 7
+    cfg = enc.BertConfigLite(vocab_size=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=4, intermediate_size=256)
+    with pytest.raises(SparseHipError, match="unknown kernel_options"):
+        enc.HipBertMLM(cfg, device="cpu", kernel_options={"no_such_switch": 1})
+    from scripts.args import ModelArguments
+    assert ModelArguments(model_name_or_path="x", kernel_options={"wgrad_stream": False}).kernel_options == {"wgrad_stream": False}
+
+
 def test_training_arguments_reject_what_the_step_driver_does_not_implement():
     """keys that would change the optimisation must not pass silently; keys HF itself ignores must not be rejected"""
     from scripts.args import TrainingArguments
