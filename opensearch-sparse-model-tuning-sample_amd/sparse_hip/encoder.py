@@ -45,9 +45,10 @@ class PackedDocs:
         self.ids, self.mask, self.rag = ids, mask, rag
 
 
-def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_id: int = 0) -> Optional[PackedDocs]:
+def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_id: int = 0, for_backward: bool = True) -> Optional[PackedDocs]:
     """Host-side packing; returns None when the batch cannot be packed (mask is not a prefix mask,
-    a document is empty or longer than the largest supported bucket)."""
+    a document is empty or longer than the largest supported bucket).  for_backward=False (inference) skips the two sorts that
+    only the embedding backward reads."""
     import numpy as np
 
     ids = input_ids.cpu().numpy()
@@ -73,9 +74,10 @@ def pack_documents(input_ids: Tensor, attention_mask: Tensor, device, pad_token_
     rag = ops.Ragged(t(doc_off, np.int32), t(row_doc[::16], np.int32), t(pos, np.int32), rows, B, smax)
     # the valid rows sorted by token id and by position: the embedding backward sums runs of equal keys in registers and
     # touches a table row once per run (ops.embed_bwd; [CLS] / [SEP] and every position occur in every document)
-    vrows = np.flatnonzero(valid)
-    by_id, by_pos = np.argsort(pids[vrows], kind="stable"), np.argsort(pos[vrows], kind="stable")
-    rag.emb_sorted = (t(vrows[by_id], np.int32), t(pids[vrows][by_id], np.int32), t(vrows[by_pos], np.int32), t(pos[vrows][by_pos], np.int32))
+    if for_backward:
+        vrows = np.flatnonzero(valid)
+        by_id, by_pos = np.argsort(pids[vrows], kind="stable"), np.argsort(pos[vrows], kind="stable")
+        rag.emb_sorted = (t(vrows[by_id], np.int32), t(pids[vrows][by_id], np.int32), t(vrows[by_pos], np.int32), t(pos[vrows][by_pos], np.int32))
     return PackedDocs(t(pids, np.int64), t(valid, np.uint8), rag)
 
 

@@ -728,6 +728,18 @@ def test_inference_postprocessor_matches_reference_golden_and_oracle():
                 assert abs(x - ref[t]) <= 1e-3 * (1 + abs(ref[t]))
     # do_count: per-token document frequencies of the batch (column 0 is never emitted)
     assert int(enc.count_tensor[1:].sum()) == sum(len(d) for d in out)
+    # large padded batches are packed on the host (padding tokens never computed): same rows as the dense layout
+    enc2 = SparseEncoder(m, max_length=32, do_count=False)
+    reps = {}
+    for thr in (0, 1 << 30):
+        enc2.PACK_MIN_SLOTS = thr
+        enc2.post_processor = lambda x: x
+        reps[thr] = enc2.encode_features(feats)
+    assert float(feats["attention_mask"].float().mean()) < 0.9, "the golden batch is padded"
+    from sparse_hip.encoder import pack_documents
+    pk = pack_documents(feats["input_ids"], feats["attention_mask"], "cuda", 0, for_backward=False)
+    assert pk is not None and pk.rag.rows <= feats["input_ids"].numel() and not hasattr(pk.rag, "emb_sorted")
+    assert float((reps[0] - reps[1 << 30]).abs().max()) <= 1e-5 * (1 + float(reps[0].abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

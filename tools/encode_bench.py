@@ -19,6 +19,19 @@ with torch.no_grad():
     for _ in range(10): rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print(f"forward (no grad), 512 docs x seq 128: {dt*1e3:.2f} ms = {512/dt:.0f} docs/s")
+# the user-facing path (SparseEncoder.encode_features from CPU token ids): padded batches are packed on the host, padding tokens skipped
+from scripts.model.sparse_encoders import SparseEncoder
+m.tokenizer = type("Tok", (), {"vocab": {f"t{i}": i for i in range(cfg.vocab_size)}})()
+enc = SparseEncoder(m, max_length=128, do_count=False)
+enc.post_processor = lambda x: x  # time the forward only
+feats = {"input_ids": ids.cpu(), "attention_mask": mask.cpu()}
+for label, thr in (("packed on the host", 8192), ("dense layout", 1 << 30)):
+    enc.PACK_MIN_SLOTS = thr
+    for _ in range(3): enc.encode_features(feats)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): enc.encode_features(feats)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"SparseEncoder.encode_features, 512 docs x 128 slots ({int(mask.sum())} tokens), {label}: {dt*1e3:.2f} ms = {512/dt:.0f} docs/s (H2D + packing included)")
 # small batches are launch-bound: one captured HIP graph per (documents, padded length) bucket against the eager launches
 for nb, sl in ((1, 32), (8, 64), (32, 128)):
     ids_s, mask_s = ids[:nb, :sl].contiguous(), mask[:nb, :sl].contiguous()
