@@ -453,6 +453,38 @@ def test_head_de_row_gathers_are_the_routed_sum_in_fp32(ops, H, B, S, V, ragged)
     assert float((db.cpu().double() - wb).abs().max()) <= 2e-6 * float(wb.abs().max())
 
 
+def test_head_de_row_gathers_random_shapes(ops):
+    """property test (hypothesis): random document counts, lengths, vocabulary sizes, live-entry densities and widths -- the
+    row-gather dE kernel equals the float64 routed sum, and untouched rows of dE / dbias keep their values"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 70), S16=st.integers(1, 8), V=st.integers(2, 1500), H=st.sampled_from([128, 256, 384, 512, 768, 1024]),
+           dens=st.sampled_from([0.0, 0.02, 0.5, 1.0]), l0=st.booleans(), seed=st.integers(0, 2 ** 16))
+    def run(B, S16, V, H, dens, l0, seed):
+        S = 16 * S16
+        g = torch.Generator().manual_seed(seed)
+        t = torch.randn(B * S, H, generator=g).to(torch.bfloat16)
+        rep = (torch.rand(B, V, generator=g) + 0.05) * (torch.rand(B, V, generator=g) < dens)
+        grad = torch.randn(B, V, generator=g)
+        am = torch.randint(0, S, (B, V), generator=g).to(torch.int16)
+        dE0, db0 = torch.randn(V, H, generator=g), torch.randn(V, generator=g)
+        dE, db = dev(dE0.clone()), dev(db0.clone())
+        ops.sparse_head_bwd(dev(grad), dev(rep), dev(am).view(torch.uint16), dev(t, torch.bfloat16), None, dE, db, B, S, V, l0, None, part="de")
+        r = rep.double()
+        fp = torch.where(rep > 0, torch.exp(-r - torch.expm1(r)) if l0 else torch.exp(-r), torch.zeros_like(r))
+        gr = grad.double() * fp
+        want = dE0.double()
+        rows = torch.arange(B)[:, None] * S + am.long()
+        for b in range(B):
+            want += gr[b][:, None] * t[rows[b]].double()
+        wb = db0.double() + gr.sum(0)
+        assert float((dE.cpu().double() - want).abs().max()) <= 3e-6 * (1 + float(want.abs().max()))
+        assert float((db.cpu().double() - wb).abs().max()) <= 3e-6 * (1 + float(wb.abs().max()))
+
+    run()
+
+
 def test_prune_rows(ops):
     rep = torch.relu(rnd(7, 333, seed=1))
     out = ops.prune_rows(dev(rep.clone()), 0.1)
