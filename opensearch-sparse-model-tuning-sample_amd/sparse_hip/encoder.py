@@ -822,7 +822,8 @@ class _EncodeGraph:
             forward()
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: the trainer's input-prefetch thread keeps allocating and copying on its own stream while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.rep = forward()
 
     def run(self, ids: Tensor, mask: Tensor) -> Tensor:

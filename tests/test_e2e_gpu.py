@@ -789,6 +789,30 @@ def test_graphed_inference_encode_equals_the_eager_forward(dtype):
             fused = bb.encode(ids, mask)  # (a new graph: the threshold is read at capture)
         err = float(((small - fused).abs() / (1 + fused.abs())).max())
         assert err <= 2e-3, err
+    # a capture must not disturb (or be disturbed by) another thread that allocates and copies on its own stream: the input prefetcher
+    import threading
+    stop, errors = threading.Event(), []
+
+    def other_thread():
+        try:
+            side = torch.cuda.Stream()
+            host = torch.empty(1 << 20, dtype=torch.float32).pin_memory()
+            with torch.cuda.stream(side):
+                while not stop.is_set():
+                    torch.empty(1 << 20, device="cuda").copy_(host, non_blocking=True)
+                side.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    th = threading.Thread(target=other_thread)
+    th.start()
+    try:
+        for B2, S2 in ((3, 30), (7, 40), (2, 100)):  # three new buckets = three captures
+            both(*batch(B2, S2))
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
     # with grad enabled (or in training mode) the autograd path runs: nothing is captured
     ids, mask = batch(8, 50)
     n = len(bb._graphs)
