@@ -12,6 +12,10 @@
 // cross-wave reductions and no atomics.
 #include "common.h"
 
+#ifndef ATTN_SKIP
+#define ATTN_SKIP 1
+#endif
+
 namespace {
 
 template <typename T> struct AT;
@@ -269,7 +273,7 @@ struct Lay {  // LDS row stride (bytes): 128-byte bf16 rows are XOR-swizzled (im
 // being the neighbouring head -- so one head per workgroup fetches every line of q/k/v twice (measured: 2x
 // the algorithmic HBM traffic forward, 3.5x backward); two adjacent heads per workgroup use whole lines.
 // DROP: dropout on / off is a compile-time switch -- as a run-time test the compiler kept one branch PER ELEMENT in the loops
-template <typename T, int DH, int NKT, int HP, bool DROP>
+template <typename T, int DH, int NKT, int HP, bool DROP, bool TAIL>  // TAIL: dense layout, trailing masked key tiles are skipped
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
@@ -284,14 +288,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   const int row0 = doc_off ? doc_off[b] : b * S;
   const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
   const int nqb = Lr / 16;             // query blocks that exist
-  const int nkt = (nqb + 1) & ~1;      // key tiles, rounded up to a pair (zero-filled, masked)
+  int nkt = (nqb + 1) & ~1;            // key tiles, rounded up to a pair (zero-filled, masked)
   char* sK0 = smem;                         // [S][HP*DH] row-major
   char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
   float* sBias = reinterpret_cast<float*>(sV0 + S * L::RS);  // per key: 0, or -inf for masked / padding keys
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
   stage2_batched<T, HP * DH, L::SWZ, NKT * 16 * (HP * DH * (int)sizeof(T) / 16) / 256>(base0 + H, ld, base0 + 2 * H, ld, Lr, nkt * 16, sK0, sV0, L::RS);
-  for (int i = threadIdx.x; i < nkt * 16; i += blockDim.x) sBias[i] = (i < Lr && keymask[(size_t)row0 + i]) ? 0.f : -INFINITY;
+  __shared__ int s_lastw[4];  // per wave: the last attended key it saw (-1: none)
+  constexpr bool skip_tail = TAIL;  // (the ragged layout has no masked tail: nkt already follows the length; its instantiation carries none of this)
+  int mylast = -1;
+  for (int i0 = 0; i0 < nkt * 16; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const bool on = i < nkt * 16 && i < Lr && keymask[(size_t)row0 + i];
+    if (i < nkt * 16) sBias[i] = on ? 0.f : -INFINITY;
+    if (skip_tail) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+      if (m != 0) mylast = i0 + (int)(threadIdx.x & ~63u) + 63 - __builtin_clzll(m);
+    }
+  }
+  if (skip_tail && (threadIdx.x & 63) == 0) s_lastw[threadIdx.x >> 6] = mylast;
   __syncthreads();
+  const int s_last = skip_tail ? max(max(s_lastw[0], s_lastw[1]), max(s_lastw[2], s_lastw[3])) : -1;
+  // key tiles behind the last attended key hold only masked keys (the padded tail of a dense [B, S] batch): their probabilities are
+  // exactly zero, so they are not computed at all -- same bits, S x len instead of S x S work per head
+  if (skip_tail) nkt = min(nkt, max(2, ((s_last >> 4) + 2) & ~1));
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   // scores in the log2 domain: exp(x - m) = exp2(x * log2e - m * log2e), one v_exp_f32 and no extra multiply
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 // the A operand of  dQ[q tile] += dS[q, keys] . K[keys, :]  (16x16x16 MFMA, contraction over the block's 16 keys, K^T
 // fragments loaded once per block).  No cross-wave sums at all -- the LDS float atomics a key-block-per-wave split needs
 // for dQ ran at ~50 cycles per instruction (690 us per launch).  Workgroup = the HP heads that share the LDS images.
-template <int DH, int HP, int NQT, bool DROP>
+template <int DH, int HP, int NQT, bool DROP, bool TAIL>  // TAIL: dense layout, trailing masked key blocks are skipped
 __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                             const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                             const float* __restrict__ lse, bf16* __restrict__ dqkv, int S, int A, DropCfg drop,
@@ -581,6 +601,7 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
   const T* dob0 = dctx + (size_t)row0 * H + h0 * DH;
   const T* ob0 = ctx + (size_t)row0 * H + h0 * DH;
+  __shared__ int s_lastw[HP];  // per wave: the last attended key it saw (-1: none)
   {
     // Q, dO images and delta = rowsum(dO . O) in one batch: the thread that stages chunk (row, c) of dO also loads the same
     // chunk of O; the DH/8 chunks of a head's row sit in adjacent lanes
@@ -594,11 +615,20 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
       vd[it] = live ? *reinterpret_cast<const uint4*>(dob0 + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
       vo[it] = live ? *reinterpret_cast<const uint4*>(ob0 + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
     }
-    for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) {
-      sM[i] = i < Lr ? keymask[(size_t)row0 + i] : 0;
+    int mylast = -1;
+    for (int i0 = 0; i0 < nt * 16; i0 += blockDim.x) {
+      const int i = i0 + threadIdx.x;
+      const bool on = i < nt * 16 && i < Lr && keymask[(size_t)row0 + i] != 0;
+      if constexpr (TAIL) {  // dense layout: where the document's attended keys end
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+        if (m != 0) mylast = i0 + (int)(threadIdx.x & ~63u) + 63 - __builtin_clzll(m);
+      }
+      if (i >= nt * 16) continue;
+      sM[i] = on ? 1 : 0;
 #pragma unroll
       for (int hh = 0; hh < HP; ++hh) sLse0[hh * S + i] = i < Lr ? lse[(size_t)(b * A + h0 + hh) * S + i] * 1.4426950408889634f : 0.f;
     }
+    if (TAIL && (threadIdx.x & 63) == 0) s_lastw[threadIdx.x >> 6] = mylast;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int idx = threadIdx.x + it * blockDim.x, r = idx / CPR, c = idx % CPR;
@@ -640,7 +670,23 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 #pragma unroll
     for (int dt = 0; dt < DH / 16; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kb = 0; kb < nblk; ++kb) {
+  // key blocks behind the last attended key (the padded tail of a dense batch) get dK = dV = 0 and contribute nothing to dQ
+  int nblk_on = nblk;
+  if constexpr (TAIL) {
+    int s_last = -1;
+#pragma unroll
+    for (int i = 0; i < HP; ++i) s_last = max(s_last, s_lastw[i]);
+    nblk_on = min(nblk, (s_last >> 4) + 1);
+  }
+  for (int kb = nblk_on; kb < nblk; ++kb) {
+    const int key = kb * 16 + li;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      store4<T>(dq_out + (size_t)key * ld + 2 * H + dt * 16 + 4 * g, f32x4{0.f, 0.f, 0.f, 0.f});
+      store4<T>(dq_out + (size_t)key * ld + H + dt * 16 + 4 * g, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+  for (int kb = 0; kb < nblk_on; ++kb) {
     const int key = kb * 16 + li;
     bf16x8 fk[NKS], fv[NKS];
 #pragma unroll
@@ -737,14 +783,18 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = fwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
-    auto kern = d.thresh16 ? attn_fwd_kernel<T, DH, NKT, 2, true> : attn_fwd_kernel<T, DH, NKT, 2, false>;
+    const bool tail = ATTN_SKIP && doc_off == nullptr;
+    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true> : attn_fwd_kernel<T, DH, NKT, 2, true, false>)
+                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true> : attn_fwd_kernel<T, DH, NKT, 2, false, false>);
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
     return SM_OK;
   }
   const size_t lds = fwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
-  auto kern = d.thresh16 ? attn_fwd_kernel<T, DH, NKT, 1, true> : attn_fwd_kernel<T, DH, NKT, 1, false>;
+  const bool tail = ATTN_SKIP && doc_off == nullptr;
+  auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 1, true, true> : attn_fwd_kernel<T, DH, NKT, 1, true, false>)
+                         : (tail ? attn_fwd_kernel<T, DH, NKT, 1, false, true> : attn_fwd_kernel<T, DH, NKT, 1, false, false>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
@@ -753,7 +803,9 @@ template <int DH, int HP>
 int launch_bwd1(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                 int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
   const size_t lds = bwd1_lds<DH, HP>(S);
-  auto kern = d.thresh16 ? attn_bwd1_kernel<DH, HP, 8, true> : attn_bwd1_kernel<DH, HP, 8, false>;
+  const bool tail = ATTN_SKIP && doc_off == nullptr;
+  auto kern = d.thresh16 ? (tail ? attn_bwd1_kernel<DH, HP, 8, true, true> : attn_bwd1_kernel<DH, HP, 8, true, false>)
+                         : (tail ? attn_bwd1_kernel<DH, HP, 8, false, true> : attn_bwd1_kernel<DH, HP, 8, false, false>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A / HP), dim3(64 * HP), lds, st, (const bf16*)qkv, km, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, S, A, d,
                      doc_off);

@@ -357,6 +357,39 @@ def test_attention_fwd_bwd(ops, dtype, B, S, A, dh):
     close(dqkv, xr.grad, tol * 2, "dqkv")
 
 
+def test_attention_dense_layout_skips_only_the_masked_tail(ops):
+    """dense [B, S] batches: key tiles behind the LAST attended key are not computed (their probabilities are exactly zero).  Masks that
+    are not prefixes (holes, a single attended key at the end, nothing attended at all, lengths on and off the 16 / 32 boundaries)
+    must give the same context rows and gradients as the full computation"""
+    B, S, A, dh = 8, 128, 2, 32
+    H = A * dh
+    dtype = torch.bfloat16
+    qkv = q(rnd(B * S, 3 * H, seed=1), dtype)
+    mask = torch.zeros(B, S, dtype=torch.uint8)
+    mask[0, :] = 1
+    mask[1, :16] = 1
+    mask[2, :33] = 1
+    mask[3, :96] = 1
+    mask[3, 20:70] = 0            # a hole
+    mask[4, 127] = 1              # only the last key
+    mask[5, :1] = 1               # only the first key
+    mask[6, :64] = 1
+    # document 7: nothing attended
+    dctx = q(rnd(B * S, H, seed=2), dtype) * mask.view(-1, 1)
+    ctx, lse = ops.attention_fwd(dev(qkv, dtype), dev(mask), B, S, A)
+    dqkv = ops.attention_bwd(dev(qkv, dtype), dev(mask), ctx, dev(dctx, dtype), lse, B, S, A)
+    live = [b for b in range(B) if int(mask[b].sum()) > 0]
+    xr = qkv.clone().requires_grad_(True)
+    sel = torch.cat([torch.arange(b * S, (b + 1) * S) for b in live])
+    cr, _ = ref_attention(xr[sel], mask[live], len(live), S, A, dh)
+    tol = TOL[dtype] * 2
+    close(ctx.float().cpu()[sel], cr, tol, "ctx")
+    (cr * dctx[sel]).sum().backward()
+    close(dqkv.float().cpu()[sel], xr.grad[sel], tol * 2, "dqkv")
+    assert float(ctx.float().cpu()[7 * S:].abs().max()) == 0.0 and float(dqkv.float().cpu()[7 * S:].abs().max()) == 0.0
+    assert bool(torch.isfinite(dqkv.float()).all())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_dropout_consistent_between_fwd_and_bwd(ops, dtype):
     """finite-difference-free check: with dropout the backward must be the exact gradient of

@@ -1,6 +1,9 @@
 """Stand-alone timing of the attention kernels at the bench's ragged shapes (v2-mini: 12 heads x 32)."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "opensearch-sparse-model-tuning-sample_amd"))
+from sparse_hip import lib as _L
+if os.environ.get("SM_LIB"):
+    _L._LIB_PATH = os.environ["SM_LIB"]
 from sparse_hip import ops, lib
 rng = np.random.default_rng(0)
 B, A, dh, S = 512, int(os.environ.get("A", 12)), int(os.environ.get("DH", 32)), int(os.environ.get("S", 128))
@@ -29,3 +32,13 @@ for p in (0.0, 0.1):
     ub = timeit(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, B, S, A, drop, rag))
     fl = tiles * 256 * dh * 2
     print(f"p={p}: rows={rows} fwd {uf:.1f} us ({2*fl/uf/1e6:.0f} TF/s)  bwd {ub:.1f} us ({7*fl/ub/1e6:.0f} TF/s)")
+# the DENSE layout of the same documents: [B, S] rows, padding keys masked (trailing masked key tiles are skipped)
+qkv_d = torch.randn(B * S, 3 * H, device='cuda').bfloat16(); dctx_d = torch.randn(B * S, H, device='cuda').bfloat16()
+mask_d = dev(np.arange(S)[None, :] < lens[:, None], torch.uint8)
+dctx_d = dctx_d * mask_d.view(-1, 1).to(dctx_d.dtype)  # padded query rows receive no gradient
+for p in (0.0, 0.1):
+    drop = lib.dropout(p, 5, 9) if p else None
+    ctx, lse = ops.attention_fwd(qkv_d, mask_d, B, S, A, drop)
+    uf = timeit(lambda: ops.attention_fwd(qkv_d, mask_d, B, S, A, drop))
+    ub = timeit(lambda: ops.attention_bwd(qkv_d, mask_d, ctx, dctx_d, lse, B, S, A, drop))
+    print(f"dense layout p={p}: rows={B*S} fwd {uf:.1f} us  bwd {ub:.1f} us")
