@@ -533,7 +533,7 @@ def main():
                                f"documents (lengths ~N(80,30) in [16,{args.seq}]) padded to {args.seq} by the collator; `value` is the "
                                + (f"ragged layout: padding tokens skipped on the device ({T:.0f} of {T_padded} token rows computed per step, "
                                   "identical outputs); value_dense_layout computes all of them" if args.layout == "ragged" else
-                                  f"dense layout: all {T_padded} token rows computed; value_ragged_layout skips padding tokens"),
+                                  f"dense layout: all {T_padded} token rows computed (attention skips key tiles that hold only masked keys: exact); value_ragged_layout skips padding tokens"),
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
                    "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks over RCCL, exchange mode "
                                                       + os.environ.get("SM_EXCHANGE", "scores") + ": scores = all-gather of the queries (under "
