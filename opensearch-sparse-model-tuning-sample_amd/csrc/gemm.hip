@@ -1080,6 +1080,7 @@ __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
   return v;
 }
 __device__ __forceinline__ void lds_w16(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_w32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
 __device__ __forceinline__ bf16x4 pack4(f32x4 v) {
   bf16x4 o;
@@ -1977,7 +1978,11 @@ extern "C" int sm_sparse_head_fwd(int dtype, const void* t, const void* E, const
 // ---------------------------------------------------------------------------------------
 constexpr int DT_R = 192, DT_C = 384, DT_NST = 4, DT_ESTAGE = 3 * TG_STAGE, DT_G = DT_R * 64, DT_MAXDOC = 12;
 constexpr int DT_CSLOT = 3 * 512 * 4;  // per step: grad_rep, rep, argmax-pair words of the 512 (document, column) slots
-constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT;
+#ifndef DT_SKIP
+#define DT_SKIP 1
+#endif
+constexpr int DT_FLAGS = 16;  // two step tags: "the G image of step k holds a non-zero" (k + 1 in word k & 1)
+constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT + DT_FLAGS;
 
 template <bool LNF>
 __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
@@ -1992,6 +1997,7 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   char* const sE = smem;
   char* const sG = smem + DT_NST * DT_ESTAGE;
   char* const sC = sG + 2 * DT_G;
+  char* const sF = sC + DT_NST * DT_CSLOT;
   const bool ragged = doc_off != nullptr;
   const int Ttot = ragged ? rag_rows : Bdocs * S;
   const int m0 = blockIdx.y * DT_R, n0 = blockIdx.x * DT_C;
@@ -2022,7 +2028,9 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
 
   // zero both G images before any DMA is in flight (plain stores: the compiler may order them as it likes here)
   for (int i = tid; i < 2 * DT_G / 16; i += 512) reinterpret_cast<uint4*>(sG)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < DT_FLAGS / 4) reinterpret_cast<uint32_t*>(sF)[tid] = 0u;
   __syncthreads();
+  const uint32_t fbase = (uint32_t)(uintptr_t)(lds_char*)sF;
 
   // ---- E loader: 24 one-KiB pieces per stage, 3 per wave ----
   const bf16* esrc[3];
@@ -2081,6 +2089,9 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     if (prev >= 0) lds_w16(base + prev, 0u);
     if (off >= 0) lds_w16(base + off, val);
     prev = off;
+    // a step whose G slice is all zero (no gradient in these 32 columns for the tile's documents: the usual case once the model is
+    // sparse) skips its MFMAs: any wave that wrote a non-zero tags the step (same value from every writer)
+    if (__builtin_amdgcn_ballot_w64(off >= 0) != 0) lds_w32(fbase + (k & 1) * 4, (uint32_t)(k + 1));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
@@ -2120,6 +2131,8 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     issue_e(k + 3);
     // 2. this step's fragments and MFMAs
     const uint32_t so = (uint32_t)((k % DT_NST) * DT_ESTAGE), go = (uint32_t)((k & 1) * DT_G);
+    // the step's tag first: it is the oldest LDS read, so it has landed by the first fragment wait at no extra latency
+    uint32_t tag = lds_r32(fbase + (k & 1) * 4);
     bf16x8 fa[6];
     TgFrag fb[6];
 #pragma unroll
@@ -2132,19 +2145,24 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     // first half of the MFMAs as soon as fa and fb[0..2] are here; the reads of fb[3..5] land underneath them
     asm volatile("s_waitcnt lgkmcnt(6)"
                  : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0].v), "+v"(fb[1].v),
-                   "+v"(fb[2].v)
+                   "+v"(fb[2].v), "+v"(tag)
                  :
                  : "memory");
+    const bool live = !DT_SKIP || __builtin_amdgcn_readfirstlane(tag) == (uint32_t)(k + 1);  // (workgroup-uniform)
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[3].v), "+v"(fb[4].v), "+v"(fb[5].v) : : "memory");
+    if (live) {
 #pragma unroll
-    for (int j = 3; j < 6; ++j)
+      for (int j = 3; j < 6; ++j)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].v, fa[i], acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // 3. the columns of step k+1 have exactly 9 younger loads behind them (E k+2, columns k+2, E k+3): once
     //    they are here so is everything older -- including E stage k+1, which the next step reads

@@ -180,9 +180,50 @@ def test_gemm_nt_residual_recomputed_from_the_layernorm_input(ops):
         assert got.dtype == torch.float32 and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), (M, K)
 
 
-def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops):
+@pytest.mark.parametrize("density", [0.0, 0.002, 0.05])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_head_dt_with_few_live_activations_skips_steps_without_changing_the_sum(ops, density, ragged):
+    """dt = G . E (head_dt192_kernel) skips the MFMAs of a 32-column step whose G slice is all zero for the tile's documents -- the
+    common step once the model is sparse.  Against a float64 evaluation of the routed sum: a few live columns, whole documents
+    without any, runs of live columns next to runs of dead ones, nothing alive at all; dense and ragged rows"""
+    dtype = torch.bfloat16
+    H, V = 384, 4000
+    g = torch.Generator().manual_seed(int(density * 1e4) + ragged)
+    if ragged:
+        lens = [37, 128, 16, 90, 5, 64, 128, 77]
+        _, off_np, rows, row_doc, pos, _ = _ragged(lens)
+        B, S = len(lens), 128
+        rag = ops.Ragged(dev(off_np.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, S)
+        off = off_np.tolist()
+    else:
+        B, S, rag = 7, 128, None
+        lens, off, rows = [S] * B, [i * S for i in range(B + 1)], B * S
+    E = torch.randn(V, H, generator=g).mul(0.2).to(dtype)
+    rep = (torch.rand(B, V, generator=g) + 0.05) * (torch.rand(B, V, generator=g) < density)
+    rep[1, 640:704] = 0.3            # a run of live columns in one document
+    rep[2] = 0.0                     # a document without any
+    if density == 0.0:
+        rep.zero_()
+    grad = torch.randn(B, V, generator=g)
+    am = torch.stack([torch.randint(0, lens[b], (V,), generator=g) for b in range(B)]).to(torch.int16)
+    dt = ops.sparse_head_bwd(dev(grad), dev(rep), dev(am).view(torch.uint16), torch.empty(rows, H, device="cuda", dtype=dtype), dev(E, dtype), None, None,
+                             B, S, V, False, rag, part="dt")
+    gr = grad.double() * torch.where(rep > 0, torch.exp(-rep.double()), torch.zeros(B, V, dtype=torch.float64))
+    want = torch.zeros(rows, H, dtype=torch.float64)
+    for b in range(B):
+        want.index_add_(0, off[b] + am[b].long(), gr[b][:, None] * E.double())
+    scale = max(float(want.abs().max()), 1e-6)
+    # (the kernel rounds G to bf16 and its result to bf16)
+    assert float((dt.float().cpu().double()[:rows] - want).abs().max()) <= 1.2e-2 * scale, density
+    if density == 0.0:
+        assert float(dt.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("live", [1.0, 0.01])
+def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops, live):
     """dt = G.E never goes to HBM: LayerNorm' and GELU' of the head transform run in the kernel's epilogue (bf16, H = 384);
-    against sparse_head_bwd(dt) -> layernorm_bwd -> gelu_bwd"""
+    against sparse_head_bwd(dt) -> layernorm_bwd -> gelu_bwd.  live = 0.01: gradient on 1 % of the entries only (most 32-column steps
+    are skipped by both forms)"""
     dtype = torch.bfloat16
     B, S, H, V = 24, 128, 384, 3000
     t = q(rnd(B * S, H, seed=1), dtype)
@@ -190,7 +231,7 @@ def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops)
     bias = 0.1 * rnd(V, seed=3)
     mask = (torch.arange(S)[None, :] < torch.randint(20, S + 1, (B, 1), generator=torch.Generator().manual_seed(4))).to(torch.uint8)
     rep, argmax = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask, torch.uint8), B, S, V, False, None)
-    grad_rep = dev(rnd(B, V, seed=5).abs())
+    grad_rep = dev(rnd(B, V, seed=5).abs() * (torch.rand(B, V, generator=torch.Generator().manual_seed(11)) < live))
     gt = q(rnd(B * S, H, seed=6, scale=1.5), dtype)   # LayerNorm input
     ft = q(rnd(B * S, H, seed=7), dtype)              # GELU input
     gamma, beta = 1.0 + 0.1 * rnd(H, seed=8), 0.1 * rnd(H, seed=9)

@@ -4,6 +4,9 @@ form of dt (LDS accumulators, owner waves) with the matrix-pipe kernel: profiles
 import os, sys, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opensearch-sparse-model-tuning-sample_amd")]
+from sparse_hip import lib as _L
+if os.environ.get("SM_LIB"):
+    _L._LIB_PATH = os.environ["SM_LIB"]
 from sparse_hip import ops
 dev = torch.device("cuda", 0)
 V, H = 30522, 384

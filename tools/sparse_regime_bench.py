@@ -5,6 +5,9 @@ documents without a live row.   python3 tools/sparse_regime_bench.py [density=0.
 import os, sys, time, types, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "opensearch-sparse-model-tuning-sample_amd")]
+from sparse_hip import lib as _L
+if os.environ.get("SM_LIB"):
+    _L._LIB_PATH = os.environ["SM_LIB"]
 import bench
 density = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
 layout = sys.argv[2] if len(sys.argv) > 2 else "dense"
