@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 4
+#define SM_ABI_VERSION 5
 #define SM_F32 0
 #define SM_BF16 1
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
@@ -138,6 +138,24 @@ int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, fl
 int sm_gemm_tn_acc_bcm(const void* A, int a_bcm, const void* B, int b_bcm, float* C, int ldc, int M, int N, int Kc, float* colsum,
                        void* stream);
 
+/* GROUPED weight gradients (ABI 5): the products of up to 6 nn.Linear layers that share the token dimension M -- the four of an
+ * encoder layer: QKV, attention output, FFN up, FFN down (hf:175-177, :290, :335, :348 backward) -- in ONE launch of about one
+ * workgroup per CU (csrc/gemm_tn2.hip: [192 x 192] tiles, bf16, every N and Kc a multiple of 192).  Per problem the same contract
+ * as sm_gemm_tn_acc / sm_gemm_tn_acc_bcm: C[N,Kc] += A[M,N]^T . B[M,Kc] (fp32 atomics), colsum[N] += column sums of A (may be
+ * NULL); a_bcm / b_bcm = 1: that operand is block-column-major and dense (its ld is ignored).  Returns 0 when the grouped kernel
+ * ran, 1 when a problem is not eligible (run the per-problem entry points instead), < 0 on error. */
+typedef struct sm_tn_problem {
+  const void* A;
+  int lda, a_bcm;
+  const void* B;
+  int ldb, b_bcm;
+  float* C;
+  int ldc;
+  int N, Kc;
+  float* colsum;
+} sm_tn_problem;
+int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, void* stream);
+
 /* ---- fused feed-forward block, hidden size 384, fp32 residual stream (hf:334-351: intermediate.dense -> GELU ->
  * output.dense -> dropout -> + residual -> LayerNorm, together with the attention-output LayerNorm hf:293 in front of it) in
  * PRODUCER / CONSUMER form (csrc/ffn_pc.hip: a pair of waves per 32 tokens, 32x32x16 MFMAs, weights staged fragment-major so that
@@ -163,8 +181,10 @@ int sm_ffn_pc_fwd(int op_f16, const float* z1, const float* ln1_g, const float* 
                   const void* w2f, const float* bias2, const float* ln2_g, const float* ln2_b, const sm_dropout* drop, void* x1,
                   float* m1, float* r1, void* f1, float* z2, void* x2, float* m2, float* r2, int T, int H, int I, void* stream);
 /* backward of the block (bf16 operands), one launch for what the unfused path runs as the dF1 GEMM + the GEMM fused with the
- * LayerNorm-1 backward: dF1 = (dy W2) * gelu'(f1) and ga = gelu(f1), both [T, I] ROW-major, written once for the two
- * weight-gradient GEMMs (dF1 is not read back: the second GEMM consumes it on the chip);  dx1 = dF1 W1 + dres;
+ * LayerNorm-1 backward: dF1 = (dy W2) * gelu'(f1) and ga = gelu(f1), both [T, I] in the BLOCK-COLUMN-MAJOR layout
+ * [ceil(T / 128) * 4][I / 8][32][8] -- element (r, c) at (((r >> 5) * (I >> 3) + (c >> 3)) * 32 + (r & 31)) * 8 + (c & 7) -- written
+ * once for the two weight-gradient GEMMs, which read that layout through sm_gemm_tn_acc_bcm / sm_gemm_tn_group (a_bcm / b_bcm);
+ * sm_gemm_tn_acc would misread it (dF1 is not read back by this kernel: the second GEMM consumes it on the chip);  dx1 = dF1 W1 + dres;
  * dz1 = LN'(dx1 | z1, ln1_g, m1, r1), dz1d = dropout_bwd(dz1; drop) (NULL: not wanted); dgamma / dbeta accumulated (atomics).
  * The dF1 / ga buffers must hold WHOLE 128-row blocks (ceil(T / 128) * 128 rows): the kernel stores the rows past T as well.
  * dy = the gradient w.r.t. the block's output behind its dropout backward, dres (may be NULL) the residual branch's;

@@ -612,8 +612,8 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
 //   producer (waves 0-3): dy^T of its 32 tokens resident as B fragments; per chunk of 32 intermediate columns
 //                         dG^T = W2^T_c . dy^T (24 MFMAs 32x32x16, A = the fragment-major rows of W2^T: w2tf), then value and
 //                         derivative of the forward's sigmoid-form GELU from the forward's tile-major f1 (the lane's 16 accumulator
-//                         registers <-> 32 contiguous bytes), dF1 / ga to memory (row-major: the weight-gradient GEMMs read
-//                         them through LDS-DMA panels) and the two B fragments of dF1^T to the consumer through LDS;
+//                         registers <-> 32 contiguous bytes), dF1 / ga to memory (BLOCK-COLUMN-MAJOR, [T / 32][I / 8][32][8]: a wave's
+//                         store is 512 contiguous bytes; the weight-gradient GEMMs read that layout through LDS-DMA panels) and the two B fragments of dF1^T to the consumer through LDS;
 //   consumer (waves 4-7): dx1^T [384 x 32 tokens] += W1^T_c . dF1^T (A = w1tf, k permuted like the forward's W2), all LDS-DMA;
 //   epilogue:             the consumers write the bf16 image of dx1 [128 rows][384] into the idle rings; all eight waves run the
 //                         LayerNorm backward on it, a row per 16 lanes (+ dres, statistics from the forward, dropout backward of
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
   // (gelu_sig_both of common.h) cut into FOUR stages spread over gaps e .. e + 3 -- (A) x^2, both polynomials, the exponent;
   // (B) exp2 and 1 + e; (C) rcp; (D) value, derivative, product -- so that every gap carries four independent chains of a few
   // instructions instead of one of sixteen with two transcendentals in it (a dependent vector instruction waits ~8 cycles for its
-  // operand, a transcendental more).  Then the two B fragments of dF1^T for the consumer and the row-major stores
+  // operand, a transcendental more).  Then the two B fragments of dF1^T for the consumer and the block-column-major stores
   // (register 4 q + k <-> column 32 c + 8 q + 4 hh + k of the lane's token).
   float o[16], og[16], s_bu[4], s_du[4], s_e[4], s_r[4];
   V glo, ghi;

@@ -458,7 +458,7 @@ struct __attribute__((packed, aligned(4))) DeRow { uint32_t w[NC / 2]; };
 template <int NC, int RPW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_de_rows_kernel(
     const float* __restrict__ grad_rep, const float* __restrict__ rep, const uint16_t* __restrict__ argmax, const bf16* __restrict__ t,
-    float* __restrict__ dE, float* __restrict__ dbias, int B, int S, int V, int use_l0, const int32_t* __restrict__ doc_off) {
+    float* __restrict__ dE, float* __restrict__ dbias, int B, int S, int V, int use_l0, const int32_t* __restrict__ doc_off, int trows) {
   constexpr int H = 64 * NC, G = 64 / RPW;  // G documents per group of column words
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int v0 = (blockIdx.x * 8 + w) * RPW;
@@ -490,7 +490,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float gr = c.g * head_fprime(c.r, use_l0);
     if (!vok || q * G + ldoc >= B) gr = 0.f;
     gv = gr;
-    ov = (uint32_t)(c.row0 + (gr != 0.f ? (int)c.a : 0)) * (uint32_t)(2 * H);  // (the launcher checks that t is below 4 GiB)
+    // the routed row, clamped into t: a non-finite gradient on a dead column (inf * 0 = NaN != 0) would otherwise route an unset
+    // arg-max word, and an empty trailing document of a ragged batch starts at row `trows`
+    ov = (uint32_t)min(c.row0 + (gr != 0.f ? (int)c.a : 0), trows - 1) * (uint32_t)(2 * H);  // (the launcher checks that t is below 4 GiB)
   };
 
   const int nq = (B + G - 1) / G;
@@ -571,7 +573,7 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
     const int32_t* doc_off = rag ? rag->doc_off : nullptr;
 #define LAUNCH_ROWS(NC, RPW)                                                                                                         \
   hipLaunchKernelGGL((head_de_rows_kernel<NC, RPW>), dim3(sm_cdiv(V, 8 * RPW)), dim3(512), 0, st_de, grad_rep, rep, argmax, (const bf16*)t, dE, \
-                     dbias, B, S, V, use_l0, doc_off)
+                     dbias, B, S, V, use_l0, doc_off, rag ? rag->rows : B * S)
     switch (H / 64) {
       case 2: LAUNCH_ROWS(2, 16); break;
       case 4: LAUNCH_ROWS(4, 16); break;

@@ -538,6 +538,7 @@ class SparseModelTrainer:
             if len(self._step_done) >= 2:
                 self._step_done.pop(0).synchronize()
         bb.set_dropout_seed(self.args.seed * 1000003 + self.state.global_step * 64 + self.accelerator.process_index)
+        bb.check_finite = bool(getattr(self.args, "check_finite", False) or _CHECK_FINITE)
         with _trace_range("forward+loss"):
             loss = self.compute_loss(self.model, inputs)
         with _trace_range("backward"):

@@ -190,6 +190,7 @@ KERNEL_OPTIONS = {
     "ffn_fwd_f16": ("SM_FFN_FWD_F16", None, bool),            # fp16 operands of the UNFUSED feed-forward forward; None: models of >= 10 layers
     "fp8_delayed": ("SM_FP8_DELAYED", True, bool),            # fp8 runs: previous step's maxima as scales from step 2 on
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
+    "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
     "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
     "pc_infer_min_rows": ("SM_PC_INFER_MIN_ROWS", 6144, int),  # no-grad forwards below this many rows: unfused feed-forward launches
@@ -229,7 +230,7 @@ class HipBertMLM(torch.nn.Module):
         H = cfg.hidden_size
         # Fused feed-forward FORWARD (csrc/ffn_pc.hip: LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2 in one
         # producer / consumer launch, 195-215 us against 250-265 us of the unfused launches at 43.9 k rows): bf16 runs with the fp32
-        # residual stream at hidden size 384; the backward stays unfused and reads the kernel's tile-major f1 in the dF1 epilogue.
+        # residual stream at hidden size 384; the backward is fused the same way (pc_ffn_bwd below).
         # ffn_f16: its operands are fp16 instead of bf16 (same MFMA rate, three more mantissa bits; gradients stay bf16).
         # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_fused_gpu.py).
         # Both numerics-relevant defaults are constructor arguments (ModelArguments.fused_ffn / fwd_f16, logged at start-up); the
@@ -240,7 +241,9 @@ class HipBertMLM(torch.nn.Module):
                        and cfg.intermediate_size >= 128 and want_pc)
         # ... and its BACKWARD in the same form (one launch for the dF1 GEMM + the GEMM fused with the LayerNorm-1 backward: dF1 is
         # consumed on the chip by the second GEMM instead of being read back); SM_PC_FFN_BWD=0 keeps the two launches
-        self.pc_ffn_bwd = self.pc_ffn and opt("pc_ffn_bwd")
+        # (its dF1 / gelu(f1) outputs are block-column-major and only the weight-gradient kernels that need whole 128-column tiles
+        # read that layout: intermediate sizes that are not multiples of 128 keep the unfused backward)
+        self.pc_ffn_bwd = self.pc_ffn and opt("pc_ffn_bwd") and cfg.intermediate_size % 128 == 0
         # fp16 FORWARD operands for the precision-critical GEMMs of a bf16 run (same MFMA rate, 11 significant bits instead of 8;
         # the backward and everything it reads stay bf16): the error budget of the sparse activations against the fp32 reference
         # (tools/bf16_error_budget.py) puts 32 % of the variance in the head (transform + decoder operands) and 44 % in the
@@ -302,6 +305,7 @@ class HipBertMLM(torch.nn.Module):
         self.graph_encode = opt("encode_graph")
         self.graph_tokens = opt("encode_graph_tokens")
         self.wgrad_stream = opt("wgrad_stream")
+        self.tn_group = opt("tn_group")
         self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
@@ -432,7 +436,7 @@ class HipBertMLM(torch.nn.Module):
     def kernel_options(self) -> dict:
         """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
         return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
-                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "encode_graph": self.graph_encode,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "encode_graph": self.graph_encode,
                 "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
 
     def sync_weights(self) -> None:
@@ -587,7 +591,9 @@ class HipBertMLM(torch.nn.Module):
             # (a no-grad forward of fewer than pc_infer_min_rows token rows takes the unfused launches: one fused workgroup walks all
             # of W1 / W2 for its 128 rows -- 69 us per layer however few rows there are -- where the plain GEMMs spread the columns
             # over the chip: 397 us against 597 us for a single 32-token query, level at about 6 k rows; profiles/r4_encode_latency.txt)
-            if self.pc_ffn and z1.shape[0] % 16 == 0 and (save or z1.shape[0] >= self.pc_infer_min_rows):
+            # ONLY inference takes that detour: a training-mode forward without grad is pass 1 of rep-level gradient caching, which
+            # pass 2 (grad on, fused kernel, sigmoid-form GELU) must replay bit for bit
+            if self.pc_ffn and z1.shape[0] % 16 == 0 and (save or training or z1.shape[0] >= self.pc_infer_min_rows):
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
                 g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
                 fused = ops.ffn_pc_fwd(z1, g1, b1, eps, st["pc_w1f"][l], v(p + "intermediate.dense.bias"), st["pc_w2f"][l],
@@ -602,7 +608,9 @@ class HipBertMLM(torch.nn.Module):
                 x = x2
                 continue
             # fp16 feed-forward operands: where the model asks for them, and in the small no-grad forwards that bypass the fused
-            # kernel above (whose operands are fp16 too: the precision of an inference does not depend on the batch size)
+            # kernel above (whose operands are fp16 too, so the OPERAND precision of an inference does not depend on the batch size;
+            # the activation does: these launches evaluate the exact-erf GELU, the fused kernel its sigmoid-form fit, |diff| <= 2.6e-5
+            # per activation -- encodings of one document in a small and in a large batch agree to 2e-3, tests/test_e2e_gpu.py)
             f16_ffn = self.ffn_fwd_f16 or (not save and self.pc_ffn and self.ffn_f16 and self.fwd_f16)
             x1h = None
             if r32:
@@ -756,20 +764,66 @@ class _WgradStream:
     packet between two kernels of the backward chain costs it ~12 us (step timeline: 34 us gaps where two forks sat between two
     GEMMs) -- one fork per layer instead of one per weight gradient."""
 
-    def __init__(self, device, enabled: bool = True):
+    def __init__(self, device, enabled: bool = True, group: bool = True):
         self.stream = torch.cuda.Stream(device=device)
         self.enabled = enabled
-        self.pending = []  # (fn, operands)
+        self.group = group
+        self.pending = []  # (fn, operands) or (None, (a, b, out, colsum)): a plain weight gradient that may join a grouped launch
 
     def run(self, a: Tensor, b: Tensor, out: Tensor, colsum: Optional[Tensor]):
-        if not self.enabled:
+        if not self.enabled and not self.group:
             ops.gemm_tn_acc(a, b, out, colsum=colsum)
             return
-        self.pending.append((lambda: ops.gemm_tn_acc(a, b, out, colsum=colsum), (a, b)))
+        self.pending.append((None, (a, b, out, colsum)))
+
+    @staticmethod
+    def _plan_groups(tiles):
+        """consecutive groups of the pending products (tiles[i] = number of [192 x 192] output tiles of product i) for the grouped
+        kernel, which launches tiles * floor(256 / tiles) workgroups: the partition with the fewest idle CU-rounds"""
+        n = len(tiles)
+        best = {n: (0.0, [])}
+        for i in range(n - 1, -1, -1):
+            cand = None
+            t = 0
+            for j in range(i, min(n, i + 6)):
+                t += tiles[j]
+                rounds = -(-t // 256) if t > 256 else 1
+                wgs = t * max(1, 256 // t) if t <= 256 else t
+                cost = t * (256.0 * rounds / wgs) + 6.0  # tile-work inflated by the idle share of the grid + the launch's atomic flush (~6 tiles' time)
+                c = (cost + best[j + 1][0], [(i, j + 1)] + best[j + 1][1])
+                if cand is None or c[0] < cand[0] - 1e-9:
+                    cand = c
+            best[i] = cand
+        return best[0][1]
+
+    def _launch_products(self, prods):
+        """prods: (a, b, out, colsum) tuples, in program order"""
+        if self.group and len(prods) > 0:
+            shapes = [(p[0].shape[1], p[1].shape[1]) for p in prods]
+            if all(n % 192 == 0 and k % 192 == 0 for n, k in shapes):
+                for lo, hi in self._plan_groups([(n // 192) * (k // 192) for n, k in shapes]):
+                    if not ops.gemm_tn_group(prods[lo:hi]):
+                        for a, b, out, colsum in prods[lo:hi]:
+                            ops.gemm_tn_acc(a, b, out, colsum=colsum)
+                return
+        for a, b, out, colsum in prods:
+            ops.gemm_tn_acc(a, b, out, colsum=colsum)
+
+    def _launch_pending(self):
+        run = []
+        for fn, operands in self.pending:
+            if fn is None:
+                run.append(operands)
+                continue
+            self._launch_products(run)
+            run = []
+            fn()
+        self._launch_products(run)
 
     def call(self, fn, *operands: Tensor):
         """any other weight-gradient launch (`fn()` enqueues it) on the side stream, ordered after the main stream so far"""
         if not self.enabled:
+            self.flush()
             fn()
             return
         self.pending.append((fn, operands))
@@ -778,27 +832,30 @@ class _WgradStream:
         """enqueue everything deferred so far on the side stream, ordered after the main stream's work up to here"""
         if not self.pending:
             return
+        if not self.enabled:  # no side stream: the deferral only serves the grouped launch
+            self._launch_pending()
+            self.pending = []
+            return
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            for fn, _ in self.pending:
-                fn()
-        for _, operands in self.pending:
-            for t in operands:
+            self._launch_pending()
+        for fn, operands in self.pending:
+            for t in (operands[:2] if fn is None else operands):
                 t.record_stream(self.stream)  # the caching allocator must not recycle the operands early
         self.pending = []
 
     def join(self):
+        self.flush()
         if self.enabled:
-            self.flush()
             torch.cuda.current_stream().wait_stream(self.stream)
 
     def mark(self):
         """Event after everything handed to the side stream so far (None when the side stream is off): lets
         a consumer on a third stream (the gradient all-reduce) wait for the weight gradients without making
         the backward chain on the main stream wait for them."""
+        self.flush()
         if not self.enabled:
             return None
-        self.flush()
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return ev
@@ -849,6 +906,13 @@ class _EncodeFn(torch.autograd.Function):
                              act=1, preact=ft, out_f32=True)
             tn, _, mt, rt, tn16 = ops.layernorm_fwd_res32(gt, v(c + "transform.LayerNorm.weight"), v(c + "transform.LayerNorm.bias"),
                                                           cfg.layer_norm_eps, x.dtype, want_y32=False, want_y16=True)
+            if model.check_finite:
+                # fp16 has 5 exponent bits: an activation beyond 65 504 becomes inf in the fp16 operand copies (the bf16 path has fp32's
+                # range).  check_finite mode looks at the two fp16 tensors this layer of the code can see and names the remedy.
+                for name, t16 in (("last layer output", xh), ("head transform output", tn16)):
+                    if t16 is not None and not bool(torch.isfinite(t16).all()):
+                        raise FloatingPointError(f"fp16 forward operand overflow in the {name}: activations exceed the fp16 range "
+                                                 "(65504); run this model with fwd_f16=False (ModelArguments.fwd_f16 / SM_FWD_F16=0)")
             rep, argmax = ops.sparse_head_fwd(tn16, st["E16"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
             del tn16
         else:
@@ -881,7 +945,7 @@ class _EncodeFn(torch.autograd.Function):
         c = "cls.predictions."
         e = "bert.embeddings."
         if model._wgrad is None:
-            model._wgrad = _WgradStream(model.device, model.wgrad_stream)
+            model._wgrad = _WgradStream(model.device, model.wgrad_stream, model.tn_group)
         wg = model._wgrad
         grad_rep = grad_rep.contiguous().float()
         # the head backward's two halves: dE / dbias are weight gradients (side stream, like every other one),
@@ -1002,6 +1066,7 @@ class _EncodeFn(torch.autograd.Function):
 
 
 HipBertMLM._layer_hook = None
+HipBertMLM.check_finite = False  # TrainingArguments.check_finite / SM_CHECK_FINITE: also look for fp16 operand overflow in the forward
 HipBertMLM._dropout_without_grad = False
 HipBertMLM._cast_table = None
 HipBertMLM._cast_key = None

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
 SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
-ABI_VERSION = 4  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
+ABI_VERSION = 5  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
 
 
 class SmDropout(C.Structure):
@@ -49,6 +49,11 @@ class SmCastDesc(C.Structure):
                 ("ld_out", C.c_int), ("ld_out_t", C.c_int), ("tile_begin", C.c_int), ("_pad", C.c_int)]
 
 
+class SmTnProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("a_bcm", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("b_bcm", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("N", C.c_int), ("Kc", C.c_int), ("colsum", C.c_void_p)]
+
+
 class SmRagged(C.Structure):
     _fields_ = [("doc_off", C.c_void_p), ("blk_doc", C.c_void_p), ("pos_ids", C.c_void_p), ("rows", C.c_int)]
 
@@ -67,6 +72,7 @@ SIGNATURES = {
     "sm_ffn_pc_fwd": [_i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_ffn_pc_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sm_gemm_tn_acc_bcm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
+    "sm_gemm_tn_group": [_i, C.POINTER(SmTnProblem), _i, _p],
     "sm_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "sm_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _i, _i, _p],
     "sm_layernorm_fwd_res32": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p],

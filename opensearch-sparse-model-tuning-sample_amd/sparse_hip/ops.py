@@ -120,6 +120,39 @@ def gemm_tn_acc(A, B, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def gemm_tn_group(problems) -> bool:
+    """The weight gradients of several linears that share the token dimension in ONE launch (csrc/gemm_tn2.hip): problems = a list
+    of (A, B, out, colsum) with gemm_tn_acc's meaning each.  Returns False without launching anything when a problem is not
+    eligible (not bf16, a dimension that is not a multiple of 192, more than 6 problems): the caller then runs gemm_tn_acc per
+    problem."""
+    n = len(problems)
+    if n == 0 or n > 6:
+        return False
+    arr = (L.SmTnProblem * n)()
+    M = None
+    for i, (A, B, out, colsum) in enumerate(problems):
+        ab, bb = isinstance(A, Bcm), isinstance(B, Bcm)
+        ta, tb = (A.buf if ab else A), (B.buf if bb else B)
+        if ta.dtype != torch.bfloat16 or tb.dtype != torch.bfloat16:
+            return False
+        m, N = A.shape
+        Kc = B.shape[1]
+        if M is None:
+            M = m
+        if m != M or B.shape[0] != M or N % 192 or Kc % 192:
+            return False
+        assert out.dtype == torch.float32 and tuple(out.shape) == (N, Kc) and out.stride(1) == 1
+        if (ab and not ta.is_contiguous()) or (bb and not tb.is_contiguous()):
+            return False
+        if (not ab and (ta.stride(1) != 1 or ta.stride(0) % 8)) or (not bb and (tb.stride(1) != 1 or tb.stride(0) % 8)):
+            return False
+        arr[i] = L.SmTnProblem(ta.data_ptr(), 0 if ab else ta.stride(0), int(ab), tb.data_ptr(), 0 if bb else tb.stride(0), int(bb),
+                               out.data_ptr(), out.stride(0), N, Kc, None if colsum is None else colsum.data_ptr())
+        if not (ta.is_cuda and tb.is_cuda and out.is_cuda):
+            raise L.SparseHipError("sparse_hip kernels need device tensors (no CPU fallback)")
+    return L.call_optional("sm_gemm_tn_group", n, arr, M, L.stream_ptr())
+
+
 # ---------------------------------------------------------------- fp8 operands
 def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None, amax_next: Optional[Tensor] = None):
     """(q, scale, amax): per-tensor fp8 copy of x (bf16 / fp32) and its device-side dequantisation scale, x ~ q * scale.  e4m3fn by

@@ -111,12 +111,14 @@ def _check_grads(dtype, bb, pr, what, pr_unrouted=None, grad_rel=None):
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
                   residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True, fp8=False, fraction_inside=FRACTION_INSIDE,
-                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None, hidden_dropout=0.0, varlen=None):
+                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None, hidden_dropout=0.0, varlen=None, attn_dropout=0.0, trained_like=False):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs.
     hidden_dropout > 0: the three hidden-dropout sites (embeddings, attention output, feed-forward output) run with that
-    probability on the device and the oracle gets the SAME masks (exported through sm_dropout_bwd(ones), DropMasks); the
-    attention-probability dropout stays off (its keep bits are per (document, head) and have no export entry point; its forward /
-    backward consistency is test_e2e_gpu's directional-derivative test).  varlen: False = the dense [B, S] layout."""
+    probability on the device and the oracle gets the SAME masks (exported through sm_dropout_bwd(ones), DropMasks).
+    attn_dropout > 0: the attention-probability dropout too; its keep bits are read back through sm_attention_fwd itself
+    (q = k = 0: uniform probabilities; V = identity blocks: the context IS the dropped probability matrix, _export_attn_masks).
+    varlen: False = the dense [B, S] layout.  trained_like: the statistics of a fine-tuned checkpoint instead of N(0, 0.02)
+    initialisation (_make_trained_like)."""
     from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
     from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
     from scripts.model.sparse_encoders import SparseModel
@@ -125,7 +127,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     from sparse_hip.encoder import BertConfigLite, HipBertMLM
     L, H, A, I = shape
     cfg = BertConfigLite(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A, intermediate_size=I,
-                         max_position_embeddings=512, hidden_dropout_prob=hidden_dropout, attention_probs_dropout_prob=0.0)
+                         max_position_embeddings=512, hidden_dropout_prob=hidden_dropout, attention_probs_dropout_prob=attn_dropout)
     oc = O.BertShape(V, H, L, A, I, 512)
     p = O.init_params(oc, seed=seed, std=std)
     g = torch.Generator().manual_seed(seed + 100)
@@ -134,6 +136,10 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
             p[n] = 0.02 * torch.randn(p[n].shape, generator=g)
         elif n.endswith("LayerNorm.weight"):
             p[n] = 1 + 0.05 * torch.randn(p[n].shape, generator=g)
+    ds = SyntheticTriplesDataset(nq, k, S, Sq, V, seed=seed + 7, len_mean=S * 0.625, len_std=S * 0.234)
+    batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
+    if trained_like:
+        _make_trained_like(p, oc, batch["docs"][0], g)
     bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32, fp8=fp8)
     assert bb.fp8 == bool(fp8)
     bb.load_hf_state_dict(p)
@@ -142,8 +148,6 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     idf = torch.exp(torch.rand(V, generator=g) * 6.6 - 3.9)  # log-uniform in [0.02, 15.6] like idf.json
     use_l0 = bool(recipe.get("use_l0", False))
     model = SparseModel(bb, idf=idf, use_l0=use_l0)
-    ds = SyntheticTriplesDataset(nq, k, S, Sq, V, seed=seed + 7, len_mean=S * 0.625, len_std=S * 0.234)
-    batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
     if teacher_scores is not None:
         batch["scores"] = teacher_scores
     lts = recipe["loss_types"]
@@ -167,9 +171,13 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     loss.backward()
     torch.cuda.synchronize()
     masks = (lambda: None)
-    if hidden_dropout > 0:
+    if hidden_dropout > 0 or attn_dropout > 0:
         assert not grad_cache_chunk
-        site_masks = _export_hidden_masks(bb, inp, hidden_dropout, drop_seed0, nq * k, S, L)
+        site_masks = (_export_hidden_masks(bb, inp, hidden_dropout, drop_seed0, nq * k, S, L) if hidden_dropout > 0
+                      else [None] * (1 + 3 * L))
+        if attn_dropout > 0:
+            for l, m in enumerate(_export_attn_masks(bb, inp, attn_dropout, drop_seed0, nq * k, S, L)):
+                site_masks[1 + 3 * l] = m
         masks = lambda: O.DropMasks(site_masks)
     if grad_cache_chunk:  # the first pass logs one entry per chunk (the second pass repeats them bit for bit)
         nchunks = -(-nq * k // grad_cache_chunk)
@@ -188,6 +196,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     with torch.no_grad():  # what the outputs are compared with: the oracle's own maxima
         od_free = O.sparse_activation(logits, d["attention_mask"], use_l0)
         oloss = O.total_loss(oq, od_free, batch.get("scores"), lc, step, 1)[0]
+        _check_argmax(logits, d["attention_mask"], route, what)
     pr_unrouted = None
     if check_grads:
         # for the GRADIENTS the oracle takes each (doc, vocab) maximum at the position the kernel's came from: a near-tie
@@ -219,6 +228,112 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     if ret is not None:
         ret.update(d_rep=out["d_rep"].detach().float().cpu(), docs=d, params=p, oracle_rep=od_identical, shape=oc)
     return trainer, bb
+
+
+def _check_argmax(logits, attention_mask, route, what, chunk=32):
+    """The device's arg-max positions against the oracle's, INDEPENDENTLY of the routed gradient check (which takes the device's
+    positions as given): wherever a (document, vocabulary) maximum is alive and leads the runner-up position by more than the
+    bf16 error of a logit (2e-2 (1 + |logit|): twice the north-star bound), the device must have picked the same position."""
+    B = logits.shape[0]
+    checked = alive = wrong = 0
+    for b0 in range(0, B, chunk):
+        lg = logits[b0:b0 + chunk].detach()
+        m = attention_mask[b0:b0 + chunk].bool()
+        lg = lg.masked_fill(~m[:, :, None], float("-inf"))
+        top = torch.topk(lg, 2, dim=1)
+        v1, v2, i1 = top.values[:, 0], top.values[:, 1], top.indices[:, 0]
+        live = v1 > 0
+        sure = live & ((v1 - v2) > 2e-2 * (1 + v1.abs()))
+        r = route[b0:b0 + chunk]
+        alive += int(live.sum())
+        checked += int(sure.sum())
+        wrong += int((sure & (r != i1)).sum())
+    print(f"[{what}] arg-max positions: {checked} of {alive} live maxima lead by more than the bf16 error; {wrong} of them differ on the device")
+    assert checked > 0.2 * alive, f"{what}: the arg-max check covers only {checked} of {alive} live maxima"
+    assert wrong == 0, f"{what}: {wrong} arg-max positions differ from the oracle's where its top-2 gap exceeds the bf16 error"
+
+
+def _make_trained_like(p, oc, docs, g, outliers=5, alive=0.01):
+    """Statistics of a fine-tuned sparse encoder (config_infonce.yaml:5 names a trained checkpoint) instead of N(0, 0.02) init:
+    a handful of OUTLIER hidden dimensions (x20 in the embeddings and in the rows that write them into the residual stream),
+    LayerNorm gains of up to 5 on them, and a decoder bias shifted until about 1 % of the (document, vocabulary) activations are
+    alive -- the regime the head kernels' zero-skipping paths and the fp16 operands live in."""
+    H = oc.hidden_size
+    dims = torch.randperm(H, generator=g)[:outliers]
+    p["bert.embeddings.word_embeddings.weight"][:, dims] *= 20.0
+    for n in p:
+        if n.endswith("LayerNorm.weight"):
+            p[n][dims] = 2.0 + 3.0 * torch.rand(outliers, generator=g)
+        if n.endswith("attention.output.dense.weight") or (n.endswith("output.dense.weight") and "attention" not in n):
+            p[n][dims, :] *= 20.0
+    with torch.no_grad():  # calibrate the bias shift on the first documents
+        lg = O.bert_mlm_logits(p, docs["input_ids"][:8], docs["attention_mask"][:8], oc)
+        mx = lg.masked_fill(~docs["attention_mask"][:8].bool()[:, :, None], float("-inf")).max(1).values
+        shift = float(torch.quantile(mx.flatten()[:: max(1, mx.numel() // 1_000_000)], 1.0 - alive))
+    p["cls.predictions.bias"] -= shift
+    print(f"[trained-like] outlier dims {sorted(dims.tolist())}, decoder bias shifted by {-shift:.3f}")
+
+
+def _export_attn_masks(bb, inp, p_attn, drop_seed0, n_docs, S, layers):
+    """keep * scale of the device's attention-probability dropout, [B, A, S(query), S(key)] per layer.  sm_attention_fwd is the
+    export entry point: with q = k = 0 every attended key has probability 1 / len, and with V = the identity block of keys
+    j d .. (j + 1) d - 1 the context row of query q is the DROPPED probability row restricted to those keys -- zero exactly where
+    the keep bit is off.  S / d passes per layer."""
+    from sparse_hip import lib as L
+    from sparse_hip import ops
+    from sparse_hip.encoder import PackedDocs, _Site
+    cfg = bb.config
+    A, H = cfg.num_attention_heads, cfg.hidden_size
+    dh = H // A
+    doc = inp["docs"][0]
+    packed = doc.get("packed")
+    if isinstance(packed, PackedDocs):
+        mask, B, Sp, rag = packed.mask, packed.rag.n_docs, packed.rag.max_len, packed.rag
+    else:
+        _, mask, B, Sp = bb._prep_inputs(doc["input_ids"], doc["attention_mask"])
+        rag = None
+    assert B == n_docs
+    rows = rag.rows if rag is not None else B * Sp
+    seed = (drop_seed0 * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
+    tq = int(p_attn * 256.0 + 0.5)
+    scale = 256.0 / (256.0 - tq)
+    am = doc["attention_mask"].cpu().bool()
+    lens = am.sum(1)
+    if rag is not None:
+        off = rag.doc_off.cpu().long()
+        nrow = off[1:] - off[:-1]
+    else:
+        off = torch.arange(B + 1) * Sp
+        nrow = torch.full((B,), Sp)
+    s_idx = torch.arange(S)
+    rowidx = off[:B, None] + s_idx[None, :]                      # row of (document, position)
+    has_row = s_idx[None, :] < nrow[:, None]
+    out = []
+    for l in range(layers):
+        drop = L.dropout(p_attn, seed, (l + 1) * 4 + _Site.ATTN)
+        keep = torch.ones(B, A, S, S)
+        for j in range((S + dh - 1) // dh):
+            qkv = torch.zeros(rows, 3 * H, dtype=torch.bfloat16)
+            for c in range(dh):
+                s_key = j * dh + c
+                if s_key >= S:
+                    break
+                sel = has_row[:, s_key]
+                r = rowidx[sel, s_key]
+                for h in range(A):
+                    qkv[r, 2 * H + h * dh + c] = 1.0
+            ctx, _ = ops.attention_fwd(qkv.cuda(), mask, B, Sp, A, drop, rag)
+            ctx = ctx.float().cpu()
+            gathered = ctx[rowidx.clamp(max=rows - 1)]               # [B, S(query), H]
+            blk = gathered.view(B, S, A, dh).permute(0, 2, 1, 3)     # [B, A, S(query), dh]
+            n = min(dh, S - j * dh)
+            keep[:, :, :, j * dh:j * dh + n] = (blk[..., :n] != 0).float() * scale
+        valid = (has_row & am)[:, None, :, None] & am[:, None, None, :]          # attended (query, key) pairs that exist on the device
+        frac = float(((keep == 0) & valid).sum()) / max(1, int(valid.sum()))
+        assert abs(frac - tq / 256.0) < 0.02, f"layer {l}: {frac:.4f} of the attention probabilities dropped, expected {tq / 256.0:.4f}"
+        keep = torch.where(valid, keep, torch.ones(()))
+        out.append(keep)
+    return out
 
 
 def _export_hidden_masks(bb, inp, p_drop, drop_seed0, n_docs, S, layers):
@@ -295,7 +410,26 @@ def test_c2_slice_with_hidden_dropout_on_the_same_masks_in_the_oracle(varlen):
     kernels that apply its backward (dx_drop, dy_drop) -- with the device's own masks fed to the oracle.  Ragged layout: a row
     count that is a multiple of 16 only; dense: 16 384 rows (not a multiple of 192)."""
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=6, what=f"c2 slice, hidden dropout 0.1, varlen={varlen}",
-                  hidden_dropout=0.1, varlen=varlen, unrouted_grads=False)
+                  hidden_dropout=0.1, varlen=varlen)
+
+
+@pytest.mark.parametrize("varlen", [True, False])
+def test_c2_slice_with_every_dropout_site_on_as_in_the_bench_step(varlen):
+    """the bench's configuration: hidden dropout 0.1 AND attention-probability dropout 0.1 (hf:63,158,287,345), every mask the device
+    drew fed to the oracle -- outputs, loss, routed and un-routed gradients (round 4 only had a directional-derivative test for the
+    attention site)"""
+    _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=9, what=f"c2 slice, all dropout sites 0.1, varlen={varlen}",
+                  hidden_dropout=0.1, attn_dropout=0.1, varlen=varlen)
+
+
+@pytest.mark.parametrize("varlen", [True, False])
+def test_c2_slice_at_trained_checkpoint_statistics(varlen):
+    """config_infonce.yaml:5 fine-tunes a TRAINED sparse encoder: outlier hidden dimensions (x20), LayerNorm gains up to 5, about
+    1 % of the sparse activations alive.  Same bounds as at random initialisation: every activation inside 1e-2 (1 + |ref|) of the
+    fp32 oracle on the unrounded weights, gradients routed and un-routed -- this is where the sigmoid-form GELU, the fp16 operands
+    and the head kernels' zero-skipping paths have to hold."""
+    _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=11, what=f"c2 slice, trained-like statistics, varlen={varlen}",
+                  varlen=varlen, trained_like=True)
 
 
 @pytest.mark.parametrize("varlen", [True, False])
@@ -306,7 +440,7 @@ def test_c2_full_batch_32x16x128_both_layouts(varlen):
     the UNROUNDED weights, the loss, and the routed gradients of the six GRAD_NAMES (sparse_encoders.py:107-119, loss.py:86-107).
     About a minute of host time per layout."""
     _student_step(MINI, torch.bfloat16, nq=32, k=16, S=128, Sq=32, recipe=INFONCE, seed=8, what=f"c2 FULL batch, varlen={varlen}",
-                  varlen=varlen, unrouted_grads=False)
+                  varlen=varlen)
 
 
 def test_c5_kd_precomputed_scores_bert_base_seq512_gradient_caching():

@@ -270,6 +270,67 @@ def test_gemm_tn_acc(ops, dtype, M, N, Kc):
     close(cs, A.sum(0), tol, "column sums")
 
 
+def _to_bcm(x: torch.Tensor) -> torch.Tensor:
+    """row-major [rows, cols] -> the block-column-major buffer of sm_ffn_pc_bwd's outputs: [ceil(rows / 128) * 4][cols / 8][32][8]"""
+    rows, cols = x.shape
+    rp = (rows + 127) // 128 * 128
+    pad = torch.zeros(rp, cols, dtype=x.dtype)
+    pad[:rows] = x
+    return pad.reshape(rp // 32, 32, cols // 8, 8).permute(0, 2, 1, 3).contiguous()
+
+
+@pytest.mark.parametrize("M", [32, 100, 1000, 4112, 70000])
+def test_gemm_tn_group_matches_fp32_products(ops, M):
+    """the grouped weight-gradient kernel (csrc/gemm_tn2.hip, hf:175-177 / :290 / :335 / :348 backward in ONE launch): every product
+    against the fp32 product of the same bf16 operands, accumulating into a non-zero C; row counts that are not multiples of the
+    32-row stage, one stage only, and more rows than one split; operands with a leading dimension, block-column-major operands,
+    problems with and without a bias gradient"""
+    dt = torch.bfloat16
+    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
+    probs, want = [], []
+    for i, (N, Kc) in enumerate(shapes):
+        A, B = q(rnd(M, N, seed=10 + i, scale=0.5), dt), q(rnd(M, Kc, seed=20 + i, scale=0.5), dt)
+        init = rnd(N, Kc, seed=30 + i)
+        out = dev(init.clone())
+        cs = torch.full((N,), 0.5, device="cuda") if i != 1 else None
+        a_dev, b_dev = dev(A, dt), dev(B, dt)
+        if i == 2:  # FFN up: dF1 block-column-major (A), x1 row-major
+            a_dev = ops.Bcm(dev(_to_bcm(A.to(dt))), M, N)
+        if i == 3:  # FFN down: gelu(f1) block-column-major (B)
+            b_dev = ops.Bcm(dev(_to_bcm(B.to(dt))), M, Kc)
+        if i == 0:  # a view with a leading dimension (the fused QKV gradient is one: lda > N)
+            wide = torch.zeros(M, N + 64, dtype=dt, device="cuda")
+            wide[:, :N] = a_dev
+            a_dev = wide[:, :N]
+        probs.append((a_dev, b_dev, out, cs))
+        want.append((init + A.t() @ B, None if cs is None else 0.5 + A.sum(0)))
+    assert ops.gemm_tn_group(probs), "the grouped kernel declined the encoder's own shapes"
+    for (a, b, out, cs), (w, wcs), (N, Kc) in zip(probs, want, shapes):
+        close(out, w, 1e-2, f"A^T B accumulate [{N} x {Kc}]")
+        rel = float((out.cpu() - w).norm() / w.norm())
+        assert rel <= 2e-5 + 1e-6 * math.sqrt(M), f"[{N} x {Kc}]: relative Frobenius error {rel:.2e} (fp32 accumulation of exact bf16 products)"
+        if cs is not None:
+            close(cs, wcs, 1e-2, f"column sums [{N}]")
+
+
+def test_gemm_tn_group_equals_the_per_matrix_kernel_and_declines_other_shapes(ops):
+    dt = torch.bfloat16
+    M = 5000
+    A, B = dev(q(rnd(M, 768, seed=1, scale=0.5), dt), dt), dev(q(rnd(M, 2304, seed=2, scale=0.5), dt), dt)
+    o1, o2 = torch.zeros(768, 2304, device="cuda"), torch.zeros(768, 2304, device="cuda")
+    c1, c2 = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+    assert ops.gemm_tn_group([(A, B, o1, c1)])  # bert-base width: 4 x 12 tiles
+    ops.gemm_tn_acc(A, B, o2, colsum=c2)
+    close(o1, o2, 1e-5, "grouped vs per-matrix kernel")  # both accumulate exact products in fp32: only the summation order differs
+    close(c1, c2, 1e-5, "column sums")
+    # not a multiple of 192 / fp32 operands / seven problems: declined, nothing launched
+    o3 = torch.zeros(128, 384, device="cuda")
+    assert not ops.gemm_tn_group([(A[:, :128].contiguous(), B[:, :384].contiguous(), o3, None)])
+    assert float(o3.abs().max()) == 0.0
+    assert not ops.gemm_tn_group([(A.float(), B.float(), o1, None)])
+    assert not ops.gemm_tn_group([(A, B, o1, None)] * 7)
+
+
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,H", [(37, 64), (130, 384), (9, 768)])
