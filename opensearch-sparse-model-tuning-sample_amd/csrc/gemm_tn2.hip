@@ -26,6 +26,8 @@
 // there).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include "gemm_tn2_asm.inc"
 
 namespace {
@@ -34,6 +36,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T2_TILE = 192, T2_BKM = 32, T2_PANEL = T2_BKM * 256, T2_STAGE = 3 * T2_PANEL, T2_MAXP = 6;
 
@@ -50,6 +53,7 @@ struct Tn2Prob {
 struct Tn2Args {
   Tn2Prob p[T2_MAXP];
   int nprob, tiles, nsplit, rows_per_split, M;
+  int dbg;  // timing experiments only (SM_TN2_DEBUG; results are wrong): 1 the loaders move nothing, 2 no flush, 4 no MFMAs
 };
 
 __device__ uint4 g_tn2_zero16;  // zero-initialised: source of LDS-DMA lanes whose token row is past the end
@@ -66,7 +70,10 @@ __device__ __forceinline__ void t2_wait_vm_dyn(int younger) {
   }
 }
 
-template <int NST>
+// NST: ring slots of the LDS image.  REGLD = 0: the loader waves fill them by LDS-DMA (NST - 1 stages in flight); REGLD = D > 0: they
+// load D stages ahead into REGISTERS (plain 16-byte loads: a loader wave has 256 registers and uses none otherwise) and store a
+// stage to LDS one barrier before the consumers read it -- two slots suffice, the HBM latency is covered by registers.
+template <int NST, int REGLD>
 __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ---- work item of this workgroup: contiguous runs of (split, tile) items per XCD ----
@@ -100,7 +107,9 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
     size_t strd[3];
     int lrow[2];
     const int rsub = lane >> 4, cphys = lane & 15;
-    const int clog = ((((cphys >> 1) ^ ((rsub & 3) << 1)) << 1) | (cphys & 1)) * 8;  // logical column (in the panel) of this lane's 16 bytes
+    // LDS-DMA: lane l of a piece lands at chunk l, so it FETCHES the chunk that belongs there; register staging: the lane fetches
+    // chunk l (a coalesced 256-byte row) and STORES it to its swizzled place
+    const int clog = REGLD ? cphys * 8 : ((((cphys >> 1) ^ ((rsub & 3) << 1)) << 1) | (cphys & 1)) * 8;  // logical column (in the panel) of this lane's 16 bytes
 #pragma unroll
     for (int pn = 0; pn < 3; ++pn) {
       const int gc = pn * 128 + clog;  // column in the A | B concatenation
@@ -119,6 +128,98 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) lrow[p] = mbeg + (w * 2 + p) * 4 + rsub;
     const char* const zsrc = reinterpret_cast<const char*>(&g_tn2_zero16);
+    if constexpr (REGLD > 0) {
+      constexpr int D = REGLD;
+      u32x4 r0[6], r1[6], r2[6], r3[6], r4[6];  // (separate arrays: an array of arrays indexed by the unrolled d stays in scratch memory)
+      static_assert(D >= 2 && D <= 5, "register-staged loader: 2 to 5 stages ahead");
+      int irow = 0;
+      auto ld = [&](u32x4 (&dst)[6]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pn = 0; pn < 3; ++pn)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const char* src = lrow[p] + irow < mend ? cur[pn][p] : zsrc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[pn * 2 + p]) : "v"(src) : "memory");
+            cur[pn][p] += strd[pn];
+          }
+        irow += T2_BKM;
+      };
+      // the lane's place in a piece of the image: row rsub of the piece, 16-byte chunk cphys moved to its swizzled 32-byte slot
+      const int woff = w * 2048 + rsub * 256 + ((((cphys >> 1) ^ ((rsub & 3) << 1)) << 5) | ((cphys & 1) << 4));
+      int wslot = 0;
+      // The loads are inline assembly with hand-counted waits: through plain loads the compiler drains the whole register ring
+      // (vmcnt(0)) at the loop header -- it cannot count the conditional refills along the back edge.  `younger` = stages loaded
+      // behind the one about to be stored (6 loads each); tools/asm_hazard_check.py replays the counters.
+      auto landed = [&](u32x4 (&q)[6]) __attribute__((always_inline)) {
+        // EVERY stage slot is refilled, also past the last stage (rows past the end fetch the zero word): exactly D - 1 younger
+        // stages of 6 loads are in flight whenever a stage is stored, so the wait is one constant.  It carries no register operands
+        // (as operands of an asm wait the compiler may copy the registers in FRONT of it: the round-3 bug class); the empty
+        // statement behind it, fenced from the scheduler, is where the compiler learns that the six registers changed.
+        t2_wait_vm<6 * (D - 1)>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]) : : "memory");
+      };
+      auto wr = [&](const u32x4 (&src)[6]) __attribute__((always_inline)) {
+        char* const base = smem + wslot * T2_STAGE + woff;
+#pragma unroll
+        for (int pn = 0; pn < 3; ++pn)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + pn * T2_PANEL + p * 1024) = src[pn * 2 + p];
+        wslot = wslot + 1 == NST ? 0 : wslot + 1;
+      };
+#define T2_PRE(d, R) \
+  if constexpr (d < D) { ld(R); }
+      T2_PRE(0, r0) T2_PRE(1, r1) T2_PRE(2, r2) T2_PRE(3, r3) T2_PRE(4, r4)
+#undef T2_PRE
+      // stage st + d goes into its slot (the consumers finished that slot's previous stage before the last barrier), then barrier
+      // B_{st+d}, then the registers are refilled with stage st + d + D
+#define T2_STEP(R)                                       \
+  {                                                      \
+    landed(R);                                           \
+    wr(R);                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+    ld(R);                                               \
+  }
+      // whole groups of D stages without a branch inside, then the nst % D stages left as NESTED conditions: the static checker
+      // follows every edge of the control-flow graph, so a stage must only be reachable through the stages before it
+      int st = 0;
+      for (; st + D <= nst; st += D) {
+        T2_STEP(r0) T2_STEP(r1)
+        if constexpr (D > 2) T2_STEP(r2)
+        if constexpr (D > 3) T2_STEP(r3)
+        if constexpr (D > 4) T2_STEP(r4)
+      }
+      const int rem = nst - st;
+      if (rem > 0) {
+        T2_STEP(r0)
+        if (rem > 1) {
+          T2_STEP(r1)
+          if constexpr (D > 2) {
+            if (rem > 2) {
+              T2_STEP(r2)
+              if constexpr (D > 3) {
+                if (rem > 3) T2_STEP(r3)
+              }
+            }
+          }
+        }
+      }
+#undef T2_STEP
+      // the refills behind the last stage are never stored, but their destination registers must stay reserved until they have
+      // landed: a register the compiler considers dead is reused while the load is still writing it
+      t2_wait_vm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+#define T2_KEEP(q) asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]) : : "memory");
+      T2_KEEP(r0) T2_KEEP(r1)
+      if constexpr (D > 2) T2_KEEP(r2)
+      if constexpr (D > 3) T2_KEEP(r3)
+      if constexpr (D > 4) T2_KEEP(r4)
+#undef T2_KEEP
+      return;
+    }
+    if (args.dbg & 8) __builtin_amdgcn_s_setprio(3);  // experiment: the loaders win the issue arbitration against their SIMD's consumer wave
     int islot = 0, irow = 0;  // ring slot and row offset of the next stage to issue
     auto issue = [&]() {
       char* const base = smem + islot * T2_STAGE + w * 2048;
@@ -126,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
       for (int pn = 0; pn < 3; ++pn)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const char* src = lrow[p] + irow < mend ? cur[pn][p] : zsrc;
+          const char* src = lrow[p] + irow < mend && !(args.dbg & 1) ? cur[pn][p] : zsrc;
           __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + pn * T2_PANEL + p * 1024), 16, 0, 0);
           cur[pn][p] += strd[pn];
         }
@@ -172,10 +273,12 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
   const int csmode = !do_cs ? 0 : wn == 0 ? 1 : 2;
 #define T2_ASM_INPUTS [b0] "v"(base[0]), [b1] "v"(base[1]), [b2] "v"(base[2]), [b3] "v"(base[3]), [b4] "v"(base[4]), [b5] "v"(base[5]), \
                       [nst] "s"(nst), [stage] "n"(T2_STAGE), [wrap] "n"(NST * T2_STAGE)
-  if (csmode == 0) asm volatile(T2_ASM_NOCS : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
+  if (args.dbg & 4) asm volatile(T2_ASM_DBG_NOMFMA : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
+  else if (csmode == 0) asm volatile(T2_ASM_NOCS : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
   else if (csmode == 1) asm volatile(T2_ASM_CS_H0 : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
   else asm volatile(T2_ASM_CS_H1 : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
 #undef T2_ASM_INPUTS
+  if (args.dbg & 2) return;
   // ---- flush: one accumulator register = rows R and R + 4 of C, 32 consecutive columns each (two 128-byte segments) ----
   float* const Cb = P.C + (size_t)(n0 + wm * 96 + (lane >> 5) * 4) * P.ldc + k0 + wn * 96 + (lane & 31);
 #pragma unroll
@@ -236,12 +339,21 @@ extern "C" int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, vo
   a.nsplit = nsplit;
   a.rows_per_split = rps;
   a.M = M;
-  constexpr int NST = 5;
-  const int lds = NST * T2_STAGE;
-  auto kern = gemm_tn2_kernel<NST>;
-  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  static const int dbg = [] { const char* e = getenv("SM_TN2_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   const int grid = (tiles * nsplit + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  SM_LAUNCH_CHECK();
-  return 0;
+  static const int loader = [] { const char* e = getenv("SM_TN2_LOADER"); return e ? atoi(e) : 0; }();  // A/B switch (tools/tn2_bench.py)
+  auto launch = [&](auto kern, int nst) -> int {
+    const int lds = nst * T2_STAGE;
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    SM_LAUNCH_CHECK();
+    return 0;
+  };
+  if (loader == 1) return launch(gemm_tn2_kernel<2, 4>, 2);
+  if (loader == 2) return launch(gemm_tn2_kernel<3, 5>, 3);
+  if (loader == 3) return launch(gemm_tn2_kernel<3, 3>, 3);
+  if (loader == 4) return launch(gemm_tn2_kernel<6, 0>, 6);
+  if (loader == 5) return launch(gemm_tn2_kernel<4, 0>, 4);
+  return launch(gemm_tn2_kernel<5, 0>, 5);
 }

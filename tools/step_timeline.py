@@ -27,3 +27,10 @@ for g, a, b in sorted(gaps, reverse=True)[:12]: print(f"   {g / 1e3:7.1f} us bet
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, q, n in step: agg[(q, n)][0] += 1; agg[(q, n)][1] += e - s
 for (q, n), (k, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]: print(f"   q{q} {n:28s} x{k:3d} {t / 1e3:8.1f} us")
+if len(sys.argv) > 3 and sys.argv[3] == "all":  # every kernel of the step in start order: offset, duration, queue, gap to its queue predecessor
+    last_end = {}
+    print("   offset_us  dur_us  gap_us  q  kernel")
+    for s, e, q, n in step:
+        gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+        last_end[q] = max(e, last_end.get(q, 0))
+        print(f"   {(s - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f} {gap:7.1f}  {'M' if q == mainq else 's'}  {n}")
