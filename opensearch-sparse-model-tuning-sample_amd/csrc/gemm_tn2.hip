@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "gemm_tn2_asm.inc"
+#include "gemm_tn3_asm.inc"
 
 namespace {
 
@@ -56,6 +57,7 @@ struct Tn2Args {
   int dbg;  // timing experiments only (SM_TN2_DEBUG; results are wrong): 1 the loaders move nothing, 2 no flush, 4 no MFMAs
 };
 
+__device__ uint32_t g_tn3_stamps[512 * 9 * 4];  // diagnostic build only (lanes other than 0 write the spare slot 8)
 __device__ uint4 g_tn2_zero16;  // zero-initialised: source of LDS-DMA lanes whose token row is past the end
 
 template <int N> __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -293,7 +295,120 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The SYMMETRIC form (tools/gen_tn3_asm.py has the reasoning, the register map and the counters): [384 x 192] output tile, eight
+// waves that all issue LDS-DMA and all run MFMAs, wave (wm, wn) = (w & 3, w >> 2) owns the [96 x 96] block at rows 96 wm, columns
+// 96 wn.  Needs N % 384 == 0 and Kc % 192 == 0 of every problem (true of every weight of the 384- and 768-wide models).
+// This function only computes addresses; the main loop is the generated assembly.
+// ---------------------------------------------------------------------------------------
+constexpr int T3_TN = 384, T3_TK = 192, T3_PANEL = T2_BKM * 256;
+static_assert(T3_STAGE_BYTES == 5 * T3_PANEL, "generator and kernel disagree about the stage image");
+
+__global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int items = args.tiles * args.nsplit;
+  const int per = (items + 7) >> 3;
+  const int L = blockIdx.x, jx = L >> 3;
+  if (jx >= per) return;
+  const int item = (L & 7) * per + jx;
+  if (item >= items) return;
+  const int tile = item % args.tiles, z = item / args.tiles;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < T2_MAXP; ++q)
+    if (q + 1 < args.nprob && tile >= args.p[q].tile_end) pi = q + 1;
+  const Tn2Prob& P = args.p[pi];
+  const int tl = tile - (pi > 0 ? args.p[pi - 1].tile_end : 0);
+  const int kt = tl % P.tiles_k, nt = tl / P.tiles_k;
+  const int n0 = nt * T3_TN, k0 = kt * T3_TK;
+  const int mbeg = z * args.rows_per_split;
+  const int mend = min(args.M, mbeg + args.rows_per_split);
+  if (mbeg >= mend) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nst = (mend - mbeg + T2_BKM - 1) / T2_BKM;
+  const int wm = w & 3, wn = w >> 2;
+  const uint32_t sb = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+  // ---- LDS-DMA sources: the wave moves rows 4w .. 4w+3 of each of the 5 panels; lane l of a piece lands at chunk l of the piece
+  const bool a_bcm = P.lda < 0, b_bcm = P.ldb < 0;
+  const uint64_t astage = (uint64_t)T2_BKM * (a_bcm ? P.N : P.lda) * 2, bstage = (uint64_t)T2_BKM * (b_bcm ? P.Kc : P.ldb) * 2;  // bytes
+  const int rsub = lane >> 4, cphys = lane & 15;
+  const int clog = ((((cphys >> 1) ^ ((rsub & 3) << 1)) << 1) | (cphys & 1)) * 8;  // logical column (in the panel) of this lane's 16 bytes
+  const int row = w * 4 + rsub;
+  const char* src[5];
+#pragma unroll
+  for (int pn = 0; pn < 5; ++pn) {
+    const bool is_a = pn < 3;
+    const int col = is_a ? n0 + pn * 128 + clog : k0 + (pn - 3) * 128 + clog;
+    size_t off;
+    if (is_a) off = a_bcm ? ((size_t)(mbeg >> 5) * (P.N >> 3) + (col >> 3)) * 256 + row * 8 : (size_t)(mbeg + row) * P.lda + col;
+    else off = b_bcm ? ((size_t)(mbeg >> 5) * (P.Kc >> 3) + (col >> 3)) * 256 + row * 8 : (size_t)(mbeg + row) * P.ldb + col;
+    src[pn] = reinterpret_cast<const char*>((is_a ? P.A : P.B) + off);
+  }
+  const int vrow = mbeg + row;
+  const int vrow4 = clog < 64 ? vrow : (1 << 30);  // panel 4 holds B columns 128 .. 191 only: its other lanes always fetch the zero word
+  const char* const zsrc = reinterpret_cast<const char*>(&g_tn2_zero16);
+  const uint32_t dst0 = sb + (uint32_t)w * 1024u;
+
+  // ---- fragment addresses (slot 0): A fragments from panels 0-2 (tile rows 96 wm + 32 i), B fragments from panels 3-4
+  uint32_t base[6];
+  {
+    const int gi = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      const int gc = f < 3 ? wm * 96 + f * 32 : T3_TN + wn * 96 + (f - 3) * 32;  // first column of the fragment in A | B
+      const int pn = gc >> 7, pc = gc & 127;
+      const int r = (gi >> 1) * 8 + q;
+      const int byte = (pc + (gi & 1) * 16 + p4 * 4) * 2;
+      const int slot = (byte >> 5) ^ (q << 1);
+      base[f] = sb + pn * T3_PANEL + r * 256 + (slot << 5) + (byte & 31);
+    }
+  }
+  f32x16 acc[3][3];
+  float cs[3];
+  // diagnostic build (SM_TN2_DEBUG & 16): per wave {cycles of the main loop, cycles in its vmcnt waits, cycles in its barriers}
+  uint32_t* const dbgp = g_tn3_stamps + ((size_t)blockIdx.x * 8 + (lane == 0 ? w : 8)) * 4;
+  // bias gradient: the kt == 0 tile of each A row block; waves (wm, 0) sum the first half of every stage, (wm, 1) the second
+  const bool do_cs = P.colsum != nullptr && kt == 0;
+  const int csmode = !do_cs ? 0 : wn == 0 ? 1 : 2;
+#define T3_ASM_INPUTS [b0] "v"(base[0]), [b1] "v"(base[1]), [b2] "v"(base[2]), [b3] "v"(base[3]), [b4] "v"(base[4]), [b5] "v"(base[5]), \
+                      [p0] "v"(src[0]), [p1] "v"(src[1]), [p2] "v"(src[2]), [p3] "v"(src[3]), [p4] "v"(src[4]), [z] "v"(zsrc),        \
+                      [row] "v"(vrow), [row4] "v"(vrow4), [nst] "s"(nst), [mend] "s"(mend), [sa] "s"(astage), [sb] "s"(bstage),       \
+                      [dst] "s"(dst0), [dbgp] "v"(dbgp)
+  // waves 0-3 issue their LDS-DMA in the first half of a stage, waves 4-7 (their SIMD partners) in the second
+  if (args.dbg & 16) {
+    if (w < 4) asm volatile(T3_ASM_STAMPS_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+    else asm volatile(T3_ASM_STAMPS_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+  } else if (w < 4) {
+    if (csmode == 0) asm volatile(T3_ASM_NOCS_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+    else if (csmode == 1) asm volatile(T3_ASM_CS_H0_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+    else asm volatile(T3_ASM_CS_H1_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+  } else {
+    if (csmode == 0) asm volatile(T3_ASM_NOCS_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+    else if (csmode == 1) asm volatile(T3_ASM_CS_H0_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+    else asm volatile(T3_ASM_CS_H1_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
+  }
+#undef T3_ASM_INPUTS
+  if (args.dbg & 2) return;
+  // ---- flush: one accumulator register = rows R and R + 4 of C, 32 consecutive columns each (two 128-byte segments) ----
+  float* const Cb = P.C + (size_t)(n0 + wm * 96 + (lane >> 5) * 4) * P.ldc + k0 + wn * 96 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(Cb + (size_t)(i * 32 + (r >> 2) * 8 + (r & 3)) * P.ldc + j * 32, acc[i][j][r]);
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) atomicAdd(P.colsum + n0 + wm * 96 + i * 32 + (lane & 31), cs[i]);
+  }
+}
+
 }  // namespace
+
+extern "C" int sm_tn3_debug_stamps(unsigned int* host, int n) {  // tools/tn3_stamps.py (not part of include/sparse_hip.h)
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn3_stamps), (size_t)n * 4);
+}
 
 // Declared in include/sparse_hip.h.  Returns 0 when the grouped kernel ran, 1 when a problem is not eligible (the caller runs
 // sm_gemm_tn_acc / sm_gemm_tn_acc_bcm per problem instead), < 0 on error.
@@ -302,6 +417,11 @@ extern "C" int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, vo
   if (nprob > T2_MAXP) return 1;
   Tn2Args a;
   int tiles = 0;
+  // the symmetric [384 x 192] kernel when every N is a multiple of 384 (SM_TN_SYM=0: the [192 x 192] loader / consumer kernel)
+  static const int want_sym = [] { const char* e = getenv("SM_TN_SYM"); return e ? atoi(e) : 1; }();
+  bool sym = want_sym != 0;
+  for (int i = 0; i < nprob; ++i) sym = sym && probs[i].N % T3_TN == 0 && probs[i].Kc % T3_TK == 0;
+  const int tile_n = sym ? T3_TN : T2_TILE;
   for (int i = 0; i < nprob; ++i) {
     const sm_tn_problem& q = probs[i];
     SM_REQUIRE(q.A && q.B && q.C && q.N > 0 && q.Kc > 0, "sm_gemm_tn_group: problem %d has a null operand or an empty shape", i);
@@ -321,7 +441,7 @@ extern "C" int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, vo
     p.N = q.N;
     p.Kc = q.Kc;
     p.tiles_k = q.Kc / T2_TILE;
-    tiles += (q.N / T2_TILE) * p.tiles_k;
+    tiles += (q.N / tile_n) * p.tiles_k;
     p.tile_end = tiles;
   }
   for (int i = nprob; i < T2_MAXP; ++i) a.p[i] = a.p[nprob - 1];
@@ -350,6 +470,12 @@ extern "C" int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, vo
     SM_LAUNCH_CHECK();
     return 0;
   };
+  if (sym) {
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NST * T3_STAGE_BYTES));
+    hipLaunchKernelGGL(gemm_tn3_kernel, dim3(grid), dim3(512), T3_NST * T3_STAGE_BYTES, (hipStream_t)stream, a);
+    SM_LAUNCH_CHECK();
+    return 0;
+  }
   if (loader == 1) return launch(gemm_tn2_kernel<2, 4>, 2);
   if (loader == 2) return launch(gemm_tn2_kernel<3, 5>, 3);
   if (loader == 3) return launch(gemm_tn2_kernel<3, 3>, 3);

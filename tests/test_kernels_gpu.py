@@ -323,6 +323,12 @@ def test_gemm_tn_group_equals_the_per_matrix_kernel_and_declines_other_shapes(op
     ops.gemm_tn_acc(A, B, o2, colsum=c2)
     close(o1, o2, 1e-5, "grouped vs per-matrix kernel")  # both accumulate exact products in fp32: only the summation order differs
     close(c1, c2, 1e-5, "column sums")
+    # N a multiple of 192 but not of 384: the [192 x 192] loader / consumer kernel instead of the symmetric [384 x 192] one
+    A5, B5 = dev(q(rnd(M, 576, seed=3, scale=0.5), dt), dt), dev(q(rnd(M, 192, seed=4, scale=0.5), dt), dt)
+    o5, c5 = torch.zeros(576, 192, device="cuda"), torch.zeros(576, device="cuda")
+    assert ops.gemm_tn_group([(A5, B5, o5, c5)])
+    close(o5, A5.float().t() @ B5.float(), 1e-5, "[576 x 192] through the [192 x 192] kernel")
+    close(c5, A5.float().sum(0), 1e-5, "its column sums")
     # not a multiple of 192 / fp32 operands / seven problems: declined, nothing launched
     o3 = torch.zeros(128, 384, device="cuda")
     assert not ops.gemm_tn_group([(A[:, :128].contiguous(), B[:, :384].contiguous(), o3, None)])
