@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the post-run per-GEMM timing steps")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sparse-regime leg and the configs[4] per-GPU-shape leg (N = 1 only)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-bounded", action="store_true",
@@ -148,7 +149,7 @@ class GemmRoofline:
             e0.record()
             out = orig(*a, **kw)
             e1.record()
-            if out is not None:  # (a fused entry point that declines the shape returns None and its caller runs the unfused ops, which
+            if out is not None and out is not False:  # (a fused entry point that declines the shape returns None / False and its caller runs the unfused ops, which
                 key = name if label is None else label(*a, **kw)                     # are counted themselves)
                 self.rec.setdefault(key, []).append((e0, e1, flops(*a, **kw)))
             return out
@@ -169,6 +170,8 @@ class GemmRoofline:
         self._wrap("gemm_nt", lambda A, B, *a, n=None, **k: 2.0 * A.shape[0] * A.shape[1] * (B.shape[0] if n is None else n), self._nt_label)
         self._wrap("gemm_nt_ln_bwd", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
         self._wrap("gemm_tn_acc", lambda A, B, *a, **k: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+        # the grouped weight-gradient launch (csrc/gemm_tn2.hip: a layer's four products in one grid)
+        self._wrap("gemm_tn_group", lambda probs, *a, **k: sum(2.0 * A.shape[0] * A.shape[1] * B.shape[1] for A, B, _, _ in probs))
         # the fused feed-forward forward (LayerNorm 1 + FFN-up + GELU + FFN-down + residual + LayerNorm 2): its two GEMMs' FLOPs
         self._wrap("ffn_pc_fwd", lambda z1, g1, b1, eps, w1f, bias1, *a, **k: 4.0 * z1.shape[0] * z1.shape[1] * bias1.shape[0])
         # ... and its backward (dF1 GEMM + FFN-up input gradient, with GELU', the LayerNorm-1 backward and the residual gradient)
@@ -368,8 +371,8 @@ def latest_traffic(kernel_names, layout):
     return None, None, None, None
 
 
-GEMM_KERNELS = ("gemm_nt_kernel", "gemm_nt192_kernel", "gemm_ws_kernel", "gemm_tn_pc_kernel", "gemm_tn_kernel", "ffn_pc_fwd_kernel",
-                "ffn_pc_bwd_kernel")
+GEMM_KERNELS = ("gemm_nt_kernel", "gemm_nt192_kernel", "gemm_ws_kernel", "gemm_tn_pc_kernel", "gemm_tn_kernel", "gemm_tn2_kernel",
+                "gemm_tn3_kernel", "ffn_pc_fwd_kernel", "ffn_pc_bwd_kernel")
 
 
 def csrc_sha() -> str:
@@ -401,6 +404,71 @@ def latest_gemm_traffic(layout):
         except (OSError, KeyError, ValueError):
             continue
     return None, None, None, None
+
+
+def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
+    """The step in the regime a TRAINED sparse encoder lives in (config_infonce.yaml:5 fine-tunes one): the decoder bias is shifted
+    down until ~1 % of the (document, vocabulary) activations are alive (random init: ~100 %), learning rate 0, then `steps` steps
+    are timed.  Only the kernels whose work depends on the activation pattern change (head backward: rows gathered, all-zero
+    G slices skipped).  The bias and the learning rate are restored afterwards."""
+    try:
+        bb = trainer.model.sparse_model.backbone
+        bias = bb.view("cls.predictions.bias")
+        keep, lr = bias.detach().clone(), trainer.args.learning_rate
+
+        def alive():
+            with torch.no_grad():
+                bb.eval()
+                b = bs_[0]["docs"][0]
+                rep = bb.encode(b["input_ids"][:64].to(bb.device), b["attention_mask"][:64].to(bb.device))
+                bb.train()
+            return float((rep > 0).float().mean())
+
+        a0 = alive()
+        lo, hi = 0.0, 10.0
+        for _ in range(12):  # bisection on the shift
+            mid = (lo + hi) / 2
+            with torch.no_grad():
+                bias.copy_(keep - mid)
+            bb.mark_weights_dirty()
+            lo, hi = (mid, hi) if alive() > density else (lo, mid)
+        trainer.args.learning_rate = 0.0
+        a1 = alive()
+        for i in range(3):
+            trainer.training_step(bs_[i % len(bs_)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trainer.training_step(bs_[i % len(bs_)])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        with torch.no_grad():
+            bias.copy_(keep)
+        bb.mark_weights_dirty()
+        trainer.args.learning_rate = lr
+        return {"what": "the same step with the decoder bias shifted until ~1 % of the sparse activations are alive (a trained checkpoint's "
+                        "regime; random init: all alive), learning rate 0", "layout": layout, "alive_fraction_random_init": a0,
+                "alive_fraction": a1, "ms_per_step": ms, "samples_per_sec": 32e3 / ms, "steps": steps}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def c5_leg(timeout_s=240):
+    """BASELINE configs[4] at its full PER-GPU shape (bert-base student, 64 queries x 31 documents, seq 512, kd on precomputed scores,
+    fp8 operands in the encoder linears, rep-level gradient caching) in a child process: tools/c5_shape_smoke.py, 2 timed steps."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c5_shape_smoke.py"), "64", "248", "2", "fp8"], capture_output=True,
+                           text=True, timeout=timeout_s, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+        line = [l for l in r.stdout.splitlines() if "ms/step" in l]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        import re
+        m = re.search(r"(\d+) ms/step = ([\d.]+) samples/s.*peak memory ([\d.]+) GiB", line[-1])
+        return {"what": "configs[4] per-GPU shape on ONE GPU (tools/c5_shape_smoke.py 64 248 2 fp8)", "ms_per_step": float(m.group(1)),
+                "samples_per_sec": float(m.group(2)), "peak_memory_gib": float(m.group(3)), "line": line[-1]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -536,11 +604,19 @@ def main():
                                   f"dense layout: all {T_padded} token rows computed (attention skips key tiles that hold only masked keys: exact); value_ragged_layout skips padding tokens"),
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
                    "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks over RCCL, exchange mode "
-                                                      + os.environ.get("SM_EXCHANGE", "scores") + ": scores = all-gather of the queries (under "
+                                                      + os.environ.get("SM_EXCHANGE", "gather") + ": scores = all-gather of the queries (under "
                                                       "the document encoder) and of the score blocks + all-reduce of the FLOPS column means, "
                                                       "gather = the reference's all-gather of the representations; flat-gradient all-reduce "
                                                       "in slices overlapped with backward)")},
     }
+    if world > 1:  # self-describing multi-GPU record: what carried the collectives
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001  (a build without the binding: say so instead of failing the run)
+            ver = f"unavailable ({type(e).__name__})"
+        result["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                          "exchange": os.environ.get("SM_EXCHANGE", "gather"), "gpus_visible": ndev,
+                          "env": {k: os.environ[k] for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_ALGO", "NCCL_PROTO") if k in os.environ}}
     head_line = {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
                  "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                  "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side reads x2-corrected + writes)", "traffic_source": traffic_src,
@@ -552,7 +628,7 @@ def main():
         # step as it runs (weight gradients on the side queue share the chip with the backward chain)
         fl = sum(g["gflop_per_step"] for g in gemm_lines)
         ms = sum(g["ms_per_step"] for g in gemm_lines)
-        result["roofline"] = {"kernel": "encoder GEMMs, in-step (all launches of sm_gemm_nt / sm_gemm_nt_ln_bwd / sm_gemm_tn_acc / "
+        result["roofline"] = {"kernel": "encoder GEMMs, in-step (all launches of sm_gemm_nt / sm_gemm_nt_ln_bwd / sm_gemm_tn_acc / sm_gemm_tn_group / "
                                         "sm_ffn_pc_fwd / sm_ffn_pc_bwd of one training step)",
                               "bound": "mfma", "achieved": fl / ms, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / ms * 1e12 / peak,
                               "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines}
@@ -571,6 +647,10 @@ def main():
         result["roofline_head_fwd"] = head_line
     else:  # N > 1 or --no-gemm-roofline: the largest single kernel of the step
         result["roofline"] = head_line
+    if world == 1 and not args.no_extras and args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
+        # two more records beside `value` (outside every timed region above; each guarded: a failure here never loses the line)
+        result["sparse_regime"] = sparse_regime_leg(trainer, batches[args.layout], args.layout)
+        result["c5_per_gpu"] = c5_leg()
     if rank == 0:
         if world == 1:
             pm = measured_peaks(device)

@@ -271,6 +271,12 @@ int sm_sparse_head_bwd_dt_ln(int dtype, const float* grad_rep, const float* rep,
                              const float* gamma, const float* mean, const float* rstd, const void* gelu_of,
                              float* dgamma, float* dbeta, int x_f32 /* 1: x (the LayerNorm input) is fp32 */, void* stream);
 
+/* The dt half as a SCATTER (ABI 5; bf16 E): dt32[row(b) + argmax[b, v], :] += grad_rep[b, v] f'(rep[b, v]) E[v, :] for the live (b, v)
+ * only, fp32 atomics into a ZEROED dt32[T, H].  Work proportional to the number of live activations: the form for a trained
+ * sparse encoder (~1 % alive); exact at any density (sparse_encoders.py:109-114 backward). */
+int sm_sparse_head_bwd_dt_scatter(const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, float* dt32,
+                                  int B, int S, int H, int V, int use_l0, const sm_ragged* rag, void* stream);
+
 /* ---- inference-free query encoder (scripts/model/sparse_encoders.py:121-127) ----------- */
 int sm_inf_free_fwd(const int64_t* ids, int bs, int sq, const float* idf, const int32_t* special,
                     int n_special, int V, float* out, void* stream);
@@ -288,8 +294,10 @@ int sm_flops_bwd(const float* rep, const float* colmean, const float* rowkeep, c
                  int rows, int g, int V, int row0, int nrows, float* grad_rep, int accumulate, void* stream);
 
 /* ---- score matrices (scripts/train/loss.py:28-37,92-101; bi_encoder_wrapper.py:124-131) --
- * dense: scores[nq, nd] = q[nq,D] . d[nd,D]^T (fp32).  pairs == 0: all pairs (in-batch);
- * pairs == 1: nd = nq*k and only the block diagonal [nq,k] is produced (torch.bmm form). */
+ * dense: scores[nq, nd] = q[nq,D] . d[nd,D]^T (fp32).  pairs bit 0 clear: all pairs (in-batch);
+ * bit 0 set: nd = nq*k and only the block diagonal [nq,k] is produced (torch.bmm form).
+ * pairs bit 1 (ABI 5, all-pairs form): DETERMINISTIC -- the vocabulary dimension is not split over workgroups, so no fp32 atomics and a
+ * fixed summation order: bit-reproducible scores (N-rank parity runs), at about a third of the rate for few queries. */
 int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pairs, float* scores, void* stream);
 /* dq (+)= ds . d ; dd[row0:row0+nrows] (+)= ds^T . q, restricted to local doc rows */
 int sm_scores_bwd(const float* q, const float* d, const float* ds, int nq, int nd, int D, int pairs,

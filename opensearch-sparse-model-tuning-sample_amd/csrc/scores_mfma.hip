@@ -197,13 +197,16 @@ __global__ __launch_bounds__(256) void wsum_nn_mfma_kernel(const float* __restri
 }  // namespace
 
 // Both return false when the shape is better served by the scalar kernels (tiny problems, odd D).
-bool sm_scores_mfma_fwd(const float* q, const float* d, int nq, int nd, int D, float* scores, hipStream_t st) {
+// deterministic: ONE split of the vocabulary dimension -- plain stores in a fixed summation order instead of fp32 atomics into a
+// zeroed matrix (bit-reproducible scores for N-rank parity runs; sm_scores_fwd's `pairs` bit 1)
+bool sm_scores_mfma_fwd(const float* q, const float* d, int nq, int nd, int D, float* scores, hipStream_t st, bool deterministic) {
   if ((D & 1) || (long)nq * nd < 32L * 64 || D < 1024 || ((uintptr_t)q % 8) || ((uintptr_t)d % 8)) return false;
   const int tiles = sm_cdiv(nq, SC_BM) * sm_cdiv(nd, SC_BN);
   int ksplit = sm_cdiv(1024, tiles);
   const int kmax = sm_cdiv(D, 8 * SC_BK);  // at least 8 K steps per block
   ksplit = ksplit < 1 ? 1 : (ksplit > kmax ? kmax : ksplit);
   if (ksplit > 64) ksplit = 64;
+  if (deterministic) ksplit = 1;
   const int kchunk = sm_cdiv(sm_cdiv(D, ksplit), SC_BK) * SC_BK;
   ksplit = sm_cdiv(D, kchunk);
   if (ksplit > 1 && hipMemsetAsync(scores, 0, sizeof(float) * (size_t)nq * nd, st) != hipSuccess) return false;

@@ -551,6 +551,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (lane < RPW && vok) dbias[v0 + lane] += bsum;
 }
 
+// ---- the dt half as a SCATTER, for the regime a trained sparse encoder lives in (about 1 % of the (document, vocabulary)
+// activations alive): dt[row(d) + argmax[d, v], :] += g[d, v] E[v, :] for the live (d, v) only -- B V f (2 H flops + 2 H bytes of E
+// + 4 H bytes of fp32 atomics) with f the live share, against the matrix form's 2 T V H whatever f is (head_dt192_kernel skips the
+// MFMAs of all-zero steps but still streams all of E past every row tile and synchronises 954 times: ~1.2 ms at f = 1 %).  One
+// workgroup per (document, 1024 vocabulary columns); a wave loads 64 (gradient, rep, arg-max) triples at a time and walks the live
+// lanes: lane l adds g E[v, 64 k + l] to dt32[row, 64 k + l] for k < H / 64 -- every atomic wave-instruction is one 256-byte row
+// segment (the full-rate shape).  Exact for any f (the host picks it below a density threshold only because the matrix form is
+// faster beyond, profiles/r5_head_dt_scatter.txt); the fp32 sums are rounded to bf16 once, by the caller.
+__global__ __launch_bounds__(256) void head_dt_scatter_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
+                                                              const uint16_t* __restrict__ argmax, const bf16* __restrict__ E,
+                                                              float* __restrict__ dt32, int B, int S, int H, int V, int use_l0,
+                                                              const int32_t* __restrict__ doc_off, int trows) {
+  const int d = blockIdx.y, lane = threadIdx.x & 63;
+  const int vbase = blockIdx.x * 1024 + (threadIdx.x >> 6) * 256;  // a wave owns 256 consecutive columns: 4 loads of 64
+  const int row0 = doc_off ? doc_off[d] : d * S;
+  const size_t o0 = (size_t)d * V;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int v = vbase + it * 64 + lane;
+    float gr = 0.f;
+    int row = row0;
+    if (v < V) {
+      gr = grad_rep[o0 + v] * head_fprime(rep[o0 + v], use_l0);
+      row = min(row0 + (int)argmax[o0 + v], trows - 1);  // (clamped like head_de_rows_kernel: a non-finite gradient on a dead column)
+    }
+    unsigned long long live = __builtin_amdgcn_ballot_w64(gr != 0.f);
+    while (live) {
+      const int src = __builtin_ctzll(live);
+      live &= live - 1;
+      const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gr), src));
+      const int r = __builtin_amdgcn_readlane(row, src);
+      const int vs = vbase + it * 64 + src;
+      const bf16* e = E + (size_t)vs * H + lane;
+      float* out = dt32 + (size_t)r * H + lane;
+      for (int k = 0; k < H; k += 64) atomicAdd(out + k, g * (float)e[k]);
+    }
+  }
+}
+
+extern "C" int sm_sparse_head_bwd_dt_scatter(const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E,
+                                             float* dt32, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, void* stream) {
+  SM_REQUIRE(B > 0 && S > 0 && V > 0 && grad_rep && rep && argmax && E && dt32, "sm_sparse_head_bwd_dt_scatter: empty problem / null operand");
+  SM_REQUIRE(H % 64 == 0 && H <= 1024, "sm_sparse_head_bwd_dt_scatter: H=%d must be a multiple of 64 (<= 1024)", H);
+  SM_REQUIRE(B <= 65535, "sm_sparse_head_bwd_dt_scatter: B=%d documents exceed the grid", B);
+  hipLaunchKernelGGL(head_dt_scatter_kernel, dim3(sm_cdiv(V, 1024), B), dim3(256), 0, (hipStream_t)stream, grad_rep, rep, argmax, (const bf16*)E,
+                     dt32, B, S, H, V, use_l0, rag ? rag->doc_off : nullptr, rag ? rag->rows : B * S);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
+
 extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* t,
                                   const void* E, void* dt, float* dE, float* dbias, int B, int S, int H, int V, int use_l0,
                                   const sm_ragged* rag, void* stream) {
@@ -686,16 +736,16 @@ extern "C" int sm_flops_bwd(const float* rep, const float* colmean, const float*
 }
 
 // csrc/scores_mfma.hip: the all-pairs products on the matrix pipe (fp32 MFMA); false = shape left to the scalar kernels here
-bool sm_scores_mfma_fwd(const float* q, const float* d, int nq, int nd, int D, float* scores, hipStream_t st);
+bool sm_scores_mfma_fwd(const float* q, const float* d, int nq, int nd, int D, float* scores, hipStream_t st, bool deterministic);
 bool sm_scores_mfma_wsum(const float* w, long ws_i, long ws_j, const float* x, int ni, int nj, int D, float* out, int accumulate, hipStream_t st);
 
 extern "C" int sm_scores_fwd(const float* q, const float* d, int nq, int nd, int D, int pairs, float* scores, void* stream) {
   SM_REQUIRE(nq > 0 && nd > 0 && D > 0, "sm_scores_fwd: empty problem");
   hipStream_t st = (hipStream_t)stream;
-  if (pairs) {
+  if (pairs & 1) {
     SM_REQUIRE(nd % nq == 0, "sm_scores_fwd: nd=%d must be a multiple of nq=%d", nd, nq);
     hipLaunchKernelGGL(scores_pairs_kernel, dim3(sm_cdiv(nd, 4)), dim3(256), 0, st, q, d, nq, nd / nq, D, scores);
-  } else if (!sm_scores_mfma_fwd(q, d, nq, nd, D, scores, st)) {
+  } else if (!sm_scores_mfma_fwd(q, d, nq, nd, D, scores, st, (pairs & 2) != 0)) {
     hipLaunchKernelGGL(scores_all_kernel, dim3(sm_cdiv(nd, 16), sm_cdiv(nq, 16)), dim3(256), 0, st, q, d, nq, nd, D, scores);
   }
   SM_LAUNCH_CHECK();

@@ -33,9 +33,10 @@ class DataTrainingArguments:
     idf_lr: Optional[float] = None
     first_rank_thresh: int = 10000
     flops_threshold: Optional[int] = None
-    # N > 1 only: "gather" = the reference's dense all-gather of the representations (scripts/utils.py:16-23,
-    # default), "scores" = exchange queries / score blocks / FLOPS column means instead (opt-in); identical results
-    dist_exchange: str = "scores"
+    # N > 1 only: "gather" = the reference's dense all-gather of the representations (scripts/utils.py:16-23; what north_star
+    # names: the default since round 5), "scores" = exchange queries / score blocks / FLOPS column means instead (opt-in: same loss,
+    # same gradients, ~100x less traffic -- DESIGN section 6 has the predicted step times of both)
+    dist_exchange: str = "gather"
     # extension (no reference key): documents per chunk of the rep-level gradient caching (0 = off): forward without saved
     # activations, then per chunk re-forward + backward once d loss / d rep is known (sparse_hip.encoder.encode_cached)
     grad_cache_chunk: int = 0

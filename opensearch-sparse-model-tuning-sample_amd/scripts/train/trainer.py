@@ -226,13 +226,13 @@ class SparseModelTrainer:
         return [(ids[a:a + n], mask[a:a + n], None) for a in range(0, ids.shape[0], n)]
 
     def _use_score_exchange(self) -> bool:
-        """N > 1: the default (data_args.dist_exchange = "scores") exchanges queries, score blocks and FLOPS column means
-        (sparse_hip.functional.distributed_loss: same loss, same gradients as the reference's dense all-gather of the
-        representations, ~100x less traffic and every V-length loss kernel stays on the local documents).  SM_EXCHANGE=gather or
-        dist_exchange: gather selects the reference's own form (utils.py:16-23), kept as the parity mode."""
+        """N > 1: data_args.dist_exchange = "gather" (default) is the reference's form and the one north_star names -- RCCL all-gather
+        of the document representations (utils.py:16-23), every rank evaluates the whole loss.  "scores" (opt-in, SM_EXCHANGE=scores)
+        exchanges queries, score blocks and FLOPS column means instead (sparse_hip.functional.distributed_loss: same loss, same
+        gradients, ~100x less traffic, every V-length loss kernel stays on the local documents)."""
         if self.accelerator.num_processes <= 1:
             return False
-        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "scores"))
+        mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "gather"))
         if mode not in ("scores", "gather"):
             raise KeyError(mode)
         return mode == "scores"

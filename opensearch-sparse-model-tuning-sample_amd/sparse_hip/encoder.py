@@ -190,6 +190,8 @@ KERNEL_OPTIONS = {
     "ffn_fwd_f16": ("SM_FFN_FWD_F16", None, bool),            # fp16 operands of the UNFUSED feed-forward forward; None: models of >= 10 layers
     "fp8_delayed": ("SM_FP8_DELAYED", True, bool),            # fp8 runs: previous step's maxima as scales from step 2 on
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
+    "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
+    "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
     "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
     "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
@@ -232,7 +234,7 @@ class HipBertMLM(torch.nn.Module):
         # producer / consumer launch, 195-215 us against 250-265 us of the unfused launches at 43.9 k rows): bf16 runs with the fp32
         # residual stream at hidden size 384; the backward is fused the same way (pc_ffn_bwd below).
         # ffn_f16: its operands are fp16 instead of bf16 (same MFMA rate, three more mantissa bits; gradients stay bf16).
-        # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_fused_gpu.py).
+        # SM_PC_FFN=0 / SM_FFN_F16=0 switch either off (both are covered by tests/test_ffn_pc_gpu.py).
         # Both numerics-relevant defaults are constructor arguments (ModelArguments.fused_ffn / fwd_f16, logged at start-up); the
         # environment switches remain for A/B runs and are overridden by an explicit argument.
         self.ffn_f16 = opt("ffn_f16")
@@ -306,6 +308,15 @@ class HipBertMLM(torch.nn.Module):
         self.graph_tokens = opt("encode_graph_tokens")
         self.wgrad_stream = opt("wgrad_stream")
         self.tn_group = opt("tn_group")
+        # Density-adaptive head backward: the share of live sparse activations of the PREVIOUS encode (counted on a sample of the
+        # columns, read back without stalling: by the next step the copy has long landed) picks between the matrix form of dt = G . E
+        # (head_dt192_kernel: 2 T V H flops whatever the density) and the scatter over the live entries (head_dt_scatter_kernel).
+        # Both are exact; the choice only moves time.  Random init: ~100 % alive -> matrix form; a trained checkpoint: ~1 %.
+        self.dt_scatter = opt("dt_scatter")
+        self.dt_scatter_density = opt("dt_scatter_density")
+        self._density = None        # share of live activations measured at the previous encode
+        self._density_probe = None  # (event, pinned count, sampled elements) of the encode before
+        self._density_host = None
         self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
@@ -436,7 +447,7 @@ class HipBertMLM(torch.nn.Module):
     def kernel_options(self) -> dict:
         """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
         return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
-                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "encode_graph": self.graph_encode,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
                 "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
 
     def sync_weights(self) -> None:
@@ -646,6 +657,25 @@ class HipBertMLM(torch.nn.Module):
             x = x2
         self._x_last_f16 = xh_last
         return x, saved
+
+    def probe_density(self, rep: Tensor) -> None:
+        """Start counting the live entries of `rep` (every 16th column) and take over the count of the PREVIOUS call: the host never
+        waits for work of the current step (the trainer runs up to two steps ahead of the device)."""
+        prev = self._density_probe
+        if prev is not None:
+            ev, host, n = prev
+            ev.synchronize()  # the encode before this one: finished long ago
+            self._density = float(host.item()) / n
+        sample = rep[:, ::16]
+        cnt = torch.count_nonzero(sample)  # (rep = log1p(relu(.)) >= 0: non-zero = alive)
+        if self._density_host is None:
+            self._density_host = [torch.empty((), dtype=cnt.dtype).pin_memory() for _ in range(2)]
+        self._density_host.reverse()       # the buffer of the call before the previous one: its value has been read
+        host = self._density_host[0]
+        host.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._density_probe = (ev, host, sample.numel())
 
     def hidden_states(self, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
         """Last hidden states [B,S,H] (no grad) -- used by frozen dense teachers."""
@@ -922,6 +952,8 @@ class _EncodeFn(torch.autograd.Function):
             rep, argmax = ops.sparse_head_fwd(tn, st["E"], v(c + "bias"), mask, B, S, cfg.vocab_size, use_l0, rag)
         if prune_ratio is not None:
             ops.prune_rows(rep, prune_ratio)
+        if need_grad and model.dt_scatter:
+            model.probe_density(rep)
         if model._argmax_log is not None:  # test hook: which position each (doc, vocab) max came from
             model._argmax_log.append(argmax)
         if need_grad:
@@ -953,11 +985,14 @@ class _EncodeFn(torch.autograd.Function):
         head_args = (grad_rep, rep, argmax, tn, st["E"], g(e + "word_embeddings.weight"), g(c + "bias"), B, S, cfg.vocab_size, use_l0, rag)
         wg.call(lambda: ops.sparse_head_bwd(*head_args, part="de"), grad_rep, rep, argmax, tn)
         head_de_done = wg.mark()
-        dft = ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, st["E"], B, S, cfg.vocab_size, use_l0, rag, gt,
-                                        v(c + "transform.LayerNorm.weight"), mt, rt, ft,
-                                        g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
+        scatter = (model.dt_scatter and model._density is not None and model._density < model.dt_scatter_density
+                   and st["E"].dtype == torch.bfloat16)
+        dft = None if scatter else ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, st["E"], B, S, cfg.vocab_size, use_l0, rag, gt,
+                                                             v(c + "transform.LayerNorm.weight"), mt, rt, ft,
+                                                             g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
         if dft is None:
-            dtn = ops.sparse_head_bwd(*head_args, part="dt")
+            dtn = (ops.sparse_head_bwd_dt_scatter(grad_rep, rep, argmax, st["E"], B, S, cfg.vocab_size, use_l0, rag, tn.shape[0])
+                   if scatter else ops.sparse_head_bwd(*head_args, part="dt"))
             dgt, _ = ops.layernorm_bwd(dtn, gt, v(c + "transform.LayerNorm.weight"), mt, rt,
                                        g(c + "transform.LayerNorm.weight"), g(c + "transform.LayerNorm.bias"))
             dft = ops.gelu_bwd(dgt, ft)

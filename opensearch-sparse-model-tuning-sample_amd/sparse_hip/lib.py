@@ -90,6 +90,7 @@ SIGNATURES = {
     "sm_prune_rows": [_p, _i, _i, _f, _p],
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "sm_sparse_head_bwd_dt_scatter": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],
     "sm_flops_fwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p],

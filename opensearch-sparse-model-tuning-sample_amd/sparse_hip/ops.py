@@ -5,6 +5,8 @@ libsparse_hip.so.  Every wrapper raises if a tensor is not on the GPU.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional
 
@@ -377,6 +379,20 @@ def sparse_head_bwd_dt_ln(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tens
     return dft if ok else None
 
 
+def sparse_head_bwd_dt_scatter(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tensor, B: int, S: int, V: int, use_l0: bool,
+                               rag: Optional[Ragged], rows: int) -> Tensor:
+    """dt half of the head backward as a scatter over the LIVE (document, vocabulary) entries (csrc/sparse_head.hip,
+    head_dt_scatter_kernel): returns dt[rows, H] in E's dtype (fp32 sums rounded once).  Exact at any density, fast below a few per
+    cent of live activations -- a trained sparse encoder's regime."""
+    if E.dtype != torch.bfloat16:
+        raise L.SparseHipError("sparse_head_bwd_dt_scatter takes the bf16 staging copy of the tied embeddings")
+    H = E.shape[1]
+    dt32 = torch.zeros((rows, H), dtype=torch.float32, device=E.device)
+    L.call("sm_sparse_head_bwd_dt_scatter", L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E), L.ptr(dt32), B, S, H, V, int(use_l0),
+           _rag_ref(rag), L.stream_ptr())
+    return dt32.to(E.dtype)
+
+
 # ---------------------------------------------------------------- [B,V] kernels
 def inf_free_fwd(ids: Tensor, idf: Tensor, special: Tensor) -> Tensor:
     bs, sq = ids.shape
@@ -410,11 +426,15 @@ def flops_bwd(rep: Tensor, colmean: Tensor, rowkeep: Optional[Tensor], gscale: T
            L.ptr(grad), int(accumulate), L.stream_ptr())
 
 
-def scores_fwd(q: Tensor, d: Tensor, pairs: bool) -> Tensor:
+DETERMINISTIC_SCORES = os.environ.get("SM_DETERMINISTIC", "0") == "1"  # all-pairs score matrices without split-K atomics (bit-reproducible)
+
+
+def scores_fwd(q: Tensor, d: Tensor, pairs: bool, deterministic: Optional[bool] = None) -> Tensor:
     nq, D = q.shape
     nd = d.shape[0]
     out = _new((nq, nd // nq) if pairs else (nq, nd), torch.float32, q)
-    L.call("sm_scores_fwd", L.ptr(q), L.ptr(d), nq, nd, D, int(pairs), L.ptr(out), L.stream_ptr())
+    det = DETERMINISTIC_SCORES if deterministic is None else bool(deterministic)
+    L.call("sm_scores_fwd", L.ptr(q), L.ptr(d), nq, nd, D, int(pairs) | (2 if det else 0), L.ptr(out), L.stream_ptr())
     return out
 
 

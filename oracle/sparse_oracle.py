@@ -423,3 +423,24 @@ def postprocess_rows(sparse_vector: Tensor):
         idx = idx[idx != 0]
         out.append((idx.tolist(), row[idx].tolist()))
     return out
+
+
+def make_trained_like(p, oc, docs, g, outliers=5, alive=0.01):
+    """Statistics of a fine-tuned sparse encoder (config_infonce.yaml:5 names a trained checkpoint) instead of N(0, 0.02) init:
+    a handful of OUTLIER hidden dimensions (x20 in the embeddings and in the rows that write them into the residual stream),
+    LayerNorm gains of up to 5 on them, and a decoder bias shifted until about 1 % of the (document, vocabulary) activations are
+    alive -- the regime the head kernels' zero-skipping paths and the fp16 operands live in."""
+    H = oc.hidden_size
+    dims = torch.randperm(H, generator=g)[:outliers]
+    p["bert.embeddings.word_embeddings.weight"][:, dims] *= 20.0
+    for n in p:
+        if n.endswith("LayerNorm.weight"):
+            p[n][dims] = 2.0 + 3.0 * torch.rand(outliers, generator=g)
+        if n.endswith("attention.output.dense.weight") or (n.endswith("output.dense.weight") and "attention" not in n):
+            p[n][dims, :] *= 20.0
+    with torch.no_grad():  # calibrate the bias shift on the first documents
+        lg = bert_mlm_logits(p, docs["input_ids"][:8], docs["attention_mask"][:8], oc)
+        mx = lg.masked_fill(~docs["attention_mask"][:8].bool()[:, :, None], float("-inf")).max(1).values
+        shift = float(torch.quantile(mx.flatten()[:: max(1, mx.numel() // 1_000_000)], 1.0 - alive))
+    p["cls.predictions.bias"] -= shift
+    print(f"[trained-like] outlier dims {sorted(dims.tolist())}, decoder bias shifted by {-shift:.3f}")

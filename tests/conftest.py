@@ -23,7 +23,7 @@ def golden_dir():
 
 # kernel / end-to-end parity first; the multi-process cases (every leg bounded to 120 s in its own process group) run BEFORE the
 # slow full-size files: in round 3 one failure in test_fullsize_gpu hid all twelve distributed legs behind `-x`
-_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_asm_hazards_cpu", "test_asan_cpu", "test_kernels_gpu", "test_ffn_fused_gpu", "test_e2e_gpu",
+_ORDER = ("test_oracle_golden", "test_host_cpu", "test_datasets_cpu", "test_asm_hazards_cpu", "test_asan_cpu", "test_kernels_gpu", "test_ffn_pc_gpu", "test_e2e_gpu",
           "test_distributed", "test_bench_cli", "test_baseline_configs_gpu", "test_fullsize_gpu")
 
 

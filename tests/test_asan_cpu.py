@@ -42,6 +42,14 @@ run("sm_gemm_nt_ln_bwd", L.SM_BF16, P(10), I, P(11), I, T, H, I, P(12), P(13), P
 run("sm_gemm_tn_acc", L.SM_BF16, P(10), H, P(11), I, P(12), I, T, H, I, P(13), None)
 run("sm_gemm_tn_acc", L.SM_F32, P(10), 72, P(11), 136, P(12), 136, 300, 72, 136, None, None)
 run("sm_gemm_tn_acc_bcm", P(10), 1, P(11), 0, P(12), H, 43904, I, H, P(13), None)
+# the grouped weight gradients of a layer (both kernels: every N a multiple of 384 -> symmetric; N = 576 -> [192 x 192] tiles), a BCM operand
+grp = (L.SmTnProblem * 4)(L.SmTnProblem(P(10).value, H, 0, P(11).value, 0, 1, P(12).value, I, H, I, P(13).value),
+                          L.SmTnProblem(P(14).value, 0, 1, P(15).value, H, 0, P(16).value, H, I, H, P(17).value),
+                          L.SmTnProblem(P(18).value, H, 0, P(19).value, H, 0, P(20).value, H, H, H, None),
+                          L.SmTnProblem(P(21).value, 3 * H + 64, 0, P(22).value, H, 0, P(23).value, H, 3 * H, H, P(24).value))
+run("sm_gemm_tn_group", 4, grp, T, None)
+one = (L.SmTnProblem * 1)(L.SmTnProblem(P(10).value, 576, 0, P(11).value, 192, 0, P(12).value, 192, 576, 192, None))
+run("sm_gemm_tn_group", 1, one, 43904 + 16, None)
 run("sm_ffn_pc_stage", 1, P(10), P(11), 1000000, 6, H, I, P(12), P(13), P(14), P(15), None)
 run("sm_ffn_pc_fwd", 1, P(10), P(11), P(12), 1e-12, P(13), P(14), P(15), P(16), P(17), P(18), C.byref(drop), P(19), P(20), P(21), P(22), P(23), P(24), P(25), P(26), 43904, H, I, None)
 run("sm_ffn_pc_bwd", P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), P(18), C.byref(drop), P(19), P(20), P(21), P(22), P(23), P(24), 43904, H, I, None)
@@ -57,6 +65,7 @@ run("sm_sparse_head_bwd", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), P(15), P
 run("sm_sparse_head_bwd_dt_ln", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), B, S, H, V, 0, None, P(15), P(16), P(17), P(18), P(19), P(20), P(21), 1, None)
 run("sm_flops_fwd", P(10), B, 16, V, 150, P(11), P(12), P(13), None)
 run("sm_scores_fwd", P(10), P(11), 32, B, V, 0, P(12), None)
+run("sm_scores_fwd", P(10), P(11), 32, B, V, 2, P(12), None)   # deterministic form
 run("sm_row_compact", P(10), 32, V, 32, P(11), P(12), P(13), P(14), None)
 run("sm_infonce_fwd_bwd", P(10), 32, B, 16, 0, P(11), P(12), None)
 run("sm_adamw", P(10), P(11), P(12), P(13), 22700000, 2e-5, 0.9, 0.999, 1e-8, 0.01, 7, 1.0, None)

@@ -52,9 +52,13 @@ def test_cli_defaults_follow_the_measurement_protocol():
 
 @pytest.mark.gpu
 def test_bench_one_gpu_line():
-    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
+    # the two records that ride beside `value` (round 5): the step at ~1 % live activations, configs[4]'s per-GPU shape on one GPU
+    sr, c5 = j["sparse_regime"], j["c5_per_gpu"]
+    assert "error" not in sr and 0.003 < sr["alive_fraction"] < 0.03 and sr["alive_fraction_random_init"] > 0.5 and sr["ms_per_step"] > 0, sr
+    assert "error" not in c5 and c5["ms_per_step"] > 0 and c5["peak_memory_gib"] < 200, c5
     assert REQUIRED <= set(j), REQUIRED - set(j)
     assert j["n_gpus"] == 1 and j["steps"] == 4 and j["unit"] == "samples/sec" and j["dtype"] == "bf16" and j["vs_baseline"] is None
     assert abs(j["value"] - 32 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
@@ -83,3 +87,4 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j and j["value"] > 0 and j["finite"] is True
+    assert j["dist"]["world_size"] == 2 and j["dist"]["backend"] == "gloo" and j["dist"]["exchange"] == "gather"  # self-describing N > 1 record

@@ -375,8 +375,9 @@ cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_at
                      max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
 bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None)
 bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
-model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
 case = os.environ["SM_TEST_CASE"]
+c3 = case == "c3_l0_threshold_ibn"   # BASELINE configs[2]'s recipe (config_l0.yaml:16-19): L0 activation + FLOPS row threshold + in-batch negatives
+model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=c3)
 K = 16 if case == "infonce_ibn_k16" else 3
 inf_free = case != "learned_queries"
 kd = case == "kd_scores"
@@ -384,9 +385,9 @@ ibn = not kd
 kind = "kldiv" if kd else "infonce"
 gc = 8 if case == "infonce_ibn_k16" else 0   # k = 16 also runs rep-level gradient caching (8 documents per chunk): the slices are
                                               # then all-reduced from inside the LAST chunk's backward
-margs = ModelArguments(model_name_or_path="x", inf_free=inf_free)
-dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.05, flops_d_T=10, flops_q_lambda=0.03,
-                              flops_q_T=10, flops_threshold=3 if kd else None, grad_cache_chunk=gc)
+margs = ModelArguments(model_name_or_path="x", inf_free=inf_free, use_l0=c3)
+dargs = DataTrainingArguments(loss_types=[kind], use_in_batch_negatives=ibn, flops_d_lambda=0.08 if c3 else 0.05, flops_d_T=10, flops_q_lambda=0.03,
+                              flops_q_T=10, flops_threshold=3 if (kd or c3) else None, grad_cache_chunk=gc)
 targs = TrainingArguments(output_dir="/tmp/sm_dist", logging_steps=1000, learning_rate=1e-3, weight_decay=0.01, warmup_steps=0, max_steps=6)
 trainer = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
                              loss_functions=[LOSS_CLS_MAP[kind](use_in_batch_negatives=ibn, weight=0.7, temperature=2.0)])
@@ -415,7 +416,7 @@ if world > 1:
 print("done", rank)
 """
 
-N_CASES = {4: ["infonce_ibn_k3", "kd_scores"], 8: ["infonce_ibn_k16", "learned_queries"]}
+N_CASES = {4: ["infonce_ibn_k3", "kd_scores"], 8: ["infonce_ibn_k16", "learned_queries", "c3_l0_threshold_ibn"]}
 
 
 @pytest.mark.gpu
@@ -424,7 +425,8 @@ def test_four_and_eight_rank_steps_equal_the_single_process_step(tmp_path, world
     """4 and 8 ranks (gloo, all on the single test GPU), both exchange modes, against ONE process stepping on the concatenated
     batch of 8 queries: k = 3 and k = 16 documents per query with in-batch negatives (k = 16 with rep-level gradient caching,
     i.e. the overlapped slice all-reduce fired from the last chunk's backward), KL distillation on teacher scores, learned
-    queries (the query gradient crosses ranks).  The reference's invariant: utils.py:16-23 + trainer.py:139-141."""
+    queries (the query gradient crosses ranks), and at 8 ranks BASELINE configs[2]'s recipe (use_l0 + flops_threshold + in-batch
+    negatives: the thresholded FLOPS column means cross ranks).  The reference's invariant: utils.py:16-23 + trainer.py:139-141."""
     script = tmp_path / "worker_n.py"
     script.write_text(WORKER_N)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", SM_TEST_CASE=case)

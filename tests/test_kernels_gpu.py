@@ -557,6 +557,44 @@ def test_sparse_head_fwd_bwd(ops, dtype, B, S, H, V, use_l0):
     close(dbias, br.grad, tol * 2, "dbias")
 
 
+@pytest.mark.parametrize("H,B,S,V", [(384, 9, 128, 30522), (384, 3, 16, 130), (768, 11, 128, 2100), (128, 7, 32, 1025)])
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("density", [0.01, 0.6])
+def test_head_dt_scatter_is_the_routed_sum_in_fp32(ops, H, B, S, V, ragged, density):
+    """dt half of the head backward as a scatter over the live entries (head_dt_scatter_kernel, the trained-checkpoint regime):
+    dt[row(d) + argmax[d, v]] += g[d, v] E[v] in fp32, rounded to bf16 once -- against a float64 evaluation, at 1 % and 60 % of the
+    activations alive, dense and ragged layouts, a vocabulary that is no multiple of the 1024 columns of a workgroup; and against
+    the matrix form (head_dt192 / head_dt_mfma), which rounds G to bf16 first"""
+    g = torch.Generator().manual_seed(H + B + int(density * 100))
+    if ragged:
+        lens = (torch.randint(1, S // 16 + 1, (B,), generator=g) * 16).tolist()
+        _, off_np, rows, row_doc, pos, _ = _ragged(lens)
+        rag = ops.Ragged(dev(off_np.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, S)
+        off = off_np.tolist()
+    else:
+        lens, off, rag = [S] * B, [i * S for i in range(B + 1)], None
+    T = off[-1]
+    E = (torch.randn(V, H, generator=g) * 0.3).to(torch.bfloat16)
+    rep = torch.rand(B, V, generator=g) + 0.05
+    rep[torch.rand(B, V, generator=g) >= density] = 0.0
+    rep[B // 2] = 0.0                     # a document without any gradient
+    grad = torch.randn(B, V, generator=g)
+    am = torch.stack([torch.randint(0, lens[b], (V,), generator=g) for b in range(B)]).to(torch.int16)
+    args = (dev(grad), dev(rep), dev(am).view(torch.uint16), dev(E, torch.bfloat16), B, S, V, False, rag)
+    dt = ops.sparse_head_bwd_dt_scatter(*args, T)
+    gr = grad.double() * torch.where(rep > 0, torch.exp(-rep.double()), torch.zeros(B, V, dtype=torch.float64))
+    want = torch.zeros(T, H, dtype=torch.float64)
+    for b in range(B):
+        want.index_add_(0, off[b] + am[b].long(), gr[b][:, None] * E.double())
+    scale = float(want.abs().max())
+    err = float((dt.double().cpu() - want).abs().max())
+    assert err <= 2 ** -8 * scale, f"scatter vs float64: {err:.3e} of {scale:.3e}"  # one bf16 rounding of the fp32 sum
+    dtm = ops.sparse_head_bwd(args[0], args[1], args[2], torch.zeros(T, H, dtype=torch.bfloat16, device="cuda"), args[3], None, None, B, S, V,
+                              False, rag, part="dt")
+    assert float((dtm.double().cpu() - want).abs().max()) <= 2e-2 * scale  # the matrix form: G rounded to bf16 before the product
+    assert float((dtm.float() - dt.float()).abs().max()) <= 2e-2 * scale
+
+
 @pytest.mark.parametrize("H,B,S,V", [(128, 7, 32, 333), (256, 5, 64, 1000), (384, 9, 128, 30522), (384, 1, 16, 130), (512, 6, 48, 257),
                                      (768, 11, 128, 2100), (1024, 18, 16, 515)])
 @pytest.mark.parametrize("ragged", [False, True])
@@ -1002,6 +1040,10 @@ def test_scores_on_the_matrix_pipe(ops, nq, nd):
     wq, wd = ds.double() @ d.double(), ds.double().t() @ q.double() + 0.5
     assert float((dq.double() - wq).abs().max() / wq.abs().max()) < 1e-4
     assert float((dd_.double() - wd).abs().max() / wd.abs().max()) < 1e-4
+    # deterministic form (one split of V, no atomics): the same matrix bit for bit on every launch
+    s1, s2 = ops.scores_fwd(q, d, False, deterministic=True), ops.scores_fwd(q, d, False, deterministic=True)
+    assert torch.equal(s1, s2)
+    assert float((s1.double() - want).abs().max() / want.abs().max()) < 1e-4
 
 
 # ---- weight-stationary NT GEMM for K = 384 (csrc/gemm_ws.hip) ------------------------------------------------------------------
@@ -1034,7 +1076,7 @@ def test_gemm_ws_df1_epilogue(ops, M):
     GELU), K = 384, N = 1536: against torch on the row-major f1"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from test_ffn_fused_gpu import _f1_tiles
+    from test_ffn_pc_gpu import _f1_tiles
     N = 1536
     g = torch.Generator(device="cuda").manual_seed(7)
     a = (torch.randn(M, 384, device="cuda", generator=g) * 0.5).to(torch.bfloat16)

@@ -5,7 +5,7 @@ bf16 rounding inserted at chosen storage points, at BASELINE configs[1]'s model 
      (what torch autocast does: hf modeling_bert.py:289-293, 347-351)
   C  only the GEMM weights rounded (activations fp32): the floor any bf16-operand path has
 Prints, against the all-fp32 oracle: worst |err| / (1 + |ref|) of rep, share of elements inside 1e-2, relative Frobenius error.
-    python tools/bf16_error_budget.py [n_docs]"""
+    python tools/bf16_error_budget.py [n_docs] [mini|base] [seq] [trained]   (trained: outlier dimensions, LayerNorm gains up to 5, ~1 % alive)"""
 import math, os, sys
 import torch
 import torch.nn.functional as F
@@ -53,8 +53,9 @@ def encode(p, ids, mask, cfg, act_round, resid_fp32, z_fp32=None):
 
 def main():
     nd = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    shape = sys.argv[2] if len(sys.argv) > 2 else "mini"      # mini | base (bert-base, 12 layers: BASELINE configs[3] / [4])
-    S = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    pos = [a for a in sys.argv[2:] if a != "trained"]
+    shape = pos[0] if len(pos) > 0 else "mini"      # mini | base (bert-base, 12 layers: BASELINE configs[3] / [4])
+    S = int(pos[1]) if len(pos) > 1 else 128
     cfg = O.BertShape() if shape == "mini" else O.BertShape(30522, 768, 12, 12, 3072, 512)
     p = O.init_params(cfg, seed=2)
     g = torch.Generator().manual_seed(102)
@@ -63,10 +64,12 @@ def main():
             p[n] = 0.02 * torch.randn(p[n].shape, generator=g)
         elif n.endswith("LayerNorm.weight"):
             p[n] = 1 + 0.05 * torch.randn(p[n].shape, generator=g)
-    pw = {n: (r(v) if v.dim() == 2 and "position" not in n and "token_type" not in n else v) for n, v in p.items()}
     k = min(nd, 16)
     ds = SyntheticTriplesDataset(nd // k, k, S, 32, cfg.vocab_size, seed=9, len_mean=S * 0.625, len_std=S * 0.234)
     d = PreTokenizedCollator()([ds[i] for i in range(nd // k)])["docs"][0]
+    if "trained" in sys.argv[2:]:  # the statistics of a fine-tuned checkpoint (oracle.make_trained_like; tests: test_c2_slice_at_trained_checkpoint_statistics)
+        O.make_trained_like(p, cfg, d, g)
+    pw = {n: (r(v) if v.dim() == 2 and "position" not in n and "token_type" not in n else v) for n, v in p.items()}
     with torch.no_grad():
         ref = O.sparse_activation(O.bert_mlm_logits(p, d["input_ids"], d["attention_mask"], cfg), d["attention_mask"])
         for name, (params, act, res, zf) in {"C weights only": (pw, False, True, True), "B fp32 residual stream": (pw, True, True, True),

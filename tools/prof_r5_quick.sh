@@ -1,5 +1,5 @@
 out=$PWD/gpurun_out/r5d; mkdir -p $out; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --only-value-layout --no-cpu-baseline > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --only-value-layout --no-cpu-baseline --no-extras > $out/stats.log 2>&1
 cp $(find $out/stats -name 's_kernel_stats.csv' | head -1) $out/kernel_stats.csv
 python3 tools/step_timeline.py $(find $out/stats -name 's_kernel_trace.csv' | head -1) 5 all > $out/step_timeline_all.txt 2>&1
 rm -rf $out/stats
