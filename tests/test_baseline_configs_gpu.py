@@ -31,7 +31,7 @@ V = 30522
 ARGMAX_MISMATCH = 3e-4  # share of the checked maxima that may sit at another position (measured <= 1.1e-5 at random init with 6 layers,
                         # 1.0e-4 with 12: the far tail of the per-logit error of a NON-maximal position, which no output bound
                         # constrains; a routing bug moves most of them)
-TRAINED_ELEMENTWISE, TRAINED_FROB = 1.9e-1, 2.9e-2  # trained-like statistics: the bf16-operand (autocast) emulation's worst element / rel. Frobenius
+TRAINED_ELEMENTWISE, TRAINED_FROB = 2.9e-1, 3.6e-2  # trained-like statistics: the bf16-operand (autocast) emulation's worst element / rel. Frobenius on the test's 64 documents
 ELEMENTWISE_BF16 = 1e-2   # worst element, in units of (1 + |ref|): the north star's bf16 bound, met ELEMENTWISE against the UNROUNDED
                           # fp32 oracle with the defaults (fp32 residual stream, fp16 forward operands in the head and, for deep
                           # models, the feed-forward): measured c1 3.5e-3, c2 4.0e-3, c3 4.0e-3, c4 6.5e-3, c5 6.3e-3;
@@ -422,17 +422,18 @@ def test_c2_slice_with_every_dropout_site_on_as_in_the_bench_step(varlen):
 def test_c2_slice_at_trained_checkpoint_statistics(varlen, scatter):
     """config_infonce.yaml:5 fine-tunes a TRAINED sparse encoder: outlier hidden dimensions (x20), LayerNorm gains up to 5, about
     1 % of the sparse activations alive (oracle.make_trained_like).  The live activations are then small differences of logits of
-    size ~10, and 1e-2 (1 + |ref|) is BELOW what bf16 weights alone cost: a CPU emulation that rounds nothing but the GEMM weights
-    to bf16 (tools/bf16_error_budget.py 16 trained) sits at worst element 1.44e-1, 99.69 % inside 1e-2, relative Frobenius
-    2.0e-2; with bf16 activation operands as well (torch autocast's arithmetic) at 1.84e-1 / 99.59 % / 2.8e-2.  The HIP path
-    (fp16 forward operands in the head and the feed-forward) measures 1.33e-1 / 99.62 % / 2.0e-2: at the weights-only floor.  The
+    size ~10, and 1e-2 (1 + |ref|) is BELOW what bf16 weights alone cost: on this test's 64 documents a CPU emulation that rounds
+    nothing but the GEMM weights to bf16 (tools/bf16_error_budget.py 64 trained) sits at worst element 2.18e-1, 99.59 % inside
+    1e-2, relative Frobenius 2.7e-2; with bf16 activation operands as well (torch autocast's arithmetic) at 2.90e-1 / 99.45 % /
+    3.6e-2.  The HIP path (fp16 forward operands in the head and the feed-forward) measures 2.24e-1 / 99.77 % / 2.5e-2 against the
+    unrounded fp32 oracle: at or inside the weights-only floor.  The
     test asserts the autocast emulation's figures as bounds; gradients as everywhere.  This is where the sigmoid-form GELU, the
     fp16 operands and the head kernels' zero-skipping paths have to hold.  scatter: the head backward w.r.t. the hidden states through
     head_dt_scatter_kernel (what the density-adaptive dispatch picks in this regime) instead of the matrix form."""
     _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=11,
                   what=f"c2 slice, trained-like statistics, varlen={varlen}, dt scatter={scatter}", force_dt_scatter=scatter,
                   varlen=varlen, trained_like=True, argmax_allowed=5e-3, elementwise=TRAINED_ELEMENTWISE, frob=TRAINED_FROB,
-                  fraction_inside=0.99, loss_tol=3e-2)  # (measured 1.1e-3: the live logits are small differences of
+                  fraction_inside=0.994, loss_tol=3e-2)  # (measured 1.1e-3: the live logits are small differences of
                                                                           # large pre-bias values, whose rounding the output bound does not scale with)
 
 
