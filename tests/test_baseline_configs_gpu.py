@@ -433,7 +433,7 @@ def test_c2_slice_at_trained_checkpoint_statistics(varlen, scatter):
     _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=11,
                   what=f"c2 slice, trained-like statistics, varlen={varlen}, dt scatter={scatter}", force_dt_scatter=scatter,
                   varlen=varlen, trained_like=True, argmax_allowed=5e-3, elementwise=TRAINED_ELEMENTWISE, frob=TRAINED_FROB,
-                  fraction_inside=0.994, loss_tol=3e-2)  # (measured 1.1e-3: the live logits are small differences of
+                  fraction_inside=0.994, loss_tol=3e-2, grad_rel=1e-1)  # (gradients: measured <= 5.0e-2 routed / 4.8e-2 un-routed beside a 2.5e-2 forward error)  # (measured 1.1e-3: the live logits are small differences of
                                                                           # large pre-bias values, whose rounding the output bound does not scale with)
 
 
