@@ -408,7 +408,7 @@ def latest_gemm_traffic(layout):
 
 def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
     """The step in the regime a TRAINED sparse encoder lives in (config_infonce.yaml:5 fine-tunes one): the decoder bias is shifted
-    down until ~1 % of the (document, vocabulary) activations are alive (random init: ~100 %), learning rate 0, then `steps` steps
+    down until ~1 % of the (document, vocabulary) activations are alive (the share before the shift is reported too), learning rate 0, then `steps` steps
     are timed.  Only the kernels whose work depends on the activation pattern change (head backward: rows gathered, all-zero
     G slices skipped).  The bias and the learning rate are restored afterwards."""
     try:
@@ -434,6 +434,7 @@ def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
             lo, hi = (mid, hi) if alive() > density else (lo, mid)
         trainer.args.learning_rate = 0.0
         a1 = alive()
+        bb._density, bb._density_tick = None, 0  # the density-adaptive head backward re-measures at once (it samples every 8th encode)
         for i in range(3):
             trainer.training_step(bs_[i % len(bs_)])
         torch.cuda.synchronize()
@@ -446,8 +447,10 @@ def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
             bias.copy_(keep)
         bb.mark_weights_dirty()
         trainer.args.learning_rate = lr
-        return {"what": "the same step with the decoder bias shifted until ~1 % of the sparse activations are alive (a trained checkpoint's "
-                        "regime; random init: all alive), learning rate 0", "layout": layout, "alive_fraction_random_init": a0,
+        dens, bb._density, bb._density_tick = bb._density, None, 0
+        return {"head_backward_form": "scatter over the live entries" if (dens is not None and dens < bb.dt_scatter_density and bb.dt_scatter) else "matrix form",
+                "what": "the same step with the decoder bias shifted until ~1 % of the sparse activations are alive (a trained checkpoint's "
+                        "regime; alive_fraction_random_init = the share before the shift), learning rate 0", "layout": layout, "alive_fraction_random_init": a0,
                 "alive_fraction": a1, "ms_per_step": ms, "samples_per_sec": 32e3 / ms, "steps": steps}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}

@@ -317,6 +317,7 @@ class HipBertMLM(torch.nn.Module):
         self._density = None        # share of live activations measured at the previous encode
         self._density_probe = None  # (event, pinned count, sampled elements) of the encode before
         self._density_host = None
+        self._density_tick = 0
         self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
@@ -664,8 +665,12 @@ class HipBertMLM(torch.nn.Module):
         prev = self._density_probe
         if prev is not None:
             ev, host, n = prev
-            ev.synchronize()  # the encode before this one: finished long ago
+            ev.synchronize()  # an encode before this one: finished long ago
             self._density = float(host.item()) / n
+            self._density_probe = None
+        self._density_tick += 1
+        if self._density is not None and self._density_tick % 8:  # the live share moves slowly: count on every 8th encode (3 small launches)
+            return
         sample = rep[:, ::16]
         cnt = torch.count_nonzero(sample)  # (rep = log1p(relu(.)) >= 0: non-zero = alive)
         if self._density_host is None:
