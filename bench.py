@@ -382,7 +382,7 @@ def csrc_sha() -> str:
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")):  # (.inc: the generated main loops of the grouped weight-gradient kernels)
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
