@@ -376,6 +376,7 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
                       [row] "v"(vrow), [row4] "v"(vrow4), [nst] "s"(nst), [mend] "s"(mend), [sa] "s"(astage), [sb] "s"(bstage),       \
                       [dst] "s"(dst0), [dbgp] "v"(dbgp)
   // waves 0-3 issue their LDS-DMA in the first half of a stage, waves 4-7 (their SIMD partners) in the second
+  if ((args.dbg & 32) && w >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the second-dispatched half (guide: +0-1 %)
   if (args.dbg & 16) {
     if (w < 4) asm volatile(T3_ASM_STAMPS_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
     else asm volatile(T3_ASM_STAMPS_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);

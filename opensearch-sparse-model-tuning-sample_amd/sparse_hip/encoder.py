@@ -479,7 +479,9 @@ class HipBertMLM(torch.nn.Module):
             self._cast_key = (self.flat_param.data_ptr(), len(st))
         self._cast_table.run()
         if self.fwd_f16:  # fp16 copies of the forward operands (a second table: one launch per storage type)
-            ffn16 = self.ffn_fwd_f16 or (self.pc_ffn and self.ffn_f16)  # (the second: small no-grad forwards, see _forward_impl)
+            # (the second: small no-grad forwards, see _forward_impl -- staged from the first such forward on: a training run never
+            # pays for 2 x layers fp16 copies per optimiser step that nothing reads)
+            ffn16 = self.ffn_fwd_f16 or (self.pc_ffn and self.ffn_f16 and self._small_ffn16)
             key16 = (self.flat_param.data_ptr(), ffn16)
             if self._cast_table16 is None or self._cast_key16 != key16:
                 def buf16(k, shape):
@@ -624,6 +626,10 @@ class HipBertMLM(torch.nn.Module):
             # the activation does: these launches evaluate the exact-erf GELU, the fused kernel its sigmoid-form fit, |diff| <= 2.6e-5
             # per activation -- encodings of one document in a small and in a large batch agree to 2e-3, tests/test_e2e_gpu.py)
             f16_ffn = self.ffn_fwd_f16 or (not save and self.pc_ffn and self.ffn_f16 and self.fwd_f16)
+            if f16_ffn and f"w1h{l}" not in st:  # first small no-grad forward of this model: stage the fp16 feed-forward weights now
+                self._small_ffn16 = True
+                self._weights_dirty = True
+                self.sync_weights()
             x1h = None
             if r32:
                 g1, b1 = v(p + "attention.output.LayerNorm.weight"), v(p + "attention.output.LayerNorm.bias")
@@ -812,19 +818,22 @@ class _WgradStream:
         self.pending.append((None, (a, b, out, colsum)))
 
     @staticmethod
-    def _plan_groups(tiles):
-        """consecutive groups of the pending products (tiles[i] = number of [192 x 192] output tiles of product i) for the grouped
-        kernel, which launches tiles * floor(256 / tiles) workgroups: the partition with the fewest idle CU-rounds"""
-        n = len(tiles)
+    def _plan_groups(shapes):
+        """consecutive groups of the pending products (shapes[i] = (N, Kc) of product i) for the grouped kernels: the partition with
+        the least estimated time, in units of one [192 x 192] tile's work.  A group of t tile units runs tiles * floor(256 / tiles)
+        workgroups (tiles of [384 x 192] when every N of the group is a multiple of 384: csrc/gemm_tn2.hip) and pays one atomic
+        flush of the whole grid (~10 units: 29 us of a 265 us layer set) -- a small product alone would be all flush."""
+        n = len(shapes)
         best = {n: (0.0, [])}
         for i in range(n - 1, -1, -1):
             cand = None
-            t = 0
             for j in range(i, min(n, i + 6)):
-                t += tiles[j]
-                rounds = -(-t // 256) if t > 256 else 1
-                wgs = t * max(1, 256 // t) if t <= 256 else t
-                cost = t * (256.0 * rounds / wgs) + 6.0  # tile-work inflated by the idle share of the grid + the launch's atomic flush (~6 tiles' time)
+                grp = shapes[i:j + 1]
+                units = sum((N // 192) * (K // 192) for N, K in grp)
+                tiles = units // 2 if all(N % 384 == 0 for N, _ in grp) else units
+                rounds = -(-tiles // 256)
+                wgs = tiles * max(1, 256 // tiles) if tiles <= 256 else tiles
+                cost = units * (256.0 * rounds / wgs) + 10.0
                 c = (cost + best[j + 1][0], [(i, j + 1)] + best[j + 1][1])
                 if cand is None or c[0] < cand[0] - 1e-9:
                     cand = c
@@ -836,8 +845,11 @@ class _WgradStream:
         if self.group and len(prods) > 0:
             shapes = [(p[0].shape[1], p[1].shape[1]) for p in prods]
             if all(n % 192 == 0 and k % 192 == 0 for n, k in shapes):
-                for lo, hi in self._plan_groups([(n // 192) * (k // 192) for n, k in shapes]):
-                    if not ops.gemm_tn_group(prods[lo:hi]):
+                for lo, hi in self._plan_groups(shapes):
+                    # (a small product on its own -- the head transform's when a gradient-reduction hook forces a flush behind the head --
+                    # would be all atomic flush in the grouped kernel's big tiles: the per-matrix kernel's [128 x 128] tiles take it)
+                    small_alone = hi - lo == 1 and (shapes[lo][0] // 192) * (shapes[lo][1] // 192) <= 8 and shapes[lo][0] % 128 == 0 and shapes[lo][1] % 128 == 0
+                    if small_alone or not ops.gemm_tn_group(prods[lo:hi]):
                         for a, b, out, colsum in prods[lo:hi]:
                             ops.gemm_tn_acc(a, b, out, colsum=colsum)
                 return
@@ -1111,6 +1123,7 @@ HipBertMLM._dropout_without_grad = False
 HipBertMLM._cast_table = None
 HipBertMLM._cast_key = None
 HipBertMLM._cast_table16 = None
+HipBertMLM._small_ffn16 = False
 HipBertMLM._cast_key16 = None
 HipBertMLM._x_last_f16 = None
 HipBertMLM._wgrad = None

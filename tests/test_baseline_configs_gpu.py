@@ -115,7 +115,7 @@ def _check_grads(dtype, bb, pr, what, pr_unrouted=None, grad_rel=None):
 
 def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None, std=0.02, check_grads=True, what="",
                   residual_fp32=None, elementwise=None, grad_cache_chunk=0, unrouted_grads=True, fp8=False, fraction_inside=FRACTION_INSIDE,
-                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None, hidden_dropout=0.0, varlen=None, attn_dropout=0.0, trained_like=False, argmax_allowed=ARGMAX_MISMATCH, force_dt_scatter=None):
+                  frob=1e-2, loss_tol=1e-2, grad_rel=None, ret=None, hidden_dropout=0.0, varlen=None, attn_dropout=0.0, trained_like=False, argmax_allowed=ARGMAX_MISMATCH, force_dt_scatter=None, kernel_options=None):
     """one compute_loss + backward through the HIP path and through the oracle on the same inputs.
     hidden_dropout > 0: the three hidden-dropout sites (embeddings, attention output, feed-forward output) run with that
     probability on the device and the oracle gets the SAME masks (exported through sm_dropout_bwd(ones), DropMasks).
@@ -144,7 +144,7 @@ def _student_step(shape, dtype, nq, k, S, Sq, recipe, seed, teacher_scores=None,
     batch = PreTokenizedCollator()([ds[i] for i in range(nq)])
     if trained_like:
         _make_trained_like(p, oc, batch["docs"][0], g)
-    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32, fp8=fp8)
+    bb = HipBertMLM(cfg, compute_dtype=dtype, device="cuda", init_seed=None, residual_fp32=residual_fp32, fp8=fp8, kernel_options=kernel_options)
     assert bb.fp8 == bool(fp8)
     bb.load_hf_state_dict(p)
     if varlen is not None:
@@ -407,6 +407,16 @@ def test_c2_slice_with_hidden_dropout_on_the_same_masks_in_the_oracle(varlen):
     count that is a multiple of 16 only; dense: 16 384 rows (not a multiple of 192)."""
     _student_step(MINI, torch.bfloat16, nq=8, k=16, S=128, Sq=32, recipe=INFONCE, seed=6, what=f"c2 slice, hidden dropout 0.1, varlen={varlen}",
                   hidden_dropout=0.1, varlen=varlen)
+
+
+@pytest.mark.parametrize("pc_ffn_bwd,wgrad_stream,tn_group", [(0, 1, 1), (1, 0, 1), (0, 0, 0), (1, 1, 0)])
+def test_c2_slice_kernel_option_combinations_with_dropout_on(pc_ffn_bwd, wgrad_stream, tn_group):
+    """the NON-default kernel selections of HipBertMLM (sparse_hip.encoder.KERNEL_OPTIONS) against the oracle, hidden dropout on: the
+    unfused feed-forward backward, weight gradients on the main queue, one launch per weight gradient instead of the grouped kernel
+    -- every combination is a supported configuration and must hold the same bounds as the default"""
+    _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=12, hidden_dropout=0.1,
+                  what=f"c2 slice, pc_ffn_bwd={pc_ffn_bwd} wgrad_stream={wgrad_stream} tn_group={tn_group}",
+                  kernel_options={"pc_ffn_bwd": bool(pc_ffn_bwd), "wgrad_stream": bool(wgrad_stream), "tn_group": bool(tn_group)})
 
 
 @pytest.mark.parametrize("varlen", [True, False])
