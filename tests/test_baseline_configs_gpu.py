@@ -409,6 +409,28 @@ def test_c2_slice_with_hidden_dropout_on_the_same_masks_in_the_oracle(varlen):
                   hidden_dropout=0.1, varlen=varlen)
 
 
+def test_c2_slice_gradient_caching_at_hidden_384_replays_the_first_pass():
+    """rep-level gradient caching at the 384-wide model with chunks far below pc_infer_min_rows: pass 1 (training
+    mode, no grad) must run the SAME kernels as pass 2 (grad on: the fused feed-forward with its sigmoid-form GELU) -- the
+    representations of the two passes are compared bit for bit (before the round-5 fix pass 1 took the unfused exact-erf launches and
+    differed by ~1e-3) -- and the step must match the oracle."""
+    from sparse_hip.encoder import HipBertMLM
+    seen, real = [], HipBertMLM.encode
+
+    def spy(self, *a, **k):
+        rep = real(self, *a, **k)
+        seen.append(rep.detach().clone())
+        return rep
+    HipBertMLM.encode = spy
+    try:
+        _student_step(MINI, torch.bfloat16, nq=2, k=16, S=128, Sq=32, recipe=INFONCE, seed=13, grad_cache_chunk=8,
+                      what="c2 slice, gradient caching in chunks of 8 documents (~650 token rows)")
+    finally:
+        HipBertMLM.encode = real
+    assert len(seen) == 8, len(seen)  # 4 chunks x 2 passes
+    assert all(torch.equal(seen[i], seen[4 + i]) for i in range(4)), "pass 2 of a chunk must reproduce pass 1 bit for bit"
+
+
 @pytest.mark.parametrize("pc_ffn_bwd,wgrad_stream,tn_group", [(0, 1, 1), (1, 0, 1), (0, 0, 0), (1, 1, 0)])
 def test_c2_slice_kernel_option_combinations_with_dropout_on(pc_ffn_bwd, wgrad_stream, tn_group):
     """the NON-default kernel selections of HipBertMLM (sparse_hip.encoder.KERNEL_OPTIONS) against the oracle, hidden dropout on: the
