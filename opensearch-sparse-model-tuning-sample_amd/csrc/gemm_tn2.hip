@@ -54,10 +54,16 @@ struct Tn2Prob {
 struct Tn2Args {
   Tn2Prob p[T2_MAXP];
   int nprob, tiles, nsplit, rows_per_split, M;
-  int dbg;  // timing experiments only (SM_TN2_DEBUG; results are wrong): 1 the loaders move nothing, 2 no flush, 4 no MFMAs
+  int dbg;  // DIAGNOSTIC builds only (-DSM_TN_DIAG, SM_TN2_DEBUG: tools/tn2_bench.py, tools/tn3_stamps.py; results are wrong): 1 the loaders move
+            // nothing, 2 no flush, 4 no MFMAs, 8 / 32 priority experiments, 16 cycle stamps.  The product build compiles every one of them out.
 };
 
-__device__ uint32_t g_tn3_stamps[512 * 9 * 4];  // diagnostic build only (lanes other than 0 write the spare slot 8)
+#ifdef SM_TN_DIAG
+#define T2_DIAG(a) ((a).dbg)
+__device__ uint32_t g_tn3_stamps[512 * 9 * 4];  // (lanes other than 0 write the spare slot 8)
+#else
+#define T2_DIAG(a) 0
+#endif
 __device__ uint4 g_tn2_zero16;  // zero-initialised: source of LDS-DMA lanes whose token row is past the end
 
 template <int N> __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
 #undef T2_KEEP
       return;
     }
-    if (args.dbg & 8) __builtin_amdgcn_s_setprio(3);  // experiment: the loaders win the issue arbitration against their SIMD's consumer wave
+    if (T2_DIAG(args) & 8) __builtin_amdgcn_s_setprio(3);  // experiment: the loaders win the issue arbitration against their SIMD's consumer wave
     int islot = 0, irow = 0;  // ring slot and row offset of the next stage to issue
     auto issue = [&]() {
       char* const base = smem + islot * T2_STAGE + w * 2048;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
       for (int pn = 0; pn < 3; ++pn)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const char* src = lrow[p] + irow < mend && !(args.dbg & 1) ? cur[pn][p] : zsrc;
+          const char* src = lrow[p] + irow < mend && !(T2_DIAG(args) & 1) ? cur[pn][p] : zsrc;
           __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + pn * T2_PANEL + p * 1024), 16, 0, 0);
           cur[pn][p] += strd[pn];
         }
@@ -275,12 +281,15 @@ __global__ __launch_bounds__(512) void gemm_tn2_kernel(const Tn2Args args) {
   const int csmode = !do_cs ? 0 : wn == 0 ? 1 : 2;
 #define T2_ASM_INPUTS [b0] "v"(base[0]), [b1] "v"(base[1]), [b2] "v"(base[2]), [b3] "v"(base[3]), [b4] "v"(base[4]), [b5] "v"(base[5]), \
                       [nst] "s"(nst), [stage] "n"(T2_STAGE), [wrap] "n"(NST * T2_STAGE)
-  if (args.dbg & 4) asm volatile(T2_ASM_DBG_NOMFMA : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
-  else if (csmode == 0) asm volatile(T2_ASM_NOCS : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
+#ifdef SM_TN_DIAG
+  if (T2_DIAG(args) & 4) asm volatile(T2_ASM_DBG_NOMFMA : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
+  else
+#endif
+  if (csmode == 0) asm volatile(T2_ASM_NOCS : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
   else if (csmode == 1) asm volatile(T2_ASM_CS_H0 : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
   else asm volatile(T2_ASM_CS_H1 : T2_ASM_OUTPUTS : T2_ASM_INPUTS : T2_ASM_CLOBBERS);
 #undef T2_ASM_INPUTS
-  if (args.dbg & 2) return;
+  if (T2_DIAG(args) & 2) return;
   // ---- flush: one accumulator register = rows R and R + 4 of C, 32 consecutive columns each (two 128-byte segments) ----
   float* const Cb = P.C + (size_t)(n0 + wm * 96 + (lane >> 5) * 4) * P.ldc + k0 + wn * 96 + (lane & 31);
 #pragma unroll
@@ -367,7 +376,11 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
   f32x16 acc[3][3];
   float cs[3];
   // diagnostic build (SM_TN2_DEBUG & 16): per wave {cycles of the main loop, cycles in its vmcnt waits, cycles in its barriers}
+#ifdef SM_TN_DIAG
   uint32_t* const dbgp = g_tn3_stamps + ((size_t)blockIdx.x * 8 + (lane == 0 ? w : 8)) * 4;
+#else
+  uint32_t* const dbgp = nullptr;
+#endif
   // bias gradient: the kt == 0 tile of each A row block; waves (wm, 0) sum the first half of every stage, (wm, 1) the second
   const bool do_cs = P.colsum != nullptr && kt == 0;
   const int csmode = !do_cs ? 0 : wn == 0 ? 1 : 2;
@@ -376,11 +389,14 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
                       [row] "v"(vrow), [row4] "v"(vrow4), [nst] "s"(nst), [mend] "s"(mend), [sa] "s"(astage), [sb] "s"(bstage),       \
                       [dst] "s"(dst0), [dbgp] "v"(dbgp)
   // waves 0-3 issue their LDS-DMA in the first half of a stage, waves 4-7 (their SIMD partners) in the second
-  if ((args.dbg & 32) && w >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the second-dispatched half (guide: +0-1 %)
-  if (args.dbg & 16) {
+  if ((T2_DIAG(args) & 32) && w >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the second-dispatched half (guide: +0-1 %)
+#ifdef SM_TN_DIAG
+  if (T2_DIAG(args) & 16) {
     if (w < 4) asm volatile(T3_ASM_STAMPS_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
     else asm volatile(T3_ASM_STAMPS_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
-  } else if (w < 4) {
+  } else
+#endif
+  if (w < 4) {
     if (csmode == 0) asm volatile(T3_ASM_NOCS_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
     else if (csmode == 1) asm volatile(T3_ASM_CS_H0_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
     else asm volatile(T3_ASM_CS_H1_D0 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
     else asm volatile(T3_ASM_CS_H1_D1 : T3_ASM_OUTPUTS : T3_ASM_INPUTS : T3_ASM_CLOBBERS);
   }
 #undef T3_ASM_INPUTS
-  if (args.dbg & 2) return;
+  if (T2_DIAG(args) & 2) return;
   // ---- flush: one accumulator register = rows R and R + 4 of C, 32 consecutive columns each (two 128-byte segments) ----
   float* const Cb = P.C + (size_t)(n0 + wm * 96 + (lane >> 5) * 4) * P.ldc + k0 + wn * 96 + (lane & 31);
 #pragma unroll
@@ -407,9 +423,11 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const Tn2Args args) {
 
 }  // namespace
 
-extern "C" int sm_tn3_debug_stamps(unsigned int* host, int n) {  // tools/tn3_stamps.py (not part of include/sparse_hip.h)
+#ifdef SM_TN_DIAG
+extern "C" int sm_tn3_debug_stamps(unsigned int* host, int n) {  // tools/tn3_stamps.py (diagnostic library only)
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn3_stamps), (size_t)n * 4);
 }
+#endif
 
 // Declared in include/sparse_hip.h.  Returns 0 when the grouped kernel ran, 1 when a problem is not eligible (the caller runs
 // sm_gemm_tn_acc / sm_gemm_tn_acc_bcm per problem instead), < 0 on error.
@@ -460,8 +478,12 @@ extern "C" int sm_gemm_tn_group(int nprob, const sm_tn_problem* probs, int M, vo
   a.nsplit = nsplit;
   a.rows_per_split = rps;
   a.M = M;
+#ifdef SM_TN_DIAG
   static const int dbg = [] { const char* e = getenv("SM_TN2_DEBUG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   const int grid = (tiles * nsplit + 7) / 8 * 8;
   static const int loader = [] { const char* e = getenv("SM_TN2_LOADER"); return e ? atoi(e) : 0; }();  // A/B switch (tools/tn2_bench.py)
   auto launch = [&](auto kern, int nst) -> int {

@@ -2,7 +2,25 @@
 four products at the bench's token count: time per layer-set, TFLOP/s, and the relative error of each against the fp32 product."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "opensearch-sparse-model-tuning-sample_amd"))
-from sparse_hip import ops
+from sparse_hip import lib as _L, ops
+
+
+def _diag_lib():
+    """the DIAGNOSTIC build of the grouped weight-gradient kernels (-DSM_TN_DIAG: timing-only switches and cycle stamps; the product
+    library compiles them out), built next to this script on first use"""
+    import subprocess
+    root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+    csrc = os.path.join(root, "opensearch-sparse-model-tuning-sample_amd", "csrc")
+    so = os.path.join(root, "tools", "_libtn_diag.so")
+    if not os.path.exists(so):
+        srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")] + [os.path.join(csrc, "api.cpp")]
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DSM_TN_DIAG", "-shared",
+                               "-o", so, *srcs])
+    return so
+
+
+if os.environ.get("SM_TN2_DEBUG", "0") != "0":  # timing-only switches live in the diagnostic library
+    _L._LIB_PATH = _diag_lib()
 
 
 def timeit(f, n=20):

@@ -6,6 +6,23 @@ import torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "opensearch-sparse-model-tuning-sample_amd"))
 from sparse_hip import ops, lib
 
+
+def _diag_lib():
+    """the DIAGNOSTIC build of the grouped weight-gradient kernels (-DSM_TN_DIAG: timing-only switches and cycle stamps; the product
+    library compiles them out), built next to this script on first use"""
+    import subprocess
+    root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+    csrc = os.path.join(root, "opensearch-sparse-model-tuning-sample_amd", "csrc")
+    so = os.path.join(root, "tools", "_libtn_diag.so")
+    if not os.path.exists(so):
+        srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")] + [os.path.join(csrc, "api.cpp")]
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DSM_TN_DIAG", "-shared",
+                               "-o", so, *srcs])
+    return so
+
+
+lib._LIB_PATH = _diag_lib()
+
 T = int(os.environ.get("T", "65536"))
 shapes = ((384, 1536), (1536, 384), (384, 384), (1152, 384))
 probs = []
