@@ -138,8 +138,8 @@ int sm_gemm_tn_acc(int dtype, const void* A, int lda, const void* B, int ldb, fl
 int sm_gemm_tn_acc_bcm(const void* A, int a_bcm, const void* B, int b_bcm, float* C, int ldc, int M, int N, int Kc, float* colsum,
                        void* stream);
 
-/* GROUPED weight gradients (ABI 5): the products of up to 6 nn.Linear layers that share the token dimension M -- the four of an
- * encoder layer: QKV, attention output, FFN up, FFN down (hf:175-177, :290, :335, :348 backward) -- in ONE launch of about one
+/* GROUPED weight gradients (ABI 5): the products of up to 8 nn.Linear layers that share the token dimension M -- the four of an
+ * encoder layer (or of two layers): QKV, attention output, FFN up, FFN down (hf:175-177, :290, :335, :348 backward) -- in ONE launch of about one
  * workgroup per CU (csrc/gemm_tn2.hip: [192 x 192] tiles, bf16, every N and Kc a multiple of 192).  Per problem the same contract
  * as sm_gemm_tn_acc / sm_gemm_tn_acc_bcm: C[N,Kc] += A[M,N]^T . B[M,Kc] (fp32 atomics), colsum[N] += column sums of A (may be
  * NULL); a_bcm / b_bcm = 1: that operand is block-column-major and dense (its ld is ignored).  Returns 0 when the grouped kernel

@@ -39,7 +39,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int T2_TILE = 192, T2_BKM = 32, T2_PANEL = T2_BKM * 256, T2_STAGE = 3 * T2_PANEL, T2_MAXP = 6;
+constexpr int T2_TILE = 192, T2_BKM = 32, T2_PANEL = T2_BKM * 256, T2_STAGE = 3 * T2_PANEL, T2_MAXP = 8;
 
 struct Tn2Prob {
   const bf16* A;

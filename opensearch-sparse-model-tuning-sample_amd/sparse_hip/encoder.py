@@ -192,7 +192,8 @@ KERNEL_OPTIONS = {
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
     "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
-    "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
+    "tn_group": ("SM_TN_GROUP", True, bool),
+    "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
     "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
     "pc_infer_min_rows": ("SM_PC_INFER_MIN_ROWS", 6144, int),  # no-grad forwards below this many rows: unfused feed-forward launches
@@ -308,6 +309,7 @@ class HipBertMLM(torch.nn.Module):
         self.graph_tokens = opt("encode_graph_tokens")
         self.wgrad_stream = opt("wgrad_stream")
         self.tn_group = opt("tn_group")
+        self.tn_pair = opt("tn_pair")
         # Density-adaptive head backward: the share of live sparse activations of the PREVIOUS encode (counted on a sample of the
         # columns, read back without stalling: by the next step the copy has long landed) picks between the matrix form of dt = G . E
         # (head_dt192_kernel: 2 T V H flops whatever the density) and the scatter over the live entries (head_dt_scatter_kernel).
@@ -448,7 +450,7 @@ class HipBertMLM(torch.nn.Module):
     def kernel_options(self) -> dict:
         """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
         return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
-                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "tn_pair": self.tn_pair, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
                 "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
 
     def sync_weights(self) -> None:
@@ -827,7 +829,7 @@ class _WgradStream:
         best = {n: (0.0, [])}
         for i in range(n - 1, -1, -1):
             cand = None
-            for j in range(i, min(n, i + 6)):
+            for j in range(i, min(n, i + 8)):
                 grp = shapes[i:j + 1]
                 units = sum((N // 192) * (K // 192) for N, K in grp)
                 tiles = units // 2 if all(N % 384 == 0 for N, _ in grp) else units
@@ -1096,7 +1098,13 @@ class _EncodeFn(torch.autograd.Function):
                     dz0 = fused[0]
             if pending is None and dz0 is None:
                 dx = model._lin(dqkv, f"qkvT{l}", grad=True, residual=dz1)
-            wg.flush()  # this layer's weight gradients: one fork
+            # this layer's weight gradients: one fork of the side stream (a marker on the main queue: ~12-20 us between two kernels) and
+            # one grouped launch.  Without a gradient-reduction hook, inner layers go in PAIRS (8 products per launch: half the forks,
+            # half the atomic flushes); the first layer of the backward and the last one keep their own (the side queue starts
+            # early and the tail behind the backward chain stays one layer long)
+            nl = cfg.num_hidden_layers
+            if model._layer_hook is not None or not model.tn_pair or l == nl - 1 or l == 0 or (nl - 1 - l) % 2 == 0:
+                wg.flush()
             if model._layer_hook is not None:
                 model._layer_hook(l, wg.mark())
         z0, m0, r0 = ctx.saved["emb"]

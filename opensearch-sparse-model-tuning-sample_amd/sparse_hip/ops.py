@@ -125,10 +125,10 @@ def gemm_tn_acc(A, B, out: Tensor, colsum: Optional[Tensor] = None) -> Tensor:
 def gemm_tn_group(problems) -> bool:
     """The weight gradients of several linears that share the token dimension in ONE launch (csrc/gemm_tn2.hip): problems = a list
     of (A, B, out, colsum) with gemm_tn_acc's meaning each.  Returns False without launching anything when a problem is not
-    eligible (not bf16, a dimension that is not a multiple of 192, more than 6 problems): the caller then runs gemm_tn_acc per
+    eligible (not bf16, a dimension that is not a multiple of 192, more than 8 problems): the caller then runs gemm_tn_acc per
     problem."""
     n = len(problems)
-    if n == 0 or n > 6:
+    if n == 0 or n > 8:
         return False
     arr = (L.SmTnProblem * n)()
     M = None

@@ -279,20 +279,21 @@ def _to_bcm(x: torch.Tensor) -> torch.Tensor:
     return pad.reshape(rp // 32, 32, cols // 8, 8).permute(0, 2, 1, 3).contiguous()
 
 
-@pytest.mark.parametrize("M", [32, 100, 1000, 4112, 70000])
-def test_gemm_tn_group_matches_fp32_products(ops, M):
+@pytest.mark.parametrize("M,layers", [(32, 1), (100, 1), (1000, 1), (4112, 1), (70000, 1), (300, 2), (43904, 2)])
+def test_gemm_tn_group_matches_fp32_products(ops, M, layers):
     """the grouped weight-gradient kernel (csrc/gemm_tn2.hip, hf:175-177 / :290 / :335 / :348 backward in ONE launch): every product
     against the fp32 product of the same bf16 operands, accumulating into a non-zero C; row counts that are not multiples of the
     32-row stage, one stage only, and more rows than one split; operands with a leading dimension, block-column-major operands,
-    problems with and without a bias gradient"""
+    problems with and without a bias gradient; the products of ONE layer, and of two (the inner layers of the backward go in pairs)"""
     dt = torch.bfloat16
-    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
+    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536)] * layers
     probs, want = [], []
-    for i, (N, Kc) in enumerate(shapes):
-        A, B = q(rnd(M, N, seed=10 + i, scale=0.5), dt), q(rnd(M, Kc, seed=20 + i, scale=0.5), dt)
-        init = rnd(N, Kc, seed=30 + i)
+    for n, (N, Kc) in enumerate(shapes):
+        i = n % 4
+        A, B = q(rnd(M, N, seed=10 + n, scale=0.5), dt), q(rnd(M, Kc, seed=20 + n, scale=0.5), dt)
+        init = rnd(N, Kc, seed=30 + n)
         out = dev(init.clone())
-        cs = torch.full((N,), 0.5, device="cuda") if i != 1 else None
+        cs = torch.full((N,), 0.5, device="cuda") if n != 1 else None
         a_dev, b_dev = dev(A, dt), dev(B, dt)
         if i == 2:  # FFN up: dF1 block-column-major (A), x1 row-major
             a_dev = ops.Bcm(dev(_to_bcm(A.to(dt))), M, N)
@@ -329,12 +330,12 @@ def test_gemm_tn_group_equals_the_per_matrix_kernel_and_declines_other_shapes(op
     assert ops.gemm_tn_group([(A5, B5, o5, c5)])
     close(o5, A5.float().t() @ B5.float(), 1e-5, "[576 x 192] through the [192 x 192] kernel")
     close(c5, A5.float().sum(0), 1e-5, "its column sums")
-    # not a multiple of 192 / fp32 operands / seven problems: declined, nothing launched
+    # not a multiple of 192 / fp32 operands / nine problems: declined, nothing launched
     o3 = torch.zeros(128, 384, device="cuda")
     assert not ops.gemm_tn_group([(A[:, :128].contiguous(), B[:, :384].contiguous(), o3, None)])
     assert float(o3.abs().max()) == 0.0
     assert not ops.gemm_tn_group([(A.float(), B.float(), o1, None)])
-    assert not ops.gemm_tn_group([(A, B, o1, None)] * 7)
+    assert not ops.gemm_tn_group([(A, B, o1, None)] * 9)
 
 
 # ------------------------------------------------------------------ LayerNorm
