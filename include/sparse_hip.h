@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 5
+#define SM_ABI_VERSION 6
 #define SM_F32 0
 #define SM_BF16 1
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
@@ -269,7 +269,14 @@ int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float* rep, const
 int sm_sparse_head_bwd_dt_ln(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E,
                              void* dft, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x,
                              const float* gamma, const float* mean, const float* rstd, const void* gelu_of,
-                             float* dgamma, float* dbeta, int x_f32 /* 1: x (the LayerNorm input) is fp32 */, void* stream);
+                             float* dgamma, float* dbeta, int x_f32 /* 1: x (the LayerNorm input) is fp32 */,
+                             float* ws, long ws_bytes, void* stream);
+/* ws (ABI 6; may be NULL): sm_sparse_head_bwd_dt_ws_bytes() bytes, 16-byte aligned, ZERO on entry and left zero on exit, used by
+ * one launch at a time.  With it, a last round of row tiles that would fill less than 3/4 of the CUs (the dense bench batch: 342
+ * tiles of 192 rows on 256 CUs) is split along the vocabulary instead (a second launch), its partial tiles summed in ws (fp32
+ * atomics: the result then depends on arrival order in the last bit; without ws, or SM_DT_SPLIT=0, the kernel is
+ * bit-reproducible) and finished by a third, small launch that zeroes ws again. */
+long sm_sparse_head_bwd_dt_ws_bytes(void);
 
 /* The dt half as a SCATTER (ABI 5; bf16 E): dt32[row(b) + argmax[b, v], :] += grad_rep[b, v] f'(rep[b, v]) E[v, :] for the live (b, v)
  * only, fp32 atomics into a ZEROED dt32[T, H].  Work proportional to the number of live activations: the form for a trained

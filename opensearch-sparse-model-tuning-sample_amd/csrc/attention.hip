@@ -273,8 +273,11 @@ struct Lay {  // LDS row stride (bytes): 128-byte bf16 rows are XOR-swizzled (im
 // being the neighbouring head -- so one head per workgroup fetches every line of q/k/v twice (measured: 2x
 // the algorithmic HBM traffic forward, 3.5x backward); two adjacent heads per workgroup use whole lines.
 // DROP: dropout on / off is a compile-time switch -- as a run-time test the compiler kept one branch PER ELEMENT in the loops
-template <typename T, int DH, int NKT, int HP, bool DROP, bool TAIL>  // TAIL: dense layout, trailing masked key tiles are skipped
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+// NW = waves per workgroup: the K / V images of a long document (S = 512, head dim 64: 128 KiB) leave room for ONE workgroup per CU,
+// and with 4 waves that is one wave per SIMD walking QK^T -> softmax -> PV with nothing to overlap its latencies (configs[4]: 110
+// TFLOP/s); 8 waves share the same images
+template <typename T, int DH, int NKT, int HP, bool DROP, bool TAIL, int NW>  // TAIL: dense layout, trailing masked key tiles are skipped
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   char* sV0 = sK0 + S * L::RS;              // V, row-major (consumed through transposing reads)
   float* sBias = reinterpret_cast<float*>(sV0 + S * L::RS);  // per key: 0, or -inf for masked / padding keys
   const T* base0 = qkv + (size_t)row0 * ld + h0 * DH;
-  stage2_batched<T, HP * DH, L::SWZ, NKT * 16 * (HP * DH * (int)sizeof(T) / 16) / 256>(base0 + H, ld, base0 + 2 * H, ld, Lr, nkt * 16, sK0, sV0, L::RS);
-  __shared__ int s_lastw[4];  // per wave: the last attended key it saw (-1: none)
+  stage2_batched<T, HP * DH, L::SWZ, NKT * 16 * (HP * DH * (int)sizeof(T) / 16) / (64 * NW)>(base0 + H, ld, base0 + 2 * H, ld, Lr, nkt * 16, sK0, sV0, L::RS);
+  __shared__ int s_lastw[NW];  // per wave: the last attended key it saw (-1: none)
   constexpr bool skip_tail = TAIL;  // (the ragged layout has no masked tail: nkt already follows the length; its instantiation carries none of this)
   int mylast = -1;
   for (int i0 = 0; i0 < nkt * 16; i0 += blockDim.x) {
@@ -308,7 +311,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   }
   if (skip_tail && (threadIdx.x & 63) == 0) s_lastw[threadIdx.x >> 6] = mylast;
   __syncthreads();
-  const int s_last = skip_tail ? max(max(s_lastw[0], s_lastw[1]), max(s_lastw[2], s_lastw[3])) : -1;
+  int s_last = -1;
+  if (skip_tail) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s_last = max(s_last, s_lastw[i]);
+  }
   // key tiles behind the last attended key hold only masked keys (the padded tail of a dense [B, S] batch): their probabilities are
   // exactly zero, so they are not computed at all -- same bits, S x len instead of S x S work per head
   if (skip_tail) nkt = min(nkt, max(2, ((s_last >> 4) + 2) & ~1));
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   // scores in the log2 domain: exp(x - m) = exp2(x * log2e - m * log2e), one v_exp_f32 and no extra multiply
   const float scale2 = rsqrtf((float)DH) * 1.4426950408889634f;
   const Drop8 d8(drop);
-  for (int u = w; u < nqb * HP; u += 4) {  // units = (query block, head)
+  for (int u = w; u < nqb * HP; u += NW) {  // units = (query block, head)
     const int qb = u / HP, hh = u % HP, h = h0 + hh;
     const T* base = base0 + hh * DH;
     const int cof = hh * DH * (int)sizeof(T);  // this head's byte column inside the images
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------
-template <typename T, int DH, int HP, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+template <typename T, int DH, int HP, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   T* dq_out0 = dqkv + (size_t)row0 * ld + h0 * DH;
 
   // ---- phase A: per query block, S^T orientation (rows = keys, col = query) -> dQ ----
-  for (int u = w; u < nblk * HP; u += 4) {  // units = (query block, head)
+  for (int u = w; u < nblk * HP; u += NW) {  // units = (query block, head)
     const int qb = u / HP, hh = u % HP, h = h0 + hh;
     const int cof = hh * DH * (int)sizeof(T);
     const T* base = base0 + hh * DH;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   __syncthreads();
 
   // ---- phase B: per key block, S orientation (rows = queries, col = key) -> dK, dV ----
-  for (int u = w; u < nblk * HP; u += 4) {  // units = (key block, head)
+  for (int u = w; u < nblk * HP; u += NW) {  // units = (key block, head)
     const int kb = u / HP, hh = u % HP, h = h0 + hh;
     const int cof = hh * DH * (int)sizeof(T);
     const T* base = base0 + hh * DH;
@@ -784,8 +791,8 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
     const size_t lds = fwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
     const bool tail = ATTN_SKIP && doc_off == nullptr;
-    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true> : attn_fwd_kernel<T, DH, NKT, 2, true, false>)
-                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true> : attn_fwd_kernel<T, DH, NKT, 2, false, false>);
+    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true, 4> : attn_fwd_kernel<T, DH, NKT, 2, true, false, 4>)
+                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true, 4> : attn_fwd_kernel<T, DH, NKT, 2, false, false, 4>);
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
     return SM_OK;
@@ -793,10 +800,12 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
   const size_t lds = fwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
   const bool tail = ATTN_SKIP && doc_off == nullptr;
-  auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 1, true, true> : attn_fwd_kernel<T, DH, NKT, 1, true, false>)
-                         : (tail ? attn_fwd_kernel<T, DH, NKT, 1, false, true> : attn_fwd_kernel<T, DH, NKT, 1, false, false>);
+  // long documents in bf16: 8 waves per workgroup (one workgroup's images fill the CU's LDS)
+  constexpr int NW = (sizeof(T) == 2 && NKT >= 16) ? 8 : 4;
+  auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 1, true, true, NW> : attn_fwd_kernel<T, DH, NKT, 1, true, false, NW>)
+                         : (tail ? attn_fwd_kernel<T, DH, NKT, 1, false, true, NW> : attn_fwd_kernel<T, DH, NKT, 1, false, false, NW>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(64 * NW), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;
 }
 template <int DH, int HP>
@@ -821,14 +830,20 @@ int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* 
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = bwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-    auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 2, true> : attn_bwd_kernel<T, DH, 2, false>;
+    auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 2, true, 4> : attn_bwd_kernel<T, DH, 2, false, 4>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
     return SM_OK;
   }
   const size_t lds = bwd_lds<T, DH, 1>(S);
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
-  auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 1, true> : attn_bwd_kernel<T, DH, 1, false>;
+  if (sizeof(T) == 2 && S > 128) {  // long documents: 12 waves share the images (152 registers per lane: three waves per SIMD)
+    auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 1, true, 12> : attn_bwd_kernel<T, DH, 1, false, 12>;
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B * A), dim3(768), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
+    return SM_OK;
+  }
+  auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 1, true, 4> : attn_bwd_kernel<T, DH, 1, false, 4>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
   return SM_OK;

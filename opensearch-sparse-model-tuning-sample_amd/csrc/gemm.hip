@@ -1068,6 +1068,19 @@ __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+// ... with an immediate byte offset (one address register serves several reads)
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16_at(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128_at(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
 __device__ __forceinline__ f32x4 lds_r128f(uint32_t addr) {
   f32x4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -1983,13 +1996,27 @@ constexpr int DT_CSLOT = 3 * 512 * 4;  // per step: grad_rep, rep, argmax-pair w
 #endif
 constexpr int DT_FLAGS = 16;  // two step tags: "the G image of step k holds a non-zero" (k + 1 in word k & 1)
 constexpr int DT_LDS = DT_NST * DT_ESTAGE + 2 * DT_G + DT_NST * DT_CSLOT + DT_FLAGS;
+// The LAST, partly filled round of tiles (dense bench batch: 342 tiles on 256 CUs -- the second round keeps a third of the chip
+// busy for as long as the first) is split along the vocabulary instead: its tiles x steps are dealt to the workgroups behind
+// the full rounds in equal contiguous runs of `upw` steps; a run adds its partial [192 x 384] tile to a zeroed fp32 image
+// (register-major: 256 contiguous bytes per wave instruction, the full-rate atomic shape); a third, small launch takes the sums
+// back, zeroes the images again for the next call, and runs the epilogue.  (One launch with a last-arriver epilogue was tried
+// first: with the tile epilogue inlined beside an outer loop over runs the allocator keeps 16 loop-invariant addresses of the
+// main loop in scratch, and their reloads -- vmcnt(0) -- drain the LDS-DMA ring every step: 5x slower.)
+constexpr int DT_CUS = 256, DT_TILE_F32 = DT_R * DT_C;
+struct DtSplit {
+  float* sum;     // [tail_tiles][DT_TILE_F32], zero on entry, zero on exit (null: no split)
+  int n_full;     // tiles 0 .. n_full-1: one workgroup each, the whole vocabulary
+  int tail_tiles; // tiles n_full .. : split
+  int upw;        // steps per workgroup of the tail
+};
 
-template <bool LNF>
+template <bool LNF, bool SPLIT>
 __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict__ grad_rep, const float* __restrict__ rep,
                                                          const uint16_t* __restrict__ argmax, const bf16* __restrict__ E,
                                                          bf16* __restrict__ dt, int Bdocs, int S, int H, int V, int use_l0,
                                                          const int32_t* __restrict__ doc_off, const int32_t* __restrict__ blk_doc,
-                                                         int rag_rows, LnBwdArgs ln) {
+                                                         int rag_rows, LnBwdArgs ln, DtSplit sp) {
   // LNF (H == 384: the tile holds whole rows): dt does not go to HBM, `dt` receives LayerNorm'(dt) . gelu'(ln.post_gelu_of),
   // the gradient w.r.t. the head transform's dense output -- the LayerNorm-backward and GELU-backward launches disappear
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2000,10 +2027,19 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   char* const sF = sC + DT_NST * DT_CSLOT;
   const bool ragged = doc_off != nullptr;
   const int Ttot = ragged ? rag_rows : Bdocs * S;
-  const int m0 = blockIdx.y * DT_R, n0 = blockIdx.x * DT_C;
+  const int n0 = blockIdx.x * DT_C;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3, g = lane >> 4, li = lane & 15;
   const int nk = (V + 31) / 32;
+  // this workgroup's run of steps: a whole tile, or `upw` steps of the split tail (at most a few tiles' worth)
+  // (SPLIT is a template parameter: with the outer loop in it the register allocator keeps 16 loop-invariant addresses in scratch;
+  //  the split tail is its own launch behind the whole tiles')
+  const int u0 = SPLIT ? (int)blockIdx.y * sp.upw : 0;
+  const int u1 = SPLIT ? min(u0 + sp.upw, sp.tail_tiles * nk) : nk;
+  for (int tl = SPLIT ? u0 / nk : 0; tl <= (SPLIT ? (u1 - 1) / nk : 0); ++tl) {
+  const int kb = SPLIT ? max(u0 - tl * nk, 0) : 0, ke = SPLIT ? min(u1 - tl * nk, nk) : nk;
+  const int m0 = (SPLIT ? sp.n_full + tl : (int)blockIdx.y) * DT_R;
+  __syncthreads();  // (a second run of this workgroup: the epilogue of the first one is done with the LDS)
 
   // documents with rows in this tile (at most 12: documents are 16-row aligned and at least 16 rows long)
   int b0, ndoc;
@@ -2021,9 +2057,7 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   const bool owner = tid < 32 * DT_MAXDOC && dd < ndoc && b0 + dd < Bdocs;
   const int dsafe = min(b0 + dd, Bdocs - 1);
   const int rbase = (ragged ? doc_off[dsafe] : dsafe * S) - m0;  // tile row of the document's position 0
-  const float* gp = grad_rep + (size_t)dsafe * V;
-  const float* rp = rep + (size_t)dsafe * V;
-  const uint16_t* ap = argmax + (size_t)dsafe * V;
+  const uint32_t doff = (uint32_t)dsafe * (uint32_t)V;  // (32-bit element offsets on the scalar base pointers: one register, not three pointers)
   const uint32_t gbase = (uint32_t)(uintptr_t)(lds_char*)sG, ebase = (uint32_t)(uintptr_t)(lds_char*)sE;
 
   // zero both G images before any DMA is in flight (plain stores: the compiler may order them as it likes here)
@@ -2033,7 +2067,7 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   const uint32_t fbase = (uint32_t)(uintptr_t)(lds_char*)sF;
 
   // ---- E loader: 24 one-KiB pieces per stage, 3 per wave ----
-  const bf16* esrc[3];
+  uint32_t esrc[3];  // byte offsets into E (V * H * 2 < 2^32): the scalar base + one register per piece
   int erow[3];
   uint32_t edst[3];
 #pragma unroll
@@ -2042,7 +2076,7 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     const int row = pp * 4 + (lane >> 4), cphys = lane & 15;
     const int clog = ((((cphys >> 1) ^ tg_f(row)) << 1) | (cphys & 1)) * 8;
     erow[p] = row;
-    esrc[p] = E + n0 + panel * 128 + clog;
+    esrc[p] = (uint32_t)(n0 + panel * 128 + clog) * 2u;
     edst[p] = panel * TG_STAGE + pp * 1024;
   }
   auto issue_e = [&](int k) {
@@ -2050,19 +2084,19 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     char* d = sE + (k % DT_NST) * DT_ESTAGE;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      const int v = min(kc * 32 + erow[p], V - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(esrc[p] + (size_t)v * H), (lds_void_t*)(d + edst[p]), 16, 0, 0);
+      const uint32_t v = (uint32_t)min(kc * 32 + erow[p], V - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)E + (size_t)(esrc[p] + v * (uint32_t)(H * 2))), (lds_void_t*)(d + edst[p]), 16, 0, 0);
     }
   };
   // the (grad_rep, rep, argmax) words of a step travel by LDS-DMA too (4 bytes per lane), two steps ahead:
   // register loads that live across the loop back-edge make the compiler wait for vmcnt(0) at their use
   const uint32_t cbase = (uint32_t)(uintptr_t)(lds_char*)sC;
   auto issue_cols = [&](int k) {
-    const int v = min(k * 32 + kk, V - 1);
+    const uint32_t e = doff + (uint32_t)min(k * 32 + kk, V - 1);
     char* d = sC + (k % DT_NST) * DT_CSLOT + w * 256;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(gp + v), (lds_void_t*)(d), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(rp + v), (lds_void_t*)(d + 2048), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(ap + (v & ~1)), (lds_void_t*)(d + 4096), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)grad_rep + (size_t)(e * 4u)), (lds_void_t*)(d), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)rep + (size_t)(e * 4u)), (lds_void_t*)(d + 2048), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)argmax + (size_t)((e & ~1u) * 2u)), (lds_void_t*)(d + 4096), 4, 0, 0);
   };
   int prev0 = -1, prev1 = -1;
   auto write_g = [&](int k) {  // landed columns of step k -> G image k & 1
@@ -2096,17 +2130,19 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
   };
 
   // ---- fragment addresses ----
-  uint32_t gaddr[6], eaddr[6][2];
+  // 7 address registers for the 18 reads of a step: the G rows of a wave's six 16-row tiles are 16 rows = 1024 bytes apart with the
+  // same swizzle term ((row >> 2) & 3 repeats every 16 rows), and the second half of an E fragment (rows r0 + 4) has the
+  // swizzle of the first (tg_f looks at row bits 0, 1 and 3; r0 = 8 g + q, q < 4): + 4 * 256 bytes
+  uint32_t gaddr0, eaddr[6];
   {
     const int q = li >> 2, pq = li & 3;
-    const int r0 = 8 * g + q, r1 = r0 + 4;
+    const int r0 = 8 * g + q;
+    const int row = wm * 96 + li;
+    gaddr0 = gbase + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int row = wm * 96 + i * 16 + li;
-      gaddr[i] = gbase + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4);
       const int c = wn * 96 + i * 16, panel = c >> 7, cb = (c & 127) * 2 + 8 * pq;
-      eaddr[i][0] = ebase + panel * TG_STAGE + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
-      eaddr[i][1] = ebase + panel * TG_STAGE + r1 * 256 + ((((cb >> 5) ^ tg_f(r1)) << 5) | (cb & 31));
+      eaddr[i] = ebase + panel * TG_STAGE + r0 * 256 + ((((cb >> 5) ^ tg_f(r0)) << 5) | (cb & 31));
     }
   }
   f32x4 acc[6][6];
@@ -2116,14 +2152,14 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue (order fixes the vmcnt arithmetic of the loop) ----
-  issue_e(0);
-  issue_e(1);
-  issue_cols(0);
+  issue_e(kb);
+  issue_e(kb + 1);
+  issue_cols(kb);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  write_g(0);
-  issue_cols(1);
-  issue_e(2);
-  for (int k = 0; k < nk; ++k) {
+  write_g(kb);
+  issue_cols(kb + 1);
+  issue_e(kb + 2);
+  for (int k = kb; k < ke; ++k) {
     __builtin_amdgcn_s_barrier();  // G(k) written by every owner, E stage k landed for every wave (see 3.)
     asm volatile("" ::: "memory");
     // 1. next loads: columns of step k+2, E stage k+3 (its slot held stage k-1, drained before the barrier)
@@ -2135,12 +2171,19 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     uint32_t tag = lds_r32(fbase + (k & 1) * 4);
     bf16x8 fa[6];
     TgFrag fb[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) fa[i] = lds_b128(gaddr[i] + go);
+    {
+      const uint32_t ga = gaddr0 + go;
+      fa[0] = lds_b128_at<0>(ga);
+      fa[1] = lds_b128_at<1024>(ga);
+      fa[2] = lds_b128_at<2048>(ga);
+      fa[3] = lds_b128_at<3072>(ga);
+      fa[4] = lds_b128_at<4096>(ga);
+      fa[5] = lds_b128_at<5120>(ga);
+    }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      fb[j].s.lo = lds_tr16(eaddr[j][0] + so);
-      fb[j].s.hi = lds_tr16(eaddr[j][1] + so);
+      fb[j].s.lo = lds_tr16_at<0>(eaddr[j] + so);
+      fb[j].s.hi = lds_tr16_at<1024>(eaddr[j] + so);
     }
     // first half of the MFMAs as soon as fa and fb[0..2] are here; the reads of fb[3..5] land underneath them
     asm volatile("s_waitcnt lgkmcnt(6)"
@@ -2169,34 +2212,88 @@ __global__ __launch_bounds__(512) void head_dt192_kernel(const float* __restrict
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     write_g(k + 1);
   }
-  if constexpr (LNF) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the redundant tail loads must not land in the image
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the redundant tail loads must not land in the epilogue's image
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if constexpr (SPLIT) {
+    // a partial sum: into the tile's fp32 image (head_dt_tail_kernel below takes the sums back and runs the epilogue)
+    float* const img = sp.sum + (size_t)tl * DT_TILE_F32 + tid;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(img + ((i * 6 + j) * 4 + r) * 512, acc[i][j][r]);
+  } else if constexpr (LNF) {
     ln_bwd_tile_epilogue<2>(acc, (uint32_t)(uintptr_t)(lds_char*)smem, m0, Ttot, H, H, dt, nullptr, ln, tid, lane, w, wm, wn, g, li);
-    return;
-  }
-  // ---- epilogue: lane = (row li, columns 4g..4g+3) of each 16 x 16 tile ----
+  } else {
+    // ---- epilogue: lane = (row li, columns 4g..4g+3) of each 16 x 16 tile ----
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int row = m0 + wm * 96 + i * 16 + li;
-    if (row < Ttot) {
+    for (int i = 0; i < 6; ++i) {
+      const int row = m0 + wm * 96 + i * 16 + li;
+      if (row < Ttot) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        bf16x4 o;
+        for (int j = 0; j < 6; ++j) {
+          bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
-        *reinterpret_cast<bf16x4*>(dt + (size_t)row * H + n0 + wn * 96 + j * 16 + 4 * g) = o;
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[i][j][r];
+          *reinterpret_cast<bf16x4*>(dt + (size_t)row * H + n0 + wn * 96 + j * 16 + 4 * g) = o;
+        }
       }
     }
   }
+  }  // runs of this workgroup
+}
+
+// The epilogue of the split tail: one workgroup per tail tile takes the summed fp32 image back into the accumulator layout of
+// head_dt192_kernel, leaves the image zero for the next launch, and runs the LayerNorm' / GELU' tile epilogue.
+__global__ __launch_bounds__(512) void head_dt_tail_kernel(bf16* __restrict__ dft, int Ttot, int H, LnBwdArgs ln, DtSplit sp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3, g = lane >> 4, li = lane & 15;
+  float* const img = sp.sum + (size_t)blockIdx.x * DT_TILE_F32 + tid;
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[i][j][r] = img[((i * 6 + j) * 4 + r) * 512];
+        img[((i * 6 + j) * 4 + r) * 512] = 0.f;
+      }
+  ln_bwd_tile_epilogue<2>(acc, (uint32_t)(uintptr_t)(lds_char*)smem, (sp.n_full + (int)blockIdx.x) * DT_R, Ttot, H, H, dft, nullptr, ln, tid, lane, w, wm,
+                          wn, g, li);
 }
 
 // dt = G . E part of sm_sparse_head_bwd (the dE / dbias part lives in sparse_head.hip)
 // the fused form of the dt half: LayerNorm' and GELU' of the head transform in the epilogue (1 = shape not eligible)
+// workspace of the split tail: the fp32 images of up to 3/4 of a round of tiles + their counters
+extern "C" long sm_sparse_head_bwd_dt_ws_bytes(void) { return (long)(DT_CUS * 3 / 4) * DT_TILE_F32 * 4; }
+
+// which tiles of `tiles` go whole and which are split: the last round when it fills less than 3/4 of the chip
+static DtSplit dt_split_plan(long tiles, int nk, float* ws, long ws_bytes, int* grid_y) {
+  DtSplit sp{};
+  *grid_y = (int)tiles;
+  const int rem = (int)(tiles % DT_CUS);
+  static const int off = [] { const char* e = getenv("SM_DT_SPLIT"); return e != nullptr && e[0] == '0'; }();
+  if (ws == nullptr || off || rem == 0 || rem > DT_CUS * 3 / 4 || ws_bytes < sm_sparse_head_bwd_dt_ws_bytes() || ((uintptr_t)ws % 16) != 0) return sp;
+  const long units = (long)rem * nk;
+  const int upw = (int)((units + DT_CUS - 1) / DT_CUS);
+  if (upw < 32) return sp;  // (a tiny vocabulary: the flush would dominate)
+  sp.sum = ws;
+  sp.n_full = (int)(tiles - rem);
+  sp.tail_tiles = rem;
+  sp.upw = upw;
+  *grid_y = sp.n_full + (int)((units + upw - 1) / upw);
+  return sp;
+}
+
 int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dft,
                          int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x, const float* gamma,
-                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, int x_f32, hipStream_t st) {
+                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, int x_f32,
+                         float* ws, long ws_bytes, hipStream_t st) {
   const long T = rag ? rag->rows : (long)B * S;
   if (dtype != SM_BF16 || H != DT_C || V % 2 != 0 || ((uintptr_t)E % 16) != 0 || !(rag || S % 16 == 0)) return 1;
   if ((((uintptr_t)x | (uintptr_t)gelu_of | (uintptr_t)dft | (uintptr_t)gamma) % 16) != 0) return 1;
@@ -2211,9 +2308,25 @@ int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, con
   ln.dbeta = dbeta;
   ln.post_gelu_of = (const bf16*)gelu_of;
   constexpr int lds = (DT_LDS > NB_LDS ? DT_LDS : NB_LDS) + 2 * NB_C * 4;
-  SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(head_dt192_kernel<true>, dim3(1, sm_cdiv(T, DT_R)), dim3(512), lds, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dft, B, S, H, V,
-                     use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0, ln);
+  int gy;
+  const DtSplit sp = dt_split_plan(sm_cdiv(T, DT_R), (V + 31) / 32, ws, ws_bytes, &gy);
+  // whole tiles: one workgroup each; then (second launch) the split tail
+  const int whole = sp.sum != nullptr ? sp.n_full : gy;
+  if (whole > 0) {
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((head_dt192_kernel<true, false>), dim3(1, whole), dim3(512), lds, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dft, B, S, H, V,
+                       use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0, ln, DtSplit{});
+    SM_LAUNCH_CHECK();
+  }
+  if (sp.sum != nullptr) {
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
+    hipLaunchKernelGGL((head_dt192_kernel<false, true>), dim3(1, gy - sp.n_full), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dft, B,
+                       S, H, V, use_l0, rag ? rag->doc_off : nullptr, rag ? rag->blk_doc : nullptr, rag ? rag->rows : 0, LnBwdArgs{}, sp);
+    SM_LAUNCH_CHECK();
+    constexpr int elds = NB_LDS + 2 * NB_C * 4;
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, elds));
+    hipLaunchKernelGGL(head_dt_tail_kernel, dim3(sp.tail_tiles), dim3(512), elds, st, (bf16*)dft, (int)T, H, ln, sp);
+  }
   SM_LAUNCH_CHECK();
   return SM_OK;
 }
@@ -2228,9 +2341,9 @@ int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const 
   const int rrows = rag ? rag->rows : 0;
   constexpr int dt192 = 1;
   if (dt192 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
-    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
-    hipLaunchKernelGGL(head_dt192_kernel<false>, dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
-                       B, S, H, V, use_l0, doc_off, blk_doc, rrows, LnBwdArgs{});
+    SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
+    hipLaunchKernelGGL((head_dt192_kernel<false, false>), dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
+                       B, S, H, V, use_l0, doc_off, blk_doc, rrows, LnBwdArgs{}, DtSplit{});
     SM_LAUNCH_CHECK();
     return SM_OK;
   }

@@ -668,16 +668,17 @@ extern "C" int sm_sparse_head_bwd(int dtype, const float* grad_rep, const float*
 // dft = LayerNorm'(G . E) * gelu'(gelu_of).  Returns 1 when the fused kernel does not take the shape.
 int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E, void* dft,
                          int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x, const float* gamma,
-                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, int x_f32, hipStream_t st);
+                         const float* mean, const float* rstd, const void* gelu_of, float* dgamma, float* dbeta, int x_f32, float* ws,
+                         long ws_bytes, hipStream_t st);
 extern "C" int sm_sparse_head_bwd_dt_ln(int dtype, const float* grad_rep, const float* rep, const uint16_t* argmax, const void* E,
                                         void* dft, int B, int S, int H, int V, int use_l0, const sm_ragged* rag, const void* x,
                                         const float* gamma, const float* mean, const float* rstd, const void* gelu_of, float* dgamma,
-                                        float* dbeta, int x_f32, void* stream) {
+                                        float* dbeta, int x_f32, float* ws, long ws_bytes, void* stream) {
   SM_REQUIRE(B > 0 && S > 0 && V > 0, "sm_sparse_head_bwd_dt_ln: empty problem");
   SM_REQUIRE(grad_rep && rep && argmax && E && dft && x && gamma && mean && rstd && gelu_of && dgamma && dbeta,
              "sm_sparse_head_bwd_dt_ln: null argument");
   return sm_head_dt_ln_launch(dtype, grad_rep, rep, argmax, E, dft, B, S, H, V, use_l0, rag, x, gamma, mean, rstd, gelu_of, dgamma, dbeta, x_f32,
-                              (hipStream_t)stream);
+                              ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sm_prune_rows(float* rep, int B, int V, float prune_ratio, void* stream) {

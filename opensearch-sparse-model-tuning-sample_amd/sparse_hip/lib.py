@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
 SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
-ABI_VERSION = 5  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
+ABI_VERSION = 6  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
 
 
 class SmDropout(C.Structure):
@@ -89,7 +89,8 @@ SIGNATURES = {
     "sm_sparse_head_fwd_scratch_bytes": [_i, _i, _i, _i, _i, _i],
     "sm_prune_rows": [_p, _i, _i, _f, _p],
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
-    "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p],
+    "sm_sparse_head_bwd_dt_ws_bytes": [],
     "sm_sparse_head_bwd_dt_scatter": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],

@@ -363,19 +363,36 @@ def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E:
     return dt
 
 
+_DT_WS = {}  # device index -> the zeroed workspace of sm_sparse_head_bwd_dt_ln's split tail (the kernel leaves it zero)
+
+
+def _dt_workspace(device) -> Optional[Tensor]:
+    """one workspace per device, used by one launch at a time: the calls of a process are ordered on the training stream.
+    None (no split: bit-reproducible sums) under SM_DETERMINISTIC=1"""
+    if DETERMINISTIC_SCORES:
+        return None
+    ws = _DT_WS.get(device.index)
+    if ws is None:
+        ws = _DT_WS[device.index] = torch.zeros(L.load().sm_sparse_head_bwd_dt_ws_bytes() // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def sparse_head_bwd_dt_ln(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tensor, B: int, S: int, V: int, use_l0: bool,
                           rag: Optional[Ragged], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, gelu_of: Tensor,
-                          dgamma: Tensor, dbeta: Tensor) -> Optional[Tensor]:
+                          dgamma: Tensor, dbeta: Tensor, split_tail: bool = True) -> Optional[Tensor]:
     """dt half of the head backward fused with the backward of the transform's LayerNorm (input x) and GELU (input gelu_of):
-    the gradient w.r.t. the transform's dense output, or None when the fused kernel does not take the shape"""
+    the gradient w.r.t. the transform's dense output, or None when the fused kernel does not take the shape.  split_tail: a last
+    round of row tiles that would leave most of the chip idle is split along the vocabulary (fp32 atomics into a workspace)"""
     H = x.shape[1]
     x32 = x.dtype == torch.float32 and E.dtype != torch.float32  # the LayerNorm input kept in fp32 (fp16-forward mode)
     if not (x.is_contiguous() and gelu_of.is_contiguous() and gelu_of.dtype == E.dtype and (x32 or x.dtype == E.dtype)):
         return None
     dft = torch.empty_like(gelu_of)
+    ws = _dt_workspace(E.device) if split_tail else None
     ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(E.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
                          L.ptr(dft), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), int(x32), L.stream_ptr())
+                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), int(x32), L.ptr(ws) if ws is not None else None,
+                         ws.numel() * 4 if ws is not None else 0, L.stream_ptr())
     return dft if ok else None
 
 

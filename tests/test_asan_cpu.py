@@ -62,7 +62,10 @@ run("sm_attention_bwd", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), P(15), B, 
 run("sm_sparse_head_fwd", L.SM_F16, P(10), P(11), P(12), P(13), P(14), P(15), B, S, H, V, 0, C.byref(rag), None, None)
 run("sm_sparse_head_fwd", L.SM_F32, P(10), P(11), P(12), P(13), P(14), P(15), B, S, H, V, 1, None, None, None)
 run("sm_sparse_head_bwd", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), B, S, H, V, 0, C.byref(rag), None)
-run("sm_sparse_head_bwd_dt_ln", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), B, S, H, V, 0, None, P(15), P(16), P(17), P(18), P(19), P(20), P(21), 1, None)
+run("sm_sparse_head_bwd_dt_ln", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), B, S, H, V, 0, None, P(15), P(16), P(17), P(18), P(19), P(20), P(21), 1, None, 0, None)
+# ... with the workspace: 342 row tiles -> the last 86 split along the vocabulary (the planner's arithmetic runs on the host)
+run("sm_sparse_head_bwd_dt_ln", L.SM_BF16, P(10), P(11), P(12), P(13), P(14), B, S, H, V, 0, None, P(15), P(16), P(17), P(18), P(19), P(20), P(21), 1, P(22),
+    lib.sm_sparse_head_bwd_dt_ws_bytes(), None)
 run("sm_flops_fwd", P(10), B, 16, V, 150, P(11), P(12), P(13), None)
 run("sm_scores_fwd", P(10), P(11), 32, B, V, 0, P(12), None)
 run("sm_scores_fwd", P(10), P(11), 32, B, V, 2, P(12), None)   # deterministic form

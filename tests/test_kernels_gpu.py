@@ -254,6 +254,45 @@ def test_head_backward_fused_with_the_transform_layernorm_and_gelu_backward(ops,
                                      mean, rstd, x256, torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")) is None
 
 
+@pytest.mark.parametrize("B,S,V,ragged", [(60, 128, 8192, False), (60, 128, 8192, True), (512, 128, 30522, False), (300, 128, 30522, False)])
+def test_head_backward_split_tail_equals_the_whole_tile_form(ops, B, S, V, ragged):
+    """sm_sparse_head_bwd_dt_ln with its workspace (ABI 6): a last round of 192-row tiles that would leave most of the chip idle is split
+    along the vocabulary, partial tiles summed with fp32 atomics, a small third launch runs the LayerNorm' / GELU' epilogue on the sums.  Same
+    result as the whole-tile form up to fp32 summation order; the workspace is zero again afterwards (the next launch relies on it).
+    40 tiles (all split, runs straddle tiles), the bench batch (342 = 256 whole + 86 split), 200 tiles (> 3/4 of the chip: not split)"""
+    dtype = torch.bfloat16
+    H = 384
+    g = torch.Generator().manual_seed(B + V)
+    if ragged:
+        lens = (torch.randint(4, S // 16 + 1, (B,), generator=g) * 16 - 3).tolist()
+        lens[0] = S
+        _, off_np, nrows, row_doc, pos, _ = _ragged(lens)
+        rag = ops.Ragged(dev(off_np.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), nrows, B, S)
+    else:
+        lens, rag, nrows = [S] * B, None, B * S
+    E = dev(q(rnd(V, H, seed=2, scale=0.2), dtype), dtype)
+    rep = dev(torch.rand(B, V, generator=g) * (torch.rand(B, V, generator=g) < 0.3))
+    grad_rep = dev(torch.randn(B, V, generator=g))
+    argmax = dev(torch.stack([torch.randint(0, lens[b], (V,), generator=g) for b in range(B)]).to(torch.int16)).view(torch.uint16)
+    gt, ft = dev(q(rnd(nrows, H, seed=6, scale=1.5), dtype), dtype), dev(q(rnd(nrows, H, seed=7), dtype), dtype)
+    gamma, beta = dev(1.0 + 0.1 * rnd(H, seed=8)), dev(0.1 * rnd(H, seed=9))
+    _, mean, rstd = ops.layernorm_fwd(gt, gamma, beta, 1e-12)
+    out = []
+    for split in (False, True, True):
+        dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        dft = ops.sparse_head_bwd_dt_ln(grad_rep, rep, argmax, E, B, S, V, False, rag, gt, gamma, mean, rstd, ft, dg, db, split_tail=split)
+        assert dft is not None
+        out.append((dft.float().cpu(), dg.cpu(), db.cpu()))
+    ws = ops._DT_WS[torch.cuda.current_device()]
+    assert float(ws.abs().max()) == 0.0, "the split tail must leave its workspace zero"
+    scale = float(out[0][0].abs().max())
+    for k in (1, 2):  # (twice: the second launch starts from the workspace the first one left)
+        assert float((out[k][0] - out[0][0]).abs().max()) <= 4e-3 * scale  # one bf16 ulp of the largest entry
+        assert float((out[k][0] - out[0][0]).norm() / out[0][0].norm()) <= 1e-3
+        for a in (1, 2):
+            assert float((out[k][a] - out[0][a]).norm() / out[0][a].norm()) <= 1e-3
+
+
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,Kc", [(300, 72, 136), (1024, 128, 128), (96, 192, 64), (2000, 64, 520 - 520 % 8),
@@ -861,9 +900,15 @@ def test_sparse_head_ragged_layout(ops, dtype, H, use_l0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_ragged_layout(ops, dtype):
-    lens, off, rows, row_doc, pos, valid = _ragged([37, 128, 16, 90, 5, 64])
-    B, A, dh, S = len(lens), 2, 32, 128
+@pytest.mark.parametrize("A,dh,S,doc_lens", [(2, 32, 128, [37, 128, 16, 90, 5, 64]), (3, 64, 512, [300, 512, 17, 129, 480, 64, 255]),
+                                             (2, 64, 256, [256, 100, 31]), (3, 32, 512, [511, 48, 200])])
+def test_attention_ragged_layout(ops, dtype, A, dh, S, doc_lens):
+    """un-padded documents against the per-document eager attention; the long-document shapes (configs[4]: head dim 64, up to 512
+    tokens) run 8 waves per workgroup forward and 12 backward over one document's K / V images"""
+    if dtype == torch.float32 and S * dh > 256 * 64:
+        pytest.skip("fp32 parity mode: two [S][dh] fp32 LDS images cap S*dh at 256*64")
+    lens, off, rows, row_doc, pos, valid = _ragged(doc_lens)
+    B = len(lens)
     H = A * dh
     rag = ops.Ragged(dev(off.astype(np.int32)), dev(row_doc[::16].astype(np.int32)), dev(pos.astype(np.int32)), rows, B, S)
     qkv = q(rnd(rows, 3 * H, seed=1), dtype)
