@@ -102,6 +102,16 @@ typedef struct sm_epilogue {
                                dtypes, N % 32 == 0) instead of a row-major [M,N] tensor */
   const float* scale_a;     /* SM_FP8 / SM_FP8_GRAD only: DEVICE scalars, the dequantisation scales of A and B (sm_quantize_fp8); the */
   const float* scale_b;     /* accumulator is multiplied by *scale_a * *scale_b before the epilogue                                     */
+  /* ABI 6 -- the result ALSO (C != NULL) or ONLY (C == NULL) as the fp8 operand of the next sm_gemm_nt, quantised in this epilogue
+   * with sm_quantize_fp8's arithmetic on the value the 16-bit store rounds to (so a separate sm_quantize_fp8 pass over C gives the
+   * same bytes): q8[M,N] (ldc) e4m3 (q8_e5m2 = 0) or e5m2; *q8_amax = the maximum the scale is derived from (delayed scaling: an
+   * earlier step's; with q8_amax_next != NULL it is taken with the same margin of 2 and this call's maximum is joined into
+   * *q8_amax_next); *q8_scale receives the dequantisation scale.  16-bit result types, N % 8 == 0, ldc % 8 == 0; all NULL / 0: off */
+  void* q8;
+  const float* q8_amax;
+  float* q8_scale;
+  float* q8_amax_next;
+  int q8_e5m2;
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

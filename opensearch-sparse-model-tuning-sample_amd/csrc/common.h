@@ -201,3 +201,31 @@ static inline DropCfg make_drop(const sm_dropout* s) {
   d.scale = 256.0f / (256.0f - (float)t);
   return d;
 }
+
+// ---- fp8 quantisation pieces shared by csrc/fp8.hip and the GEMM epilogue that emits fp8 itself (csrc/gemm.hip) ----
+// running maximum of |v| that REMEMBERS a NaN / Inf: fmaxf drops a NaN operand, so a tensor that went non-finite would be
+// quantised against the maximum of its finite part and come out finite (saturated) -- the non-finite value laundered away.  A
+// non-finite element makes the maximum NaN (as a bit pattern it orders above every finite float: atomicMax keeps it), the
+// scale derived from it is NaN and the GEMM that multiplies by the scale returns NaN: the failure surfaces where it happened.
+__device__ __forceinline__ void amax_acc(float& m, bool& bad, float v) {
+  const float a = fabsf(v);
+  bad = bad || !(a <= 3.4028234e38f);
+  m = fmaxf(m, a);
+}
+__device__ __forceinline__ float amax_final(float m, bool bad) { return bad ? __uint_as_float(0x7FC00000u) : m; }
+__device__ __forceinline__ float amax_join(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7FC00000u) : fmaxf(a, b); }
+
+// four floats -> four fp8 bytes (one dword), E5M2 selects the gradient format
+template <bool E5M2> __device__ __forceinline__ uint32_t fp8_pack4(float a, float b, float c, float d) {
+  int w = 0;
+  if constexpr (E5M2) {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  }
+  return (uint32_t)w;
+}
+
+

@@ -11,18 +11,6 @@ namespace {
 
 template <typename T> __device__ __forceinline__ float fp8_in(const T* p, long i) { return to_f32<T>(p[i]); }
 
-// running maximum of |v| that REMEMBERS a NaN / Inf: fmaxf drops a NaN operand, so a tensor that went non-finite would be
-// quantised against the maximum of its finite part and come out finite (saturated) -- the non-finite value laundered away.  A
-// non-finite element makes the maximum NaN (as a bit pattern it orders above every finite float: atomicMax keeps it), the
-// scale derived from it is NaN and the GEMM that multiplies by the scale returns NaN: the failure surfaces where it happened.
-__device__ __forceinline__ void amax_acc(float& m, bool& bad, float v) {
-  const float a = fabsf(v);
-  bad = bad || !(a <= 3.4028234e38f);
-  m = fmaxf(m, a);
-}
-__device__ __forceinline__ float amax_final(float m, bool bad) { return bad ? __uint_as_float(0x7FC00000u) : m; }
-__device__ __forceinline__ float amax_join(float a, float b) { return (a != a || b != b) ? __uint_as_float(0x7FC00000u) : fmaxf(a, b); }
-
 template <typename T>
 __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long n, float* __restrict__ amax) {
   float m = 0.f;
@@ -52,19 +40,6 @@ __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, long
     // non-negative floats order like their bit patterns (and the NaN pattern above all of them)
     atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
   }
-}
-
-// four floats -> four fp8 bytes (one dword), E5M2 selects the gradient format
-template <bool E5M2> __device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d) {
-  int w = 0;
-  if constexpr (E5M2) {
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
-  } else {
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  }
-  return (uint32_t)w;
 }
 
 // amax_next != NULL (delayed scaling): the scale comes from an EARLIER pass over this tensor site (*amax, e.g. the previous training
@@ -100,8 +75,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(f[k] * mul, -FMAX), FMAX);
     uint2 o;
-    o.x = pack4<E5M2>(f[0], f[1], f[2], f[3]);
-    o.y = pack4<E5M2>(f[4], f[5], f[6], f[7]);
+    o.x = fp8_pack4<E5M2>(f[0], f[1], f[2], f[3]);
+    o.y = fp8_pack4<E5M2>(f[4], f[5], f[6], f[7]);
     *reinterpret_cast<uint2*>(q + v * 8) = o;
   }
   if (blockIdx.x == 0)
@@ -109,7 +84,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ x, 
       const float v = fp8_in<T>(x, i);
       amax_acc(seen, bad, v);
       const float f = fminf(fmaxf(v * mul, -FMAX), FMAX);
-      q[i] = (uint8_t)(pack4<E5M2>(f, 0.f, 0.f, 0.f) & 0xff);
+      q[i] = (uint8_t)(fp8_pack4<E5M2>(f, 0.f, 0.f, 0.f) & 0xff);
     }
   if (amax_next != nullptr) {  // (uniform)
     seen = amax_final(seen, bad);

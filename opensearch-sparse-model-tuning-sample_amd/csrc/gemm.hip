@@ -426,6 +426,13 @@ struct EpiArgs {
   const float *scale_a, *scale_b;  // fp8 operands: the accumulator is multiplied by *scale_a * *scale_b (device scalars, csrc/fp8.hip)
   int res32, out32;  // fp32 residual stream: residual read / C written as fp32 whatever T is
   const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // res32: residual = LayerNorm(residual) recomputed from its fp32 input
+  // the result ALSO (C != null) or ONLY (C == null) as the fp8 operand of the next GEMM, quantised here exactly as sm_quantize_fp8
+  // would quantise the 16-bit tensor this epilogue stores (delayed scaling: *q8_amax is an earlier step's maximum of this site)
+  uint8_t* q8;
+  const float* q8_amax;
+  float* q8_scale;
+  float* q8_amax_next;
+  int q8_e5m2;
 };
 
 // gelu_grad_of as the producer / consumer feed-forward kernel leaves it (csrc/ffn_pc.hip, include/sparse_hip.h): tiles of 32 rows x
@@ -500,6 +507,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
   float bv[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) bv[k] = (e.bias && col + k < N) ? e.bias[col + k] : 0.f;
+  // fp8 copy of the result (e.q8): sm_quantize_fp8's arithmetic with the delayed scale (csrc/fp8.hip)
+  float q8_mul = 0.f, q8_seen = 0.f;
+  bool q8_bad = false;
+  if (e.q8) {
+    const float fmax8 = e.q8_e5m2 ? 57344.f : 448.f;
+    const float a0 = *e.q8_amax;
+    const float am = a0 != a0 ? a0 : fmaxf(a0, 1e-30f) * (e.q8_amax_next != nullptr ? 2.0f : 1.0f);
+    q8_mul = fmax8 / am;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *e.q8_scale = am / fmax8;
+  }
 #pragma unroll
   for (int half = 0; half < WM; ++half) {  // one wave row (64 tile rows) per pass
     // LDS-only barriers: __syncthreads() also waits for the previous pass's GLOBAL stores (vmcnt(0)), ~3 k cycles of write latency
@@ -588,12 +605,38 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
             }
           }
         }
-        if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);
-        else store8<T>(C + off, v, full, N - col);
+        if (e.q8) {  // (launcher: full vectors only, a 16-bit result type)
+          const float fmax8 = e.q8_e5m2 ? 57344.f : 448.f;
+          float f[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            f[k] = to_f32<T>(from_f32<T>(v[k]));  // the value the 16-bit store rounds to: what a separate pass would read back
+            amax_acc(q8_seen, q8_bad, f[k]);
+            f[k] = fminf(fmaxf(f[k] * q8_mul, -fmax8), fmax8);
+          }
+          uint2 o;
+          if (e.q8_e5m2) { o.x = fp8_pack4<true>(f[0], f[1], f[2], f[3]); o.y = fp8_pack4<true>(f[4], f[5], f[6], f[7]); }
+          else { o.x = fp8_pack4<false>(f[0], f[1], f[2], f[3]); o.y = fp8_pack4<false>(f[4], f[5], f[6], f[7]); }
+          *reinterpret_cast<uint2*>(e.q8 + off) = o;
+        }
+        if (C != nullptr) {
+          if (e.out32) store8<float>(reinterpret_cast<float*>(C) + off, v, full, N - col);
+          else store8<T>(C + off, v, full, N - col);
+        }
         NT_STAMP(22 + 8 * half + it);
       }
     }
     NT_STAMP(2 + half);
+  }
+  if (e.q8 && e.q8_amax_next != nullptr) {  // this tile's maximum for the next step's scale: one atomic per wave, and only when it raises the value
+    float m = amax_final(q8_seen, q8_bad);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = amax_join(m, __shfl_xor(m, o));
+    if (lane == 0) {
+      const unsigned int mb = __float_as_uint(m);  // non-negative floats order like their bit patterns (NaN above all of them)
+      if (mb > __hip_atomic_load(reinterpret_cast<unsigned int*>(e.q8_amax_next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned int*>(e.q8_amax_next), mb);
+    }
   }
 }
 
@@ -1639,6 +1682,21 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
                     const void* f1_tiled, void* ga, hipStream_t st);  // gemm_ws.hip
 namespace {
 
+// sm_epilogue.q8*: checked and copied (the other launchers leave e.q8 null)
+int epi_q8(EpiArgs& e, const sm_epilogue* epi, const void* C, int N, bool types_ok) {
+  e.q8 = epi ? (uint8_t*)epi->q8 : nullptr;
+  e.q8_amax = epi ? epi->q8_amax : nullptr;
+  e.q8_scale = epi ? epi->q8_scale : nullptr;
+  e.q8_amax_next = epi ? epi->q8_amax_next : nullptr;
+  e.q8_e5m2 = epi ? epi->q8_e5m2 : 0;
+  SM_REQUIRE(C != nullptr || e.q8 != nullptr, "sm_gemm_nt: C is NULL and there is no q8 output either");
+  if (e.q8 == nullptr) return 0;
+  SM_REQUIRE(types_ok, "sm_gemm_nt: q8 needs a 16-bit result type (no out_f32)");
+  SM_REQUIRE(e.q8_amax && e.q8_scale, "sm_gemm_nt: q8 needs q8_amax (the scale's source) and q8_scale");
+  SM_REQUIRE(e.vec_ok && N % 8 == 0 && ((uintptr_t)e.q8 % 8) == 0, "sm_gemm_nt: q8 needs N %% 8 == 0, ldc %% 8 == 0 and aligned tensors");
+  return 0;
+}
+
 template <typename T>
 int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const sm_epilogue* epi, hipStream_t st) {
@@ -1669,6 +1727,8 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   const uintptr_t vb = 8 * sizeof(T);
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
+  const int q8rc = epi_q8(e, epi, C, N, sizeof(T) == 2 && !(epi && epi->out_f32));
+  if (q8rc != 0) return q8rc;
   constexpr int nt192 = 1;
   constexpr bool is_f16 = std::is_same<T, f16>::value;
   // fp16 operands: the 192 x 384 kernel's epilogue types its 16-bit tensors bf16, so it takes fp16 only when there is none
@@ -1678,7 +1738,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 512) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
-    if (nt192 && nt192_shape && nt192_types_ok && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
+    if (nt192 && !e.q8 && nt192_shape && nt192_types_ok && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
       const int items = sm_cdiv(M, NB_R) * (N / NB_C);
       auto kern = is_f16 ? gemm_nt192_kernel<false, 0, true> : gemm_nt192_kernel<false, 0, false>;
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
@@ -1692,7 +1752,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     // K = 384 with a plain (bias) or dF1 (x gelu'(tile-major f1), + gelu(f1)) epilogue: the weight-stationary kernel (gemm_ws.hip)
     const bool plain = !e.act && !e.preact && !e.drop.thresh16 && !e.residual && !e.out32 && !e.rl_mean;
     const bool epi0 = !e.gelu_grad_of && !e.gelu_out, epi1 = e.gelu_grad_of && e.ggo_tiled && !e.bias;
-    if (plain && (epi0 || epi1) &&
+    if (plain && !e.q8 && (epi0 || epi1) &&
         sm_gemm_ws_try(SM_BF16, A, lda, B, ldb, C, ldc, M, N, K, e.bias, epi1 ? e.gelu_grad_of : nullptr, e.gelu_out, st))
       return 0;
   }
@@ -1705,7 +1765,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
 #define SM_NT256 0
 #endif
     constexpr bool nt256 = SM_NT256 != 0;
-    if (bool(glds_on) && nt256 && (long)sm_cdiv(M, 256) * sm_cdiv(N, BN) >= 1024) {
+    if (bool(glds_on) && nt256 && !e.q8 && (long)sm_cdiv(M, 256) * sm_cdiv(N, BN) >= 1024) {
       constexpr int smem256 = 3 * (256 * 64 + GL_STAGE);
       auto kern = gemm_nt_kernel<T, true, T, 4>;
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem256);
@@ -1798,6 +1858,8 @@ int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, 
   const uintptr_t vb = 16;
   e.vec_ok = (ldc % 8 == 0) && ((uintptr_t)C % (e.out32 ? 32 : vb) == 0) && ((uintptr_t)e.preact % vb == 0) &&
              ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
+  const int q8rc = epi_q8(e, epi, C, N, !epi->out_f32);
+  if (q8rc != 0) return q8rc;
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 2 * 3 * GL_STAGE, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
                      K, e);

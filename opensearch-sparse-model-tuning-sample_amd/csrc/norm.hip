@@ -88,31 +88,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
   }
 }
 
-template <typename T, int NCH, typename TX = T>
+// LPR = lanes per row (16: four rows per wave and pass, NCH chunks of 8 columns per lane; 32: two rows, for the wide rows of
+// bert-base -- at H = 768 the 16-lane form holds 5 x 48 values per lane, 256 registers, one wave per SIMD: 1.7 TB/s)
+template <typename T, int NCH, typename TX = T, int LPR = 16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, T* __restrict__ dx_drop, DropCfg drop,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int H) {
   __shared__ float red[4][2][MAXC * 64];
-  const int lane = threadIdx.x & 63, sl = lane & 15, sub = lane >> 4, w = threadIdx.x >> 6;
+  constexpr int RPW = 64 / LPR;  // rows per wave and pass
+  const int lane = threadIdx.x & 63, sl = lane & (LPR - 1), sub = lane / LPR, w = threadIdx.x >> 6;
   const int nch = H >> 3;
   float gam[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { dg[i][k] = 0.f; db[i][k] = 0.f; gam[i][k] = 0.f; }
-    if (sl + 16 * i < nch) ld8<float>(gamma + (sl + 16 * i) * 8, gam[i]);
+    if (sl + LPR * i < nch) ld8<float>(gamma + (sl + LPR * i) * 8, gam[i]);
   }
-  for (int row = (blockIdx.x * 4 + w) * 4 + sub; row < rows; row += gridDim.x * 16) {
+  for (int row = (blockIdx.x * 4 + w) * RPW + sub; row < rows; row += gridDim.x * 4 * RPW) {
     const float mu = mean[row], rs = rstd[row];
     float xh[NCH][8], dyh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (sl + 16 * i < nch) {
+      if (sl + LPR * i < nch) {
         float d[8];
-        ld8<T>(dy + (size_t)row * H + (sl + 16 * i) * 8, d);
-        ld8<TX>(x + (size_t)row * H + (sl + 16 * i) * 8, xh[i]);
+        ld8<T>(dy + (size_t)row * H + (sl + LPR * i) * 8, d);
+        ld8<TX>(x + (size_t)row * H + (sl + LPR * i) * 8, xh[i]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           xh[i][k] = (xh[i][k] - mu) * rs;
@@ -123,11 +126,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           s2 += dyh[i][k] * xh[i][k];
         }
       }
+    if constexpr (LPR == 32) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }
     const float c1 = sub16_sum(s1) / H, c2 = sub16_sum(s2) / H;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (sl + 16 * i < nch) {
-        const int c0 = (sl + 16 * i) * 8;
+      if (sl + LPR * i < nch) {
+        const int c0 = (sl + LPR * i) * 8;
         float gx[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) gx[k] = rs * (dyh[i][k] - c1 - xh[i][k] * c2);
@@ -146,9 +150,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float a = dg[i][k], b = db[i][k];
-      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (sub == 0 && sl + 16 * i < nch) { red[w][0][(sl + 16 * i) * 8 + k] = a; red[w][1][(sl + 16 * i) * 8 + k] = b; }
+      if constexpr (LPR == 16) { a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); }
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (sub == 0 && sl + LPR * i < nch) { red[w][0][(sl + LPR * i) * 8 + k] = a; red[w][1][(sl + LPR * i) * 8 + k] = b; }
     }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
@@ -406,6 +411,14 @@ extern "C" int sm_layernorm_bwd_res32(int dtype, const void* dy, const float* x3
   const DropCfg d = make_drop(drop);
   int grid = sm_cdiv(rows, 64);
   if (grid > 512) grid = 512;
+  if (H > 512 && H % 256 == 0) {  // wide rows: 32 lanes per row (H / 256 chunks per lane)
+    grid = sm_cdiv(rows, 32) < 1024 ? sm_cdiv(rows, 32) : 1024;
+    SM_DISPATCH(dtype, "sm_layernorm_bwd_res32",
+                LN_NCH(H / 2, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, float, 32>), dim3(grid), dim3(256), 0, st, (const T*)dy, x32, gamma, mean, rstd,
+                                                 (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   SM_DISPATCH(dtype, "sm_layernorm_bwd_res32",
               LN_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, float>), dim3(grid), dim3(256), 0, st, (const T*)dy, x32, gamma, mean, rstd,
                                            (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));
@@ -421,6 +434,14 @@ extern "C" int sm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
   const DropCfg d = make_drop(drop);
   int grid = sm_cdiv(rows, 64);  // >= 4 passes per wave so the dgamma/dbeta atomics stay few
   if (grid > 512) grid = 512;
+  if (H > 512 && H % 256 == 0) {
+    grid = sm_cdiv(rows, 32) < 1024 ? sm_cdiv(rows, 32) : 1024;
+    SM_DISPATCH(dtype, "sm_layernorm_bwd",
+                LN_NCH(H / 2, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, T, 32>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                                                 (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+  }
   SM_DISPATCH(dtype, "sm_layernorm_bwd",
               LN_NCH(H, hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
                                            (T*)dx, (T*)dx_drop, d, dgamma, dbeta, rows, H)));

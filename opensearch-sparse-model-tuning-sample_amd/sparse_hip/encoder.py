@@ -192,6 +192,7 @@ KERNEL_OPTIONS = {
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
     "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
+    "fp8_emit": ("SM_FP8_EMIT", True, bool),                  # fp8 mode: the FFN-up epilogue writes the FFN-down's e4m3 operand itself (no quantisation pass)
     "tn_group": ("SM_TN_GROUP", True, bool),
     "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
@@ -309,6 +310,7 @@ class HipBertMLM(torch.nn.Module):
         self.graph_tokens = opt("encode_graph_tokens")
         self.wgrad_stream = opt("wgrad_stream")
         self.tn_group = opt("tn_group")
+        self.fp8_emit = opt("fp8_emit")
         self.tn_pair = opt("tn_pair")
         # Density-adaptive head backward: the share of live sparse activations of the PREVIOUS encode (counted on a sample of the
         # columns, read back without stalling: by the next step the copy has long landed) picks between the matrix form of dt = G . E
@@ -450,7 +452,7 @@ class HipBertMLM(torch.nn.Module):
     def kernel_options(self) -> dict:
         """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
         return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
-                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "tn_group": self.tn_group, "tn_pair": self.tn_pair, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "fp8_emit": self.fp8_emit, "tn_group": self.tn_group, "tn_pair": self.tn_pair, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
                 "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
 
     def sync_weights(self) -> None:
@@ -527,26 +529,44 @@ class HipBertMLM(torch.nn.Module):
         self._weights_dirty = False
 
     # ------------------------------------------------------------------ forward / backward
-    def _lin(self, a: Tensor, key: str, grad: bool = False, **epi) -> Tensor:
+    def _fp8_site(self, key: str, device) -> int:
+        if self._fp8_cur is None:
+            n = 8 * self.config.num_hidden_layers
+            self._fp8_cur, self._fp8_next = (torch.zeros(n, dtype=torch.float32, device=device) for _ in range(2))
+        return self._fp8_sites.setdefault(key, len(self._fp8_sites))
+
+    def _lin(self, a, key: str, grad: bool = False, emit8: Optional[str] = None, keep16: bool = True, **epi):
         """epilogue(a . W^T) for the staged weight `key` of an encoder linear: bf16 / fp32 operands, or (self.fp8) `a` quantised here
-        to e4m3 (e5m2 when it is a gradient) against the staged e4m3 weight"""
+        to e4m3 (e5m2 when it is a gradient) against the staged e4m3 weight.  emit8 = the key of the linear that consumes the result
+        (fp8 mode with delayed scaling, once that site has a history): the GEMM's epilogue writes the fp8 operand itself -- no
+        separate quantisation pass over the [T, N] result -- and the return value is (out, (q, scale)) where `a` of the consumer's
+        _lin call may be that pair; keep16 = False: the 16-bit result is not written at all (out is None)"""
         st = self._staged
+        q8 = None
+        if emit8 is not None and self.fp8 and self._fp8_delayed and self.fp8_emit:
+            j = self._fp8_site(emit8, st[key].device)
+            if j in self._fp8_ready:
+                q8 = (self._fp8_cur[j:j + 1], self._fp8_next[j:j + 1], False)
+                epi = dict(epi, q8=q8, no_out=not keep16)
+        if isinstance(a, tuple):  # an fp8 operand an earlier epilogue produced: (q, scale)
+            aq, sa = a
+            r = ops.gemm_nt(aq, st[key + "_8"], scale_a=sa, scale_b=st[key + "_8s"], **epi)
+            return (r[0], (r[1], r[2])) if q8 is not None else ((r, None) if emit8 is not None else r)
         if self.fp8 and a.dtype == torch.bfloat16:
             if not self._fp8_delayed:
                 aq, sa, _ = ops.quantize_fp8(a, e5m2=grad)
             else:
-                if self._fp8_cur is None:
-                    n = 8 * self.config.num_hidden_layers
-                    self._fp8_cur, self._fp8_next = (torch.zeros(n, dtype=torch.float32, device=a.device) for _ in range(2))
-                i = self._fp8_sites.setdefault(key, len(self._fp8_sites))
+                i = self._fp8_site(key, a.device)
                 nxt = self._fp8_next[i:i + 1]
                 if i in self._fp8_ready:
                     aq, sa, _ = ops.quantize_fp8(a, e5m2=grad, amax=self._fp8_cur[i:i + 1], amax_next=nxt)
                 else:  # no history for this site yet: measure now, remember for the next step
                     aq, sa, am = ops.quantize_fp8(a, e5m2=grad)
                     torch.maximum(nxt, am, out=nxt)
-            return ops.gemm_nt(aq, st[key + "_8"], scale_a=sa, scale_b=st[key + "_8s"], **epi)
-        return ops.gemm_nt(a, st[key], **epi)
+            r = ops.gemm_nt(aq, st[key + "_8"], scale_a=sa, scale_b=st[key + "_8s"], **epi)
+            return (r[0], (r[1], r[2])) if q8 is not None else ((r, None) if emit8 is not None else r)
+        r = ops.gemm_nt(a, st[key], **epi)
+        return (r, None) if emit8 is not None else r
 
     @staticmethod
     def padded_len(S: int) -> int:
@@ -649,8 +669,11 @@ class HipBertMLM(torch.nn.Module):
                 z2 = ops.gemm_nt(gah, st[f"w2h{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=True, residual_ln=res1_ln)
                 ga = None
             else:
-                ga = self._lin(x1, f"w1{l}", bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
-                z2 = self._lin(ga, f"w2{l}", bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
+                # (fp8: the FFN-up epilogue writes gelu(f1) as the FFN-down's e4m3 operand itself; the bf16 copy only when the
+                # backward will want it -- the no-grad pass of gradient caching skips it)
+                ga, ga8 = self._lin(x1, f"w1{l}", emit8=f"w2{l}", keep16=save, bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
+                z2 = self._lin(ga8 if ga8 is not None else ga, f"w2{l}", bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32,
+                               residual_ln=res1_ln)
             if r32:
                 g2, b2 = v(p + "output.LayerNorm.weight"), v(p + "output.LayerNorm.bias")
                 last16 = self.fwd_f16 and l == cfg.num_hidden_layers - 1  # the head transform's fp16 operand

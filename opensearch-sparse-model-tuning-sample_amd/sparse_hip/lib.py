@@ -41,6 +41,11 @@ class SmEpilogue(C.Structure):
         ("gelu_grad_tiled", C.c_int),  # gelu_grad_of is the tile-major f1 of sm_ffn_pc_fwd
         ("scale_a", C.c_void_p),  # fp8 operands: device scalars, dequantisation scales of A and B
         ("scale_b", C.c_void_p),
+        ("q8", C.c_void_p),  # ABI 6: the result also / only as the next GEMM's fp8 operand (include/sparse_hip.h)
+        ("q8_amax", C.c_void_p),
+        ("q8_scale", C.c_void_p),
+        ("q8_amax_next", C.c_void_p),
+        ("q8_e5m2", C.c_int),
     ]
 
 

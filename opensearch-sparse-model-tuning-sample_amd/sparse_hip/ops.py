@@ -43,29 +43,39 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
             drop: Optional[L.SmDropout] = None, residual: Optional[Tensor] = None,
             gelu_grad_of: Optional[Tensor] = None, out: Optional[Tensor] = None, n: Optional[int] = None,
             out_f32: bool = False, residual_ln=None, gelu_out: Optional[Tensor] = None, gelu_grad_tiled: bool = False,
-            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None) -> Tensor:
+            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None, q8=None, no_out: bool = False):
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T); B may have more than N rows (padded tables).  fp32 residual stream of a
     bf16 run: an fp32 `residual` is added in fp32 and `out_f32` writes the sum as fp32; residual_ln = (mean, rstd, gamma, beta):
     `residual` is the fp32 INPUT of that LayerNorm and its output is recomputed on the fly.  fp16 A / B (SM_F16: forward operands
     of a bf16 run): `preact` must be bf16, `out` is fp16 unless out_f32.  gelu_out (with gelu_grad_of): receives gelu(gelu_grad_of);
     gelu_grad_tiled: gelu_grad_of is the tile-major f1 of ffn_pc_fwd.  fp8 operands (quantize_fp8: A e4m3 or, for an input-gradient
-    GEMM, e5m2; B e4m3; scale_a / scale_b their device-side dequantisation scales): out and every epilogue tensor are bf16."""
+    GEMM, e5m2; B e4m3; scale_a / scale_b their device-side dequantisation scales): out and every epilogue tensor are bf16.
+    q8 = (amax, amax_next, e5m2): the epilogue ALSO writes the result as the fp8 operand of the next GEMM (quantize_fp8's arithmetic on
+    the 16-bit result, scale from *amax, this call's maximum joined into *amax_next) and the return value is (out, q, scale); no_out
+    (with q8): the 16-bit result itself is not written, out is None."""
     M, K = A.shape
     N = B.shape[0] if n is None else n
     fp8 = B.dtype == torch.float8_e4m3fn
     assert B.shape[1] == K and (A.dtype == B.dtype or (fp8 and A.dtype == torch.float8_e5m2))
     assert not fp8 or (scale_a is not None and scale_b is not None)
-    if out is None:
+    assert q8 is not None or not no_out
+    if out is None and not no_out:
         out = _new((M, N), torch.float32 if out_f32 else (torch.bfloat16 if fp8 else A.dtype), A)
+    q = qscale = None
+    if q8 is not None:
+        q = torch.empty((M, N), dtype=torch.float8_e5m2 if q8[2] else torch.float8_e4m3fn, device=A.device)
+        qscale = torch.empty(1, dtype=torch.float32, device=A.device)
     res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
                        L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32),
-                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled), L.ptr(scale_a), L.ptr(scale_b))
+                       *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled), L.ptr(scale_a), L.ptr(scale_b),
+                       L.ptr(q), L.ptr(q8[0]) if q8 is not None else None, L.ptr(qscale), L.ptr(q8[1]) if q8 is not None else None,
+                       int(bool(q8[2])) if q8 is not None else 0)
     assert residual_ln is None or res32, "residual_ln needs an fp32 residual under a bf16 GEMM"
     code = L.SM_FP8_GRAD if A.dtype == torch.float8_e5m2 else L.dtype_code(A.dtype)
     L.call("sm_gemm_nt", code, L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
-           out.stride(0), M, N, K, C.byref(epi), L.stream_ptr())
-    return out
+           out.stride(0) if out is not None else N, M, N, K, C.byref(epi), L.stream_ptr())
+    return out if q8 is None else (out, q, qscale)
 
 
 def gemm_nt_ln_bwd(A: Tensor, B: Tensor, residual: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,

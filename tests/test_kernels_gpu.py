@@ -379,7 +379,7 @@ def test_gemm_tn_group_equals_the_per_matrix_kernel_and_declines_other_shapes(op
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,H", [(37, 64), (130, 384), (9, 768)])
+@pytest.mark.parametrize("rows,H", [(37, 64), (130, 384), (9, 768), (301, 768), (77, 1024)])
 def test_layernorm_fwd_bwd(ops, dtype, rows, H):
     x = q(rnd(rows, H, seed=1) * 2 + 0.3, dtype)
     gamma, beta = 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
@@ -1064,6 +1064,47 @@ def test_gemm_nt_fp8_operands(ops, M, N, K, grad):
         res = torch.randn(M, N, device="cuda", generator=g)
         z = ops.gemm_nt(qa, qb, bias=bias, residual=res, out_f32=True, scale_a=sa, scale_b=sb)
         assert float((z.double() - (wpre + res.double())).abs().max() / (scale + 4)) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,fp8_in", [(4100, 3072, 768, True), (2100, 768, 768, True), (1000, 1152, 384, False), (130, 136, 128, True)])
+@pytest.mark.parametrize("e5m2", [False, True])
+def test_gemm_nt_epilogue_emits_the_next_gemms_fp8_operand(ops, M, N, K, fp8_in, e5m2):
+    """sm_epilogue.q8 (ABI 6): the epilogue writes its result as fp8 with sm_quantize_fp8's arithmetic on the 16-bit value it stores --
+    the SAME bytes, scale and next-step maximum as a separate sm_quantize_fp8 pass over the stored tensor (delayed scaling: the
+    scale comes from an earlier maximum, here half and twice the true one: saturation and head room); with and without the 16-bit
+    output; fp8 and bf16 operands; the FFN-up epilogue (bias + GELU + pre-activation)"""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    kw = {}
+    if fp8_in:
+        qa, sa, _ = ops.quantize_fp8(a)
+        qb, sb, _ = ops.quantize_fp8(b)
+        A, B, kw = qa, qb, dict(scale_a=sa, scale_b=sb)
+    else:
+        A, B = a, b
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ref = ops.gemm_nt(A, B, bias=bias, act=1, preact=pre, **kw)
+    true_max = ref.float().abs().max().reshape(1)
+    for factor in (0.5, 2.0):
+        cur = true_max * factor
+        nxt_ref = torch.full((1,), 0.01, device="cuda")
+        q_ref, s_ref, _ = ops.quantize_fp8(ref, e5m2=e5m2, amax=cur, amax_next=nxt_ref)
+        for no_out in (False, True):
+            nxt = torch.full((1,), 0.01, device="cuda")
+            pre2 = torch.empty_like(pre)
+            out, q, s = ops.gemm_nt(A, B, bias=bias, act=1, preact=pre2, q8=(cur, nxt, e5m2), no_out=no_out, **kw)
+            assert (out is None) == no_out and (no_out or torch.equal(out, ref)) and torch.equal(pre2, pre)
+            assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)), "fp8 bytes differ from a separate quantisation pass"
+            assert float(s) == float(s_ref) and float(nxt) == float(nxt_ref) == float(true_max)
+    # a non-finite value in the result poisons the next step's maximum exactly as the separate pass does
+    bias_bad = bias.clone()
+    bias_bad[3] = float("inf")
+    nxt = torch.zeros(1, device="cuda")
+    ops.gemm_nt(A, B, bias=bias_bad, q8=(true_max, nxt, e5m2), **kw)
+    assert float(nxt) != float(nxt)
 
 
 @pytest.mark.gpu
