@@ -535,7 +535,7 @@ class HipBertMLM(torch.nn.Module):
             self._fp8_cur, self._fp8_next = (torch.zeros(n, dtype=torch.float32, device=device) for _ in range(2))
         return self._fp8_sites.setdefault(key, len(self._fp8_sites))
 
-    def _lin(self, a, key: str, grad: bool = False, emit8: Optional[str] = None, keep16: bool = True, **epi):
+    def _lin(self, a, key: str, grad: bool = False, emit8: Optional[str] = None, keep16: bool = True, emit8_grad: bool = False, **epi):
         """epilogue(a . W^T) for the staged weight `key` of an encoder linear: bf16 / fp32 operands, or (self.fp8) `a` quantised here
         to e4m3 (e5m2 when it is a gradient) against the staged e4m3 weight.  emit8 = the key of the linear that consumes the result
         (fp8 mode with delayed scaling, once that site has a history): the GEMM's epilogue writes the fp8 operand itself -- no
@@ -546,7 +546,7 @@ class HipBertMLM(torch.nn.Module):
         if emit8 is not None and self.fp8 and self._fp8_delayed and self.fp8_emit:
             j = self._fp8_site(emit8, st[key].device)
             if j in self._fp8_ready:
-                q8 = (self._fp8_cur[j:j + 1], self._fp8_next[j:j + 1], False)
+                q8 = (self._fp8_cur[j:j + 1], self._fp8_next[j:j + 1], emit8_grad)  # (a gradient operand is e5m2)
                 epi = dict(epi, q8=q8, no_out=not keep16)
         if isinstance(a, tuple):  # an fp8 operand an earlier epilogue produced: (q, scale)
             aq, sa = a
@@ -1076,11 +1076,13 @@ class _EncodeFn(torch.autograd.Function):
                     df1, ga, dz1, dz1d = fb
                     fused = (dz1, dz1d)
                     wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
+            df18 = None
             if fused is not None:
                 pass
             elif ga is not None:
                 wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                df1 = model._lin(a2, f"w2T{l}", grad=True, gelu_grad_of=f1)
+                # (fp8: dF1 leaves this epilogue in bf16 for the weight gradient AND as the e5m2 operand of the FFN-up input gradient)
+                df1, df18 = model._lin(a2, f"w2T{l}", grad=True, emit8=f"w1T{l}", emit8_grad=True, gelu_grad_of=f1)
             else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
                 ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
                 df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)
@@ -1095,7 +1097,7 @@ class _EncodeFn(torch.autograd.Function):
             if fused is not None:
                 dz1, dz1d = fused
             else:
-                dx1 = model._lin(df1, f"w1T{l}", grad=True, residual=dz2)
+                dx1 = model._lin(df18 if df18 is not None else df1, f"w1T{l}", grad=True, residual=dz2)
                 dz1, dz1d = ops.layernorm_bwd(dx1, z1, v(p + "attention.output.LayerNorm.weight"), m1, r1,
                                               g(p + "attention.output.LayerNorm.weight"),
                                               g(p + "attention.output.LayerNorm.bias"), d_h1, want_drop=d_h1 is not None)
