@@ -1365,15 +1365,16 @@ struct LnBwdArgs {
 // fused head backward (head_dt192_kernel).  `smem` must be idle (no LDS-DMA in flight, every wave past its last read) and
 // hold NB_LDS + 2 * 384 * 4 bytes.  ln.post_gelu_of: the result is additionally multiplied by gelu'(that tensor).
 // LMODE: 0 plain, 1 with ln.dy_drop, 2 with ln.post_gelu_of (compile-time: as run-time branches they cost the plain case 20 spilled registers)
-template <int LMODE>
-__device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_t sbase, int m0, int M, int N, int ldc, bf16* __restrict__ C,
+// RT = 16-row tiles per wave: 6 = the [192 x 384] workgroup tile, 4 = [128 x 384] (gemm_nt192_kernel's second form)
+template <int LMODE, int RT = 6>
+__device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[RT][6], uint32_t sbase, int m0, int M, int N, int ldc, bf16* __restrict__ C,
                                                      const bf16* residual, const LnBwdArgs& ln, int tid, int lane, int w, int wm,
                                                      int wn, int g, int li) {
   // (1) accumulators -> bf16 image dy'[192][384] in the idle ring (exactly NB_LDS bytes); 16-byte chunks are
   //     XOR-swizzled with (row & 7) so that the 16 rows a store instruction covers spread over the banks
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int trow = wm * 96 + i * 16 + li;
+  for (int i = 0; i < RT; ++i) {
+    const int trow = wm * (16 * RT) + i * 16 + li;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int chunk = wn * 12 + j * 2 + (g >> 1);
@@ -1399,8 +1400,8 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
   // unrolled by two: two iterations' global loads in flight (a rolled loop pays the full load latency six times,
   // a fully unrolled one spills)
 #pragma unroll 2
-  for (int it = 0; it < 6; ++it) {
-    const int trow = w * 24 + it * 4 + sub, row = m0 + trow;
+  for (int it = 0; it < RT; ++it) {
+    const int trow = w * (4 * RT) + it * 4 + sub, row = m0 + trow;
     const bool live = row < M;
     bf16x8 raw[3];
 #pragma unroll
@@ -1512,11 +1513,16 @@ __device__ __forceinline__ void ln_bwd_tile_epilogue(f32x4 (&acc)[6][6], uint32_
 }
 
 // F16: A and B hold fp16 (SM_F16; launched only with an fp32 C and no 16-bit epilogue tensor: the FFN-down forward)
-template <bool LNB, int LMODE = 0, bool F16 = false>
+// RT = 6: [192 x 384] tiles; RT = 4: [128 x 384] tiles (wave = 64 x 96), for row counts whose last round of 192-row tiles would leave
+// most of the chip idle (the dense bench batch: 342 tiles on 256 CUs = two rounds of 192 rows; 512 tiles of 128 = two of 128)
+template <bool LNB, int LMODE = 0, bool F16 = false, int RT = 6>
 __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
                                                          bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, LnBwdArgs ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
+  constexpr int NB_R = 32 * RT, WR = 16 * RT;                 // (shadow the 192-row constants) rows per workgroup / per wave
+  constexpr int NB_STAGE = (NB_R + NB_C) * 64;
+  constexpr int NPIECE = 2 * RT + 24, NSLOT = (NPIECE + 7) / 8;  // 1-KiB pieces per stage: 2 RT of A, 24 of B; load slots per wave
   const int NBLK = N / NB_C, MT = (M + NB_R - 1) / NB_R, items = MT * NBLK;
   // XCD-blocked order: the column blocks of a row tile (same A rows) run on one XCD
   int item;
@@ -1532,34 +1538,38 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   const int nk = K / 32;
   const uint32_t sbase = (uint32_t)(uintptr_t)(lds_char*)smem;
 
-  // ---- loader: 12 A pieces + 24 B pieces of 1 KiB (16 rows x 64 B) per stage, 5 slots per wave (4 duplicates) ----
-  const bf16* src[5];
-  uint32_t dst[5];
+  // ---- loader: 2 RT A pieces + 24 B pieces of 1 KiB (16 rows x 64 B) per stage, NSLOT slots per wave (RT = 6: 5 slots, 4 duplicates) ----
+  const bf16* src[NSLOT];
+  uint32_t dst[NSLOT];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) {
-    const int piece = min(w + 8 * u, 35);
-    const int prow = (piece < 12 ? piece : piece - 12) * 16 + (lane >> 2);
+  for (int u = 0; u < NSLOT; ++u) {
+    const int piece = min(w + 8 * u, NPIECE - 1);
+    const int prow = (piece < 2 * RT ? piece : piece - 2 * RT) * 16 + (lane >> 2);
     const int lchunk = (lane & 3) ^ ((0 - (prow >> 2)) & 3);
-    src[u] = piece < 12 ? A + (size_t)min(m0 + prow, M - 1) * lda + lchunk * 8 : B + (size_t)(n0 + prow) * ldb + lchunk * 8;
+    src[u] = piece < 2 * RT ? A + (size_t)min(m0 + prow, M - 1) * lda + lchunk * 8 : B + (size_t)(n0 + prow) * ldb + lchunk * 8;
     dst[u] = piece * 1024;
   }
   auto issue = [&](int k) {
     const int kc = min(k, nk - 1);
     char* d = smem + (k % NB_NST) * NB_STAGE;
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < NSLOT; ++u)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[u] + kc * 32), (lds_void_t*)(d + dst[u]), 16, 0, 0);
   };
-  uint32_t aaddr[6], baddr[6];
+  uint32_t aaddr[RT], baddr[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int ra = wm * 96 + i * 16 + li, rb = wn * 96 + i * 16 + li;
-    aaddr[i] = sbase + ra * 64 + ((g ^ ((0 - (ra >> 2)) & 3)) << 4);
+    const int rb = wn * 96 + i * 16 + li;
     baddr[i] = sbase + NB_R * 64 + rb * 64 + ((g ^ ((0 - (rb >> 2)) & 3)) << 4);
   }
-  f32x4 acc[6][6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < RT; ++i) {
+    const int ra = wm * WR + i * 16 + li;
+    aaddr[i] = sbase + ra * 64 + ((g ^ ((0 - (ra >> 2)) & 3)) << 4);
+  }
+  f32x4 acc[RT][6];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1567,7 +1577,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   issue(1);
   issue(2);
   for (int k = 0; k < nk; ++k) {
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // stage k landed: only stages k+1, k+2 (5 loads each) may be in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSLOT) : "memory");  // stage k landed: only stages k+1, k+2 (NSLOT loads each) may be in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // the slot of stage k+3 held stage k-1, drained by every wave before the barrier.  Waves 0-3 issue their
@@ -1575,20 +1585,26 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
     // LDS-DMA at once and then fighting for the matrix pipe at once serialises the two phases
     if (w < 4) issue(k + 3);
     const uint32_t so = (uint32_t)((k % NB_NST) * NB_STAGE);
-    bf16x8 fa[6], fb[6];
+    bf16x8 fa[6], fb[6];  // (RT = 4: fa[4], fa[5] stay unused)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) fa[i] = lds_b128(aaddr[i] + so);
+    for (int i = 0; i < RT; ++i) fa[i] = lds_b128(aaddr[i] + so);
 #pragma unroll
     for (int j = 0; j < 6; ++j) fb[j] = lds_b128(baddr[j] + so);
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
-                   "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5])
-                 :
-                 : "memory");
+    if constexpr (RT == 6)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]),
+                     "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5])
+                   :
+                   : "memory");
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < RT; ++i) {
         if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[i]), acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
       }
@@ -1607,14 +1623,14 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
   const uint32_t patch = sbase + w * (16 * NB_PS * 4);
   const int prow = lane >> 2, pc = (lane & 3) * 8;  // patch row / first column (within each 32-column third) of this lane
   if constexpr (LNB) {
-    ln_bwd_tile_epilogue<LMODE>(acc, sbase, m0, M, N, ldc, C, residual, ln, tid, lane, w, wm, wn, g, li);
+    ln_bwd_tile_epilogue<LMODE, RT>(acc, sbase, m0, M, N, ldc, C, residual, ln, tid, lane, w, wm, wn, g, li);
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < RT; ++i) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) lds_w128f(patch + (li * NB_PS + j * 16 + 4 * g) * 4, acc[i][j]);
-    const int row = m0 + wm * 96 + i * 16 + prow;
+    const int row = m0 + wm * WR + i * 16 + prow;
     f32x4 lo[3], hi[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -1682,6 +1698,15 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
                     const void* f1_tiled, void* ga, hipStream_t st);  // gemm_ws.hip
 namespace {
 
+// rows per workgroup tile of gemm_nt192_kernel: 128 when rounds x height is lower that way by more than the smaller tile's lower
+// arithmetic intensity costs (dense bench batch, 65 536 rows: 2 rounds x 128 against 2 x 192; ragged, 43 904 rows: 192 in one round)
+int nt192_tile_rows(long M, int nblk) {
+  auto cost = [&](int h) { return (double)(((long)sm_cdiv(M, h) * nblk + 255) / 256) * h; };
+  static const int forced = [] { const char* e = getenv("SM_NT192_ROWS"); return e ? atoi(e) : 0; }();
+  if (forced == 128 || forced == 192) return forced;
+  return cost(128) * 1.08 < cost(192) ? 128 : 192;
+}
+
 // sm_epilogue.q8*: checked and copied (the other launchers leave e.q8 null)
 int epi_q8(EpiArgs& e, const sm_epilogue* epi, const void* C, int N, bool types_ok) {
   e.q8 = epi ? (uint8_t*)epi->q8 : nullptr;
@@ -1739,8 +1764,10 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 512) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
     if (nt192 && !e.q8 && nt192_shape && nt192_types_ok && K >= nt192_mink && K % 32 == 0 && e.vec_ok && ((uintptr_t)e.bias % 16 == 0) && M >= 32 * NB_R) {
-      const int items = sm_cdiv(M, NB_R) * (N / NB_C);
-      auto kern = is_f16 ? gemm_nt192_kernel<false, 0, true> : gemm_nt192_kernel<false, 0, false>;
+      const int trows = nt192_tile_rows(M, N / NB_C);
+      const int items = sm_cdiv(M, trows) * (N / NB_C);
+      auto kern = trows == 128 ? (is_f16 ? gemm_nt192_kernel<false, 0, true, 4> : gemm_nt192_kernel<false, 0, false, 4>)
+                               : (is_f16 ? gemm_nt192_kernel<false, 0, true> : gemm_nt192_kernel<false, 0, false>);
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NB_LDS);
       hipLaunchKernelGGL(kern, dim3((items + 7) / 8 * 8), dim3(512), NB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                          M, N, K, e, LnBwdArgs{});
@@ -1925,9 +1952,11 @@ extern "C" int sm_gemm_nt_ln_bwd(int dtype, const void* A, int lda, const void* 
   ln.dy_drop = make_drop(dy_drop);
   ln.post_gelu_of = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int items = sm_cdiv(M, NB_R);
+  const int trows = nt192_tile_rows(M, 1);
+  const int items = sm_cdiv(M, trows);
   constexpr int LNB_LDS = NB_LDS + 2 * NB_C * 4;  // + the [2][384] column-sum patch
-  auto kern = ln.dy_drop.thresh16 ? gemm_nt192_kernel<true, 1> : gemm_nt192_kernel<true, 0>;
+  auto kern = trows == 128 ? (ln.dy_drop.thresh16 ? gemm_nt192_kernel<true, 1, false, 4> : gemm_nt192_kernel<true, 0, false, 4>)
+                           : (ln.dy_drop.thresh16 ? gemm_nt192_kernel<true, 1> : gemm_nt192_kernel<true, 0>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LNB_LDS));
   hipLaunchKernelGGL(kern, dim3((items + 7) / 8 * 8), dim3(512), LNB_LDS, st, (const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)dx, N, M, N, K, e, ln);
   SM_LAUNCH_CHECK();

@@ -120,7 +120,8 @@ def test_gemm_nt_fused_with_layernorm_backward_matches_the_two_separate_kernels(
     gemm_nt followed by layernorm_bwd, and against torch autograd in fp32"""
     from sparse_hip import lib
     dtype = torch.bfloat16
-    for M, K in ((6200, 1024), (6151, 1536), (6160, 384)):
+    # (6 k rows: one round of [128 x 384] tiles; 43 904 rows, the ragged bench batch: one round of [192 x 384] tiles; 65 536: two of 128)
+    for M, K in ((6200, 1024), (6151, 1536), (6160, 384), (43904, 1536), (65536, 1152)):
         N = 384
         A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.05), dtype)
         res, x = q(rnd(M, N, seed=3), dtype), q(rnd(M, N, seed=4, scale=2.0), dtype)
