@@ -112,10 +112,13 @@ typedef struct sm_epilogue {
   float* q8_scale;
   float* q8_amax_next;
   int q8_e5m2;
+  float* q8_partials;       /* with q8_amax_next: sm_gemm_nt_q8_partials(M, N) floats of scratch (per-tile maxima, joined by a small
+                               launch behind the GEMM: thousands of atomics on one address would cost more than the pass they replace) */
 } sm_epilogue;
 
 int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                int M, int N, int K, const sm_epilogue* epi, void* stream);
+int sm_gemm_nt_q8_partials(int M, int N); /* floats sm_epilogue.q8_partials must hold */
 
 /* Per-tensor fp8 quantisation, just in time and without a host round trip:
  *   sm_amax:          *amax = max(*amax, max |x[i]|)            (the caller zeroes *amax first; dtype SM_BF16 or SM_F32)

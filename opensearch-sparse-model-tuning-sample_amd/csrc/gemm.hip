@@ -433,6 +433,7 @@ struct EpiArgs {
   float* q8_scale;
   float* q8_amax_next;
   int q8_e5m2;
+  float* q8_partials;  // one maximum per workgroup tile, joined into *q8_amax_next by amax_partials_kernel behind the GEMM
 };
 
 // gelu_grad_of as the producer / consumer feed-forward kernel leaves it (csrc/ffn_pc.hip, include/sparse_hip.h): tiles of 32 rows x
@@ -628,16 +629,28 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const OP* __restrict_
     }
     NT_STAMP(2 + half);
   }
-  if (e.q8 && e.q8_amax_next != nullptr) {  // this tile's maximum for the next step's scale: one atomic per wave, and only when it raises the value
+  if (e.q8 && e.q8_amax_next != nullptr) {
+    // this tile's maximum for the next step's scale: into the tile's own slot (14 k tiles x 4 waves of atomics on ONE address cost
+    // the FFN-width GEMMs 0.07-0.47 ms each); amax_partials_kernel joins the slots behind the GEMM
     float m = amax_final(q8_seen, q8_bad);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = amax_join(m, __shfl_xor(m, o));
-    if (lane == 0) {
-      const unsigned int mb = __float_as_uint(m);  // non-negative floats order like their bit patterns (NaN above all of them)
-      if (mb > __hip_atomic_load(reinterpret_cast<unsigned int*>(e.q8_amax_next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<unsigned int*>(e.q8_amax_next), mb);
-    }
+    float* const slot = e.q8_partials + (size_t)(mt * gridDim.x + nt) * (WM * 2);
+    if (lane == 0) slot[w] = m;
   }
+}
+
+// joins the per-wave maxima a q8 epilogue left (non-negative floats and the NaN pattern order like their bits)
+__global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ amax_next) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = amax_join(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = amax_join(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned int*>(amax_next), __float_as_uint(amax_join(amax_join(wm[0], wm[1]), amax_join(wm[2], wm[3]))));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1707,6 +1720,9 @@ int nt192_tile_rows(long M, int nblk) {
   return cost(128) * 1.08 < cost(192) ? 128 : 192;
 }
 
+// floats of sm_epilogue.q8_partials: one per wave of every [128 x 128] tile (each tile writes its four: nothing to zero)
+int q8_partials_count(int M, int N) { return sm_cdiv(M, BM) * sm_cdiv(N, BN) * 4; }
+
 // sm_epilogue.q8*: checked and copied (the other launchers leave e.q8 null)
 int epi_q8(EpiArgs& e, const sm_epilogue* epi, const void* C, int N, bool types_ok) {
   e.q8 = epi ? (uint8_t*)epi->q8 : nullptr;
@@ -1714,8 +1730,10 @@ int epi_q8(EpiArgs& e, const sm_epilogue* epi, const void* C, int N, bool types_
   e.q8_scale = epi ? epi->q8_scale : nullptr;
   e.q8_amax_next = epi ? epi->q8_amax_next : nullptr;
   e.q8_e5m2 = epi ? epi->q8_e5m2 : 0;
+  e.q8_partials = epi ? epi->q8_partials : nullptr;
   SM_REQUIRE(C != nullptr || e.q8 != nullptr, "sm_gemm_nt: C is NULL and there is no q8 output either");
   if (e.q8 == nullptr) return 0;
+  SM_REQUIRE(e.q8_amax_next == nullptr || e.q8_partials != nullptr, "sm_gemm_nt: q8_amax_next needs q8_partials (sm_gemm_nt_q8_partials floats)");
   SM_REQUIRE(types_ok, "sm_gemm_nt: q8 needs a 16-bit result type (no out_f32)");
   SM_REQUIRE(e.q8_amax && e.q8_scale, "sm_gemm_nt: q8 needs q8_amax (the scale's source) and q8_scale");
   SM_REQUIRE(e.vec_ok && N % 8 == 0 && ((uintptr_t)e.q8 % 8) == 0, "sm_gemm_nt: q8 needs N %% 8 == 0, ldc %% 8 == 0 and aligned tensors");
@@ -1808,6 +1826,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   else
     hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(NTHREADS), 4 * TILE_BYTES, st, (const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, M,
                        N, K, e);
+  if (e.q8 && e.q8_amax_next) hipLaunchKernelGGL(amax_partials_kernel, dim3(1), dim3(256), 0, st, e.q8_partials, q8_partials_count(M, N), e.q8_amax_next);
   return 0;
 }
 
@@ -1890,6 +1909,7 @@ int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, 
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 2 * 3 * GL_STAGE, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
                      K, e);
+  if (e.q8 && e.q8_amax_next) hipLaunchKernelGGL(amax_partials_kernel, dim3(1), dim3(256), 0, st, e.q8_partials, q8_partials_count(M, N), e.q8_amax_next);
   return 0;
 }
 
@@ -1898,6 +1918,8 @@ int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, 
 #ifdef NT_STAMPS
 extern "C" int sm_nt_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nt_stamps), sizeof(nt_stamps)); }
 #endif
+
+extern "C" int sm_gemm_nt_q8_partials(int M, int N) { return q8_partials_count(M, N); }
 
 extern "C" int sm_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                           int K, const sm_epilogue* epi, void* stream) {

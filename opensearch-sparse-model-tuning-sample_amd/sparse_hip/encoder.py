@@ -192,7 +192,7 @@ KERNEL_OPTIONS = {
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
     "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
-    "fp8_emit": ("SM_FP8_EMIT", True, bool),                  # fp8 mode: the FFN-up epilogue writes the FFN-down's e4m3 operand itself (no quantisation pass)
+    "fp8_emit": ("SM_FP8_EMIT", False, bool),                 # fp8 mode: the FFN-width GEMM epilogues write the next GEMM's fp8 operand themselves (byte-identical; measured +-0 on configs[4]: opt-in)
     "tn_group": ("SM_TN_GROUP", True, bool),
     "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph

@@ -46,6 +46,7 @@ class SmEpilogue(C.Structure):
         ("q8_scale", C.c_void_p),
         ("q8_amax_next", C.c_void_p),
         ("q8_e5m2", C.c_int),
+        ("q8_partials", C.c_void_p),
     ]
 
 
@@ -96,6 +97,7 @@ SIGNATURES = {
     "sm_sparse_head_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_sparse_head_bwd_dt_ln": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p, _p, _p, _p, _p, _p, _p, _i, _p, _l, _p],
     "sm_sparse_head_bwd_dt_ws_bytes": [],
+    "sm_gemm_nt_q8_partials": [_i, _i],
     "sm_sparse_head_bwd_dt_scatter": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _rag, _p],
     "sm_inf_free_fwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p],
     "sm_inf_free_bwd": [_p, _i, _i, _p, _p, _i, _i, _p, _p, _p],

@@ -64,13 +64,15 @@ def gemm_nt(A: Tensor, B: Tensor, bias: Optional[Tensor] = None, act: int = 0, p
     q = qscale = None
     if q8 is not None:
         q = torch.empty((M, N), dtype=torch.float8_e5m2 if q8[2] else torch.float8_e4m3fn, device=A.device)
-        qscale = torch.empty(1, dtype=torch.float32, device=A.device)
+        npart = int(L.load().sm_gemm_nt_q8_partials(M, N)) if q8[1] is not None else 0
+        qbuf = torch.empty(1 + npart, dtype=torch.float32, device=A.device)  # [0]: the dequantisation scale; the rest: per-tile maxima (scratch)
+        qscale = qbuf[:1]
     res32 = residual is not None and residual.dtype == torch.float32 and A.dtype != torch.float32
     epi = L.SmEpilogue(L.ptr(bias), int(act), L.ptr(preact), drop if drop is not None else L.dropout(),
                        L.ptr(residual), L.ptr(gelu_grad_of), int(res32), int(out_f32 and A.dtype != torch.float32),
                        *([L.ptr(t) for t in residual_ln] if residual_ln is not None else [None] * 4), L.ptr(gelu_out), int(gelu_grad_tiled), L.ptr(scale_a), L.ptr(scale_b),
                        L.ptr(q), L.ptr(q8[0]) if q8 is not None else None, L.ptr(qscale), L.ptr(q8[1]) if q8 is not None else None,
-                       int(bool(q8[2])) if q8 is not None else 0)
+                       int(bool(q8[2])) if q8 is not None else 0, L.ptr(qbuf[1:]) if q8 is not None and npart else None)
     assert residual_ln is None or res32, "residual_ln needs an fp32 residual under a bf16 GEMM"
     code = L.SM_FP8_GRAD if A.dtype == torch.float8_e5m2 else L.dtype_code(A.dtype)
     L.call("sm_gemm_nt", code, L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),

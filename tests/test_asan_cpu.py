@@ -40,7 +40,8 @@ run("sm_gemm_nt", L.SM_BF16, P(10), H, P(11), H, P(12), I, T, I, H, C.byref(epi2
 run("sm_gemm_nt", L.SM_F32, P(10), 72, P(11), 72, P(12), 136, 300, 136, 64, None, None)
 # fp8 operands, the epilogue emits the next GEMM's fp8 operand and no 16-bit C (ABI 6: the q8 fields at the end of sm_epilogue)
 epi3 = L.SmEpilogue(P(1).value, 1, P(2).value, nodrop, None, None, 0, 0, None, None, None, None, None, 0, P(3).value, P(4).value,
-                    P(5).value, P(6).value, P(7).value, P(8).value, 0)
+                    P(5).value, P(6).value, P(7).value, P(8).value, 0, P(9).value)
+assert lib.sm_gemm_nt_q8_partials(T, 3072) == (T // 128) * 24 * 4
 run("sm_gemm_nt", L.SM_FP8, P(10), 768, P(11), 768, None, 3072, T, 3072, 768, C.byref(epi3), None)
 run("sm_gemm_nt_ln_bwd", L.SM_BF16, P(10), I, P(11), I, T, H, I, P(12), P(13), P(14), P(15), P(16), C.byref(drop), P(17), P(18), P(19), P(20), 1, None, None)
 run("sm_gemm_tn_acc", L.SM_BF16, P(10), H, P(11), I, P(12), I, T, H, I, P(13), None)
