@@ -1777,7 +1777,7 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   // fp16 operands: the 192 x 384 kernel's epilogue types its 16-bit tensors bf16, so it takes fp16 only when there is none
   const bool nt192_types_ok = !is_f16 || (e.out32 && !e.preact && !e.gelu_grad_of && (!e.residual || e.res32));
   if constexpr (sizeof(T) == 2) {
-    constexpr int nt192_mink = 768;  // (bert-base: K = 768 through the 192 x 384 tile, measured on the configs[4] shape)
+    static const int nt192_mink = [] { const char* e = getenv("SM_NT192_MINK"); return e ? atoi(e) : 768; }();  // (bert-base: K = 768 through the 192 x 384 tile, measured on the configs[4] shape)
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 512) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
