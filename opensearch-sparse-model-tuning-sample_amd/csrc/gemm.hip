@@ -1777,7 +1777,10 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
   // fp16 operands: the 192 x 384 kernel's epilogue types its 16-bit tensors bf16, so it takes fp16 only when there is none
   const bool nt192_types_ok = !is_f16 || (e.out32 && !e.preact && !e.gelu_grad_of && (!e.residual || e.res32));
   if constexpr (sizeof(T) == 2) {
-    static const int nt192_mink = [] { const char* e = getenv("SM_NT192_MINK"); return e ? atoi(e) : 768; }();  // (bert-base: K = 768 through the 192 x 384 tile, measured on the configs[4] shape)
+    // (bert-base: K = 768 through the 192 x 384 tile, measured on the configs[4] shape.  Round 5, with the [128 x 384] form: the K = 384
+    // forward GEMMs of the bench step through it are +0.22 ms per dense step, same-box A/B -- three [128 x 128] workgroups per CU cover
+    // each other's epilogues, one 8-wave workgroup does not)
+    constexpr int nt192_mink = 768;
     constexpr int nt192_multi = 1;  // also N = 768, 1152, ... when there are >= 2 rounds of tiles (bert-base: -3 % per step)
     const long nt192_items = (long)sm_cdiv(M, NB_R) * (N / NB_C);
     const bool nt192_shape = (N == NB_C && nt192_items <= 512) || (nt192_multi && N % NB_C == 0 && nt192_items >= 512);
