@@ -431,14 +431,17 @@ def test_c2_slice_gradient_caching_at_hidden_384_replays_the_first_pass():
     assert all(torch.equal(seen[i], seen[4 + i]) for i in range(4)), "pass 2 of a chunk must reproduce pass 1 bit for bit"
 
 
-@pytest.mark.parametrize("pc_ffn_bwd,wgrad_stream,tn_group,tn_pair", [(0, 1, 1, 1), (1, 0, 1, 0), (0, 0, 0, 1), (1, 1, 0, 0), (1, 1, 1, 0)])
-def test_c2_slice_kernel_option_combinations_with_dropout_on(pc_ffn_bwd, wgrad_stream, tn_group, tn_pair):
+@pytest.mark.parametrize("pc_ffn_bwd,wgrad_stream,tn_group,tn_pair,ffn_f16", [(0, 1, 1, 1, 1), (1, 0, 1, 0, 1), (0, 0, 0, 1, 1), (1, 1, 0, 0, 1), (1, 1, 1, 0, 1),
+                                                                               (1, 1, 1, 1, 0), (0, 0, 1, 1, 0)])
+def test_c2_slice_kernel_option_combinations_with_dropout_on(pc_ffn_bwd, wgrad_stream, tn_group, tn_pair, ffn_f16):
     """the NON-default kernel selections of HipBertMLM (sparse_hip.encoder.KERNEL_OPTIONS) against the oracle, hidden dropout on: the
     unfused feed-forward backward, weight gradients on the main queue, one launch per weight gradient instead of the grouped kernel
-    -- every combination is a supported configuration and must hold the same bounds as the default"""
+    -- and bf16 instead of fp16 operands inside the fused feed-forward forward (ffn_f16 = 0) -- every combination is a supported
+    configuration and must hold the same bounds as the default"""
     _student_step(MINI, torch.bfloat16, nq=4, k=16, S=128, Sq=32, recipe=INFONCE, seed=12, hidden_dropout=0.1,
-                  what=f"c2 slice, pc_ffn_bwd={pc_ffn_bwd} wgrad_stream={wgrad_stream} tn_group={tn_group} tn_pair={tn_pair}",
-                  kernel_options={"pc_ffn_bwd": bool(pc_ffn_bwd), "wgrad_stream": bool(wgrad_stream), "tn_group": bool(tn_group), "tn_pair": bool(tn_pair)})
+                  what=f"c2 slice, pc_ffn_bwd={pc_ffn_bwd} wgrad_stream={wgrad_stream} tn_group={tn_group} tn_pair={tn_pair} ffn_f16={ffn_f16}",
+                  kernel_options={"pc_ffn_bwd": bool(pc_ffn_bwd), "wgrad_stream": bool(wgrad_stream), "tn_group": bool(tn_group), "tn_pair": bool(tn_pair),
+                                  "ffn_f16": bool(ffn_f16)})
 
 
 @pytest.mark.parametrize("varlen", [True, False])
