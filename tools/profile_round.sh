@@ -10,7 +10,7 @@ out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 B="bench.py --steps 2 --warmup 1 --only-value-layout --no-cpu-baseline --no-gemm-roofline --no-extras"
 timeout 900 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --only-value-layout --no-cpu-baseline --no-extras > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --only-value-layout --no-cpu-baseline --no-extras --no-gemm-roofline > $out/stats.log 2>&1   # (--no-gemm-roofline: its HIP events around every GEMM launch are marker packets, ~0.5 ms of main-queue gaps per step that the timed steps of the bench do not have)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- python3 $B > $out/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3 $B > $out/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
