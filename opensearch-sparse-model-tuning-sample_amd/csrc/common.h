@@ -202,6 +202,13 @@ static inline DropCfg make_drop(const sm_dropout* s) {
   return d;
 }
 
+// the fp32-residual epilogue of the weight-stationary GEMM (csrc/gemm_ws.hip, EPI 2), filled in by gemm.hip's launcher
+struct WsResidual {
+  const float* residual;  // [M, N] fp32
+  const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;  // all four or none: residual = LayerNorm(residual) recomputed
+  DropCfg drop;
+};
+
 // ---- fp8 quantisation pieces shared by csrc/fp8.hip and the GEMM epilogue that emits fp8 itself (csrc/gemm.hip) ----
 // running maximum of |v| that REMEMBERS a NaN / Inf: fmaxf drops a NaN operand, so a tensor that went non-finite would be
 // quantised against the maximum of its finite part and come out finite (saturated) -- the non-finite value laundered away.  A

@@ -1708,7 +1708,7 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
 
 }  // namespace
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                    const void* f1_tiled, void* ga, hipStream_t st);  // gemm_ws.hip
+                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res = nullptr);  // gemm_ws.hip
 namespace {
 
 // rows per workgroup tile of gemm_nt192_kernel: 128 when rounds x height is lower that way by more than the smaller tile's lower
@@ -1803,6 +1803,11 @@ int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int 
     if (plain && !e.q8 && (epi0 || epi1) &&
         sm_gemm_ws_try(SM_BF16, A, lda, B, ldb, C, ldc, M, N, K, e.bias, epi1 ? e.gelu_grad_of : nullptr, e.gelu_out, st))
       return 0;
+    // ... and the attention-output projection of the fp32 residual stream: bias, dropout, + fp32 residual (or its LayerNorm, recomputed), fp32 out
+    if (!e.q8 && !e.act && !e.preact && e.residual && e.res32 && e.out32 && epi0 && e.vec_ok) {
+      WsResidual r{(const float*)e.residual, e.rl_mean, e.rl_rstd, e.rl_gamma, e.rl_beta, e.drop};
+      if (sm_gemm_ws_try(SM_BF16, A, lda, B, ldb, C, ldc, M, N, K, e.bias, nullptr, nullptr, st, &r)) return 0;
+    }
   }
   if constexpr (sizeof(T) == 2) {
     // 256 x 128 tiles (8 waves), a BUILD option (-DSM_NT256=1; the library reads no environment): measured SLOWER than the 128 x 128 tile where it was expected to pay

@@ -80,9 +80,15 @@ struct WsArgs {
   const bf16* f1;       // EPI 1: tile-major f1 (include/sparse_hip.h, sm_ffn_pc_fwd)
   bf16* ga;             // EPI 1: gelu(f1), [M, N] bf16 (may be null)
   int M, N, rsplit;     // rsplit: row ranges (grid = (N / 128) * rsplit workgroups)
+  // EPI 2 (the attention-output projection of the fp32 residual stream): C32 = dropout(acc + bias) + residual, where the residual is
+  // res32 itself or, with rl_mean, LayerNorm(res32; mean, rstd, gamma, beta) recomputed on the fly (gemm.hip's epilogue, same arithmetic)
+  float* C32;           // [M, N] fp32
+  const float* res32;   // [M, N] fp32
+  const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;
+  DropCfg drop;
 };
 
-// EPI 0: C = acc + bias.  EPI 1: C = acc * gelu'(f1), ga = gelu(f1) (the fused forward's sigmoid-form GELU)
+// EPI 0: C = acc + bias.  EPI 1: C = acc * gelu'(f1), ga = gelu(f1) (the fused forward's sigmoid-form GELU).  EPI 2: see WsArgs
 template <bool F16, int EPI>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
   constexpr int KS = WS_KS, NST = WS_NST, D = WS_D, BAR_KS = WS_BAR_KS;
@@ -110,7 +116,29 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
     const int col = n0 + cg * 8;
     float bv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bv[k] = (EPI == 0 && a.bias) ? a.bias[col + k] : 0.f;
+    for (int k = 0; k < 8; ++k) bv[k] = (EPI != 1 && a.bias) ? a.bias[col + k] : 0.f;
+    // EPI 2: this lane's eight columns of the LayerNorm parameters, and the residual words / row statistics of the step processed
+    // NEXT (fetched one barrier early, like f1 below)
+    float lg[8], lb[8];
+    f32x4 rsn[4][2];
+    float mun[4], rstn[4];
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { lg[k] = a.rl_mean ? a.rl_gamma[col + k] : 1.f; lb[k] = a.rl_mean ? a.rl_beta[col + k] : 0.f; }
+    }
+    auto res_fetch = [&](int s) __attribute__((always_inline)) {
+      if constexpr (EPI == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int row = min(row_base + s * 32 + sw * 16 + p * 4 + rq, a.M - 1);
+          const float* q = a.res32 + (size_t)row * a.N + col;
+          rsn[p][0] = *reinterpret_cast<const f32x4*>(q);
+          rsn[p][1] = *reinterpret_cast<const f32x4*>(q + 4);
+          mun[p] = a.rl_mean ? a.rl_mean[row] : 0.f;
+          rstn[p] = a.rl_mean ? a.rl_rstd[row] : 1.f;
+        }
+      }
+    };
     typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
     u16x4 f1n[4][2];  // EPI 1: the f1 words of the step processed NEXT (fetched one barrier early)
     auto f1_fetch = [&](int s) __attribute__((always_inline)) {
@@ -144,12 +172,33 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
         for (int p = 0; p < 4; ++p) { f1c[p][0] = f1n[p][0]; f1c[p][1] = f1n[p][1]; }
         if (s + 1 < nsteps) f1_fetch(s + 1);
       }
+      f32x4 rsc[4][2];
+      float muc[4], rstc[4];
+      if constexpr (EPI == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { rsc[p][0] = rsn[p][0]; rsc[p][1] = rsn[p][1]; muc[p] = mun[p]; rstc[p] = rstn[p]; }
+        if (s + 1 < nsteps) res_fetch(s + 1);
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = row_base + s * 32 + sw * 16 + p * 4 + rq;
         float v[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[k] = lo[p][k] + bv[k]; v[4 + k] = hi[p][k] + bv[4 + k]; }
+        if constexpr (EPI == 2) {
+          if (a.drop.thresh16) drop_apply8(a.drop, (uint64_t)row * (uint64_t)a.N + col, v);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float r = k < 4 ? rsc[p][0][k] : rsc[p][1][k - 4];
+            v[k] += a.rl_mean ? (r - muc[p]) * rstc[p] * lg[k] + lb[k] : r;
+          }
+          if (row < a.M) {
+            float* q = a.C32 + (size_t)row * a.N + col;
+            *reinterpret_cast<f32x4*>(q) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(q + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+          continue;
+        }
         bf16x8 o, g;
         if constexpr (EPI == 1) {
 #pragma unroll
@@ -174,6 +223,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
       }
     };
     f1_fetch(0);
+    res_fetch(0);
     for (int t = 0; t < nsteps + 2; ++t) {
       __builtin_amdgcn_s_barrier();  // B_t
       asm volatile("" ::: "memory");
@@ -356,14 +406,19 @@ extern "C" int sm_ws_debug_stamps(unsigned long long* host) { return (int)hipMem
 
 // false: shape not taken (the caller runs the 128 x 128 kernel)
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                    const void* f1_tiled, void* ga, hipStream_t st) {
+                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res) {
 #ifdef SM_WS_DISABLE  // (A/B builds of tools/: the 128 x 128 kernel everywhere)
   return false;
 #endif
   if ((dtype != SM_BF16 && dtype != SM_F16) || K != WS_H || lda != WS_H || ldb != WS_H || ldc != N || N % 128 != 0 || M < 8192) return false;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)f1_tiled | (uintptr_t)ga) % 16) return false;
   if (dtype == SM_F16 && f1_tiled) return false;
-  WsArgs a;
+  if (res != nullptr) {
+    static const bool off = [] { const char* e = getenv("SM_WS_RESIDUAL"); return e != nullptr && e[0] == '0'; }();
+    if (off || dtype != SM_BF16 || f1_tiled || res->residual == nullptr) return false;
+    if (((uintptr_t)res->residual | (uintptr_t)res->rl_gamma | (uintptr_t)res->rl_beta) % 16) return false;
+  }
+  WsArgs a{};
   a.A = (const bf16*)A;
   a.W = (const bf16*)W;
   a.C = (bf16*)C;
@@ -385,7 +440,17 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess) return false; \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WS_LDS, st, a);                                                     \
   } while (0)
-  if (f1_tiled) WS_GO(false, 1);
+  if (res != nullptr) {
+    a.C = nullptr;
+    a.C32 = (float*)C;
+    a.res32 = res->residual;
+    a.rl_mean = res->rl_mean;
+    a.rl_rstd = res->rl_rstd;
+    a.rl_gamma = res->rl_gamma;
+    a.rl_beta = res->rl_beta;
+    a.drop = res->drop;
+    WS_GO(false, 2);
+  } else if (f1_tiled) WS_GO(false, 1);
   else if (dtype == SM_F16) return false;  // (no fp16-operand caller at K = 384 with a plain epilogue)
   else WS_GO(false, 0);
 #undef WS_GO

@@ -35,6 +35,9 @@ def run(name, *args, expect_launch=True):
     print(name, rc, msg[:90])
 epi = L.SmEpilogue(P(1).value, 1, P(2).value, drop, P(3).value, None, 1, 1, P(4).value, P(5).value, P(6).value, P(7).value, None, 0, None, None)
 run("sm_gemm_nt", L.SM_BF16, P(10), H, P(11), H, P(12), H, T, H, H, C.byref(epi), None)
+# the attention-output projection of the fp32 residual stream: weight-stationary kernel, fp32-residual epilogue (gemm_ws.hip EPI 2)
+epi_o = L.SmEpilogue(P(1).value, 0, None, drop, P(3).value, None, 1, 1, P(4).value, P(5).value, P(6).value, P(7).value, None, 0, None, None)
+run("sm_gemm_nt", L.SM_BF16, P(10), H, P(11), H, P(12), H, T, H, H, C.byref(epi_o), None)
 epi2 = L.SmEpilogue(None, 0, None, nodrop, None, P(3).value, 0, 0, None, None, None, None, P(4).value, 1, None, None)
 run("sm_gemm_nt", L.SM_BF16, P(10), H, P(11), H, P(12), I, T, I, H, C.byref(epi2), None)       # weight-stationary, dF1 epilogue
 run("sm_gemm_nt", L.SM_F32, P(10), 72, P(11), 72, P(12), 136, 300, 136, 64, None, None)

@@ -181,6 +181,39 @@ def test_gemm_nt_residual_recomputed_from_the_layernorm_input(ops):
         assert got.dtype == torch.float32 and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), (M, K)
 
 
+@pytest.mark.parametrize("M", [8192, 8300, 43904])
+@pytest.mark.parametrize("with_ln", [False, True])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gemm_nt_fp32_residual_epilogue_of_the_weight_stationary_kernel(ops, M, with_ln, p):
+    """the attention-output projection of the fp32 residual stream at K = 384 and >= 8192 rows runs in the weight-stationary kernel
+    (gemm_ws.hip, EPI 2): fp32 out = dropout(A.W^T + bias) + residual, the residual being the fp32 tensor itself or LayerNorm of it
+    recomputed from (mean, rstd, gamma, beta).  Against fp32 torch on the same bf16 operands with the dropout mask the backward
+    kernels regenerate (sm_dropout_bwd on ones); a row count that ends inside a 32-row step"""
+    from sparse_hip import lib
+    dtype = torch.bfloat16
+    N = K = 384
+    A, B = q(rnd(M, K, seed=1, scale=0.5), dtype), q(rnd(N, K, seed=2, scale=0.05), dtype)
+    z = rnd(M, N, seed=3, scale=1.5) + 0.2
+    gamma, beta, bias = 1.0 + 0.1 * rnd(N, seed=4), 0.1 * rnd(N, seed=5), 0.1 * rnd(N, seed=6)
+    zd = dev(z)
+    drop = lib.dropout(p, 5, 2) if p else None
+    ln = None
+    res = z
+    if with_ln:
+        _, _, mean, rstd = ops.layernorm_fwd_res32(zd, dev(gamma), dev(beta), 1e-12, dtype)
+        ln = (mean, rstd, dev(gamma), dev(beta))
+        res = torch.nn.functional.layer_norm(z, (N,), gamma, beta, 1e-12)
+    got = ops.gemm_nt(dev(A, dtype), dev(B, dtype), bias=dev(bias), drop=drop, residual=zd, out_f32=True, residual_ln=ln)
+    lin = A @ B.t() + bias
+    if p:
+        keep = ops.dropout_bwd(torch.ones(M, N, dtype=dtype, device="cuda"), drop).float().cpu() != 0
+        p_q = int(p * 256 + 0.5) / 256  # the rate actually applied (include/sparse_hip.h, sm_dropout)
+        lin = lin * keep / (1 - p_q)
+    want = lin + res
+    assert got.dtype == torch.float32
+    close(got, want, 2e-5 if not with_ln else 1e-4, "fp32 residual epilogue")
+
+
 @pytest.mark.parametrize("density", [0.0, 0.002, 0.05])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_head_dt_with_few_live_activations_skips_steps_without_changing_the_sum(ops, density, ragged):
