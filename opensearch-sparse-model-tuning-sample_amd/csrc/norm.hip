@@ -285,12 +285,19 @@ __global__ __launch_bounds__(256) void embed_grad_sorted_kernel(const bf16* __re
 #pragma unroll
     for (int i = 0; i < NC2; ++i) acc[i][0] = acc[i][1] = 0.f;
     int cur = __shfl(my_key, 0, 64);
+    // a lane holds the column PAIR (2 lane, 2 lane + 1) of each 128-column block (one 4-byte load of two bf16); added as they sit,
+    // an atomic instruction would touch every other float of a 512-byte span -- half-filled 128-byte segments, half the rate of the
+    // memory-side adders.  Two bpermutes per instruction turn the pairs into 64 CONSECUTIVE columns per instruction (256 contiguous bytes)
+    const int src = lane >> 1;
+    const bool odd = lane & 1;
     auto flush = [&](int k) {
 #pragma unroll
       for (int i = 0; i < NC2; ++i) {
-        float* dst = table + (size_t)k * H + 2 * (lane + 64 * i);
-        atomicAdd(dst, acc[i][0]);
-        atomicAdd(dst + 1, acc[i][1]);
+        float* dst = table + (size_t)k * H + 128 * i + lane;
+        const float lo0 = __shfl(acc[i][0], src, 64), lo1 = __shfl(acc[i][1], src, 64);
+        const float hi0 = __shfl(acc[i][0], 32 + src, 64), hi1 = __shfl(acc[i][1], 32 + src, 64);
+        atomicAdd(dst, odd ? lo1 : lo0);
+        atomicAdd(dst + 64, odd ? hi1 : hi0);
         tot[i][0] += acc[i][0];
         tot[i][1] += acc[i][1];
         acc[i][0] = acc[i][1] = 0.f;

@@ -455,12 +455,13 @@ def test_embed_fwd_bwd(ops, dtype):
     close(gt, dz.sum(0), 1e-4, "type grad")
 
 
-def test_embed_bwd_from_host_sorted_rows_matches_the_scatter(ops):
+@pytest.mark.parametrize("H", [128, 384, 768])
+def test_embed_bwd_from_host_sorted_rows_matches_the_scatter(ops, H):
     """packed layout, bf16: run sums over the rows sorted by token id / by position (pack_documents -> rag.emb_sorted; [CLS] /
     [SEP] in every document, a token repeated 100 times) against index_add in fp32 and against the atomic scatter kernel"""
     from sparse_hip.encoder import pack_documents
     dtype = torch.bfloat16
-    B, S, H, V = 150, 64, 128, 500
+    B, S, V = 150, 64, 500
     g = torch.Generator().manual_seed(3)
     lens = torch.randint(3, S + 1, (B,), generator=g)
     ids = torch.randint(10, V, (B, S), generator=g)
