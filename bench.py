@@ -85,7 +85,8 @@ def build_trainer(args, device, rank, layouts=("ragged",)):
     model = SparseModel(bb, idf=idf, use_l0=False)
     k = args.negs + 1
     n_batches = 4
-    ds = SyntheticTriplesDataset(args.bs * n_batches, k, args.seq, 32, cfg.vocab_size, seed=1234 + rank)
+    lens = {} if getattr(args, "len_scale", None) is None else {"len_mean": 80.0 * args.len_scale, "len_std": 30.0 * args.len_scale}
+    ds = SyntheticTriplesDataset(args.bs * n_batches, k, args.seq, 32, cfg.vocab_size, seed=1234 + rank, **lens)
     coll = PreTokenizedCollator()
     margs = ModelArguments(model_name_or_path="random-init-v2-mini-shape", inf_free=True)
     dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=200,
@@ -411,11 +412,15 @@ def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
     down until ~1 % of the (document, vocabulary) activations are alive (the share before the shift is reported too), learning rate 0, then `steps` steps
     are timed.  Only the kernels whose work depends on the activation pattern change (head backward: rows gathered, all-zero
     G slices skipped).  The bias and the learning rate are restored afterwards."""
+    bb = trainer.model.sparse_model.backbone
+    bias = bb.view("cls.predictions.bias")
+    # everything the leg touches is snapshotted and restored in `finally`: the weights and the AdamW moments (the moments move even
+    # at learning rate 0), the step counter, the learning rate, the density probe
+    keep, lr, gstep = bias.detach().clone(), trainer.args.learning_rate, trainer.state.global_step
+    flat = bb.flat_param.detach().clone()
+    adam = None if trainer._adam is None else {k: v.detach().clone() for k, v in trainer._adam.items()}
+    mavg = trainer.ranking_loss_moving_avg
     try:
-        bb = trainer.model.sparse_model.backbone
-        bias = bb.view("cls.predictions.bias")
-        keep, lr = bias.detach().clone(), trainer.args.learning_rate
-
         def alive():
             with torch.no_grad():
                 bb.eval()
@@ -434,7 +439,7 @@ def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
             lo, hi = (mid, hi) if alive() > density else (lo, mid)
         trainer.args.learning_rate = 0.0
         a1 = alive()
-        bb._density, bb._density_tick = None, 0  # the density-adaptive head backward re-measures at once (it samples every 8th encode)
+        bb._density, bb._density_tick, bb._density_probe = None, 0, None  # the density-adaptive head backward re-measures at once (it samples every 8th encode)
         for i in range(3):
             trainer.training_step(bs_[i % len(bs_)])
         torch.cuda.synchronize()
@@ -443,17 +448,62 @@ def sparse_regime_leg(trainer, bs_, layout, density=0.01, steps=15):
             trainer.training_step(bs_[i % len(bs_)])
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        with torch.no_grad():
-            bias.copy_(keep)
-        bb.mark_weights_dirty()
-        trainer.args.learning_rate = lr
-        dens, bb._density, bb._density_tick = bb._density, None, 0
+        dens = bb._density
         return {"head_backward_form": "scatter over the live entries" if (dens is not None and dens < bb.dt_scatter_density and bb.dt_scatter) else "matrix form",
                 "what": "the same step with the decoder bias shifted until ~1 % of the sparse activations are alive (a trained checkpoint's "
                         "regime; alive_fraction_random_init = the share before the shift), learning rate 0", "layout": layout, "alive_fraction_random_init": a0,
                 "alive_fraction": a1, "ms_per_step": ms, "samples_per_sec": 32e3 / ms, "steps": steps}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            bb.flat_param.copy_(flat)
+            if adam is None:
+                trainer._adam = None
+            else:
+                for k, v in adam.items():
+                    trainer._adam[k].copy_(v)
+        bb.mark_weights_dirty()
+        trainer.args.learning_rate = lr
+        trainer.state.global_step = gstep
+        trainer.ranking_loss_moving_avg = mavg
+        bb._density, bb._density_tick, bb._density_probe = None, 0, None
+
+
+def seq_sweep_leg(args, device, base_ms, steps=12, warmup=4):
+    """configs[1]'s model and recipe at the sequence lengths the reference's shipped recipes train at (max_seq_length 512 / 256:
+    config_infonce.yaml:9, config_l0.yaml:9, config_kd.yaml:9) with the SAME number of token rows per step as the headline
+    (65 536 padded rows: 16 queries x 16 documents x 256, 8 x 16 x 512; document lengths scaled with the sequence length), dense
+    layout like `value`: tokens/s beside the S = 128 figure.  Outside every timed region of the headline; its own trainers."""
+    import copy
+    out = {"what": "same model / recipe / token rows per step as `value` (dense layout, dropout on, optimiser included) at longer documents; "
+                   "tokens = padded token rows of the document encoder", "steps": steps, "warmup": warmup,
+           "seq128": {"ms_per_step": base_ms, "tokens_per_sec": args.bs * (args.negs + 1) * args.seq / (base_ms * 1e-3)}}
+    for S in (256, 512):
+        try:
+            a = copy.copy(args)
+            a.seq, a.bs, a.len_scale = S, args.bs * args.seq // S, S / 128.0
+            trainer, _, batches = build_trainer(a, device, 0, layouts=("dense",))
+            bs_ = batches["dense"]
+            for i in range(warmup):
+                trainer.training_step(bs_[i % len(bs_)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = None
+            for i in range(steps):
+                last = trainer.training_step(bs_[i % len(bs_)])
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            toks = a.bs * (a.negs + 1) * S
+            out[f"seq{S}"] = {"queries": a.bs, "docs": a.bs * (a.negs + 1), "ms_per_step": ms, "tokens_per_sec": toks / (ms * 1e-3),
+                              "vs_seq128": (toks / ms) / (args.bs * (args.negs + 1) * args.seq / base_ms), "loss": float(last),
+                              "finite": bool(torch.isfinite(last).item())}
+            del trainer, batches, bs_
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            out[f"seq{S}"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def c5_leg(timeout_s=240):
@@ -654,6 +704,7 @@ def main():
         # two more records beside `value` (outside every timed region above; each guarded: a failure here never loses the line)
         result["sparse_regime"] = sparse_regime_leg(trainer, batches[args.layout], args.layout)
         result["c5_per_gpu"] = c5_leg()
+        result["seq_sweep"] = seq_sweep_leg(args, device, elapsed / args.steps * 1e3 if args.layout == "dense" else elapsed_other / args.steps * 1e3)
     if rank == 0:
         if world == 1:
             pm = measured_peaks(device)

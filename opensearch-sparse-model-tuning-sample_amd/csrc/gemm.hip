@@ -2417,6 +2417,9 @@ int sm_head_dt_ln_launch(int dtype, const float* grad_rep, const float* rep, con
                          float* ws, long ws_bytes, hipStream_t st) {
   const long T = rag ? rag->rows : (long)B * S;
   if (dtype != SM_BF16 || H != DT_C || V % 2 != 0 || ((uintptr_t)E % 16) != 0 || !(rag || S % 16 == 0)) return 1;
+  // head_dt192_kernel addresses grad_rep / rep / argmax and E with 32-bit byte offsets on scalar bases: larger batches or
+  // vocabularies take the caller's fallback (the unfused path below sm_head_dt_launch's same check)
+  if ((long)B * V * 4 >= (1L << 32) || (long)V * H * 2 >= (1L << 32)) return 1;
   if ((((uintptr_t)x | (uintptr_t)gelu_of | (uintptr_t)dft | (uintptr_t)gamma) % 16) != 0) return 1;
   LnBwdArgs ln{};
   ln.x = (const bf16*)x;
@@ -2461,7 +2464,9 @@ int sm_head_dt_launch(int dtype, const float* grad_rep, const float* rep, const 
   const int32_t* blk_doc = rag ? rag->blk_doc : nullptr;
   const int rrows = rag ? rag->rows : 0;
   constexpr int dt192 = 1;
-  if (dt192 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
+  // (32-bit byte offsets into the [B, V] words and into E inside head_dt192_kernel: beyond 2^32 the 128 x 128 kernel below runs)
+  const bool off32 = (long)B * V * 4 < (1L << 32) && (long)V * H * 2 < (1L << 32);
+  if (dt192 && off32 && dtype == SM_BF16 && H % DT_C == 0 && V % 2 == 0 && ((uintptr_t)E % 16) == 0 && ((uintptr_t)dt % 8) == 0 && (rag || S % 16 == 0)) {
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)head_dt192_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
     hipLaunchKernelGGL((head_dt192_kernel<false, false>), dim3(H / DT_C, sm_cdiv(T, DT_R)), dim3(512), DT_LDS, st, grad_rep, rep, argmax, (const bf16*)E, (bf16*)dt,
                        B, S, H, V, use_l0, doc_off, blk_doc, rrows, LnBwdArgs{}, DtSplit{});

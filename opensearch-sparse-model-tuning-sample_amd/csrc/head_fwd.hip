@@ -497,10 +497,13 @@ __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
 #undef VS_READ
 }
 
-// S <= 256: the position of a maximum takes the low 8 mantissa bits of its value (near-ties inside 2^-15 go to the lower
-// position); longer documents take the generic kernel of gemm.hip, which compares exactly
+// The position of a maximum takes the low mantissa bits of its value: 7 bits at S <= 128, 8 at S <= 256, 9 at S <= 512 (the
+// reference's shipped max_seq_length, config_infonce.yaml:9 / config_l0.yaml:9) -- the value keeps 14 significant bits (2^-15
+// relative, three orders of magnitude inside the 16-bit operands' own rounding) and near-ties inside 2^-14 go to the lower
+// position.  Round 5 stopped at 256 and sent S = 512 to the generic kernel of gemm.hip (exact comparisons, 520-670 TFLOP/s
+// against 1 000 here); the block metadata word already carried 5 bits of block position (512 rows).
 bool vs_eligible(int dtype, int H, int S, const void* t, const void* E) {
-  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 128 || H == 256 || H == 384) && S <= 256 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
+  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 128 || H == 256 || H == 384) && S <= 512 && ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
 }
 
 template <int H, bool F16>

@@ -193,8 +193,8 @@ KERNEL_OPTIONS = {
     "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
     "fp8_emit": ("SM_FP8_EMIT", False, bool),                 # fp8 mode: the FFN-width GEMM epilogues write the next GEMM's fp8 operand themselves (byte-identical; measured +-0 on configs[4]: opt-in)
-    "tn_group": ("SM_TN_GROUP", True, bool),
-    "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
+    "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
+    "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
     "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
     "pc_infer_min_rows": ("SM_PC_INFER_MIN_ROWS", 6144, int),  # no-grad forwards below this many rows: unfused feed-forward launches
@@ -322,6 +322,7 @@ class HipBertMLM(torch.nn.Module):
         self._density_probe = None  # (event, pinned count, sampled elements) of the encode before
         self._density_host = None
         self._density_tick = 0
+        self._density_rows = 0
         self._graphs: "collections.OrderedDict" = collections.OrderedDict()
         if init_seed is not None:
             self.reset_parameters(init_seed)
@@ -696,9 +697,15 @@ class HipBertMLM(torch.nn.Module):
         prev = self._density_probe
         if prev is not None:
             ev, host, n = prev
-            ev.synchronize()  # an encode before this one: finished long ago
+            # never wait: with rep-level gradient caching several need_grad encodes are enqueued within ONE step, and the probe
+            # of the encode just before this one has not run yet -- its count is taken over by a later call, the old density stays
+            if not ev.query():
+                return
             self._density = float(host.item()) / n
             self._density_probe = None
+        if rep.shape[0] < self._density_rows:  # sample the step's document encodes (the largest batch seen), not the query encodes
+            return
+        self._density_rows = rep.shape[0]
         self._density_tick += 1
         if self._density is not None and self._density_tick % 8:  # the live share moves slowly: count on every 8th encode (3 small launches)
             return

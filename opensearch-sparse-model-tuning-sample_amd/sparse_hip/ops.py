@@ -375,17 +375,19 @@ def sparse_head_bwd(grad_rep: Tensor, rep: Tensor, argmax: Tensor, t: Tensor, E:
     return dt
 
 
-_DT_WS = {}  # device index -> the zeroed workspace of sm_sparse_head_bwd_dt_ln's split tail (the kernel leaves it zero)
+_DT_WS = {}  # (device index, stream handle) -> the zeroed workspace of sm_sparse_head_bwd_dt_ln's split tail (the kernel leaves it zero)
 
 
 def _dt_workspace(device) -> Optional[Tensor]:
-    """one workspace per device, used by one launch at a time: the calls of a process are ordered on the training stream.
+    """one workspace per (device, stream): launches on ONE stream are ordered, so they may share the zeroed fp32 images; a second
+    model or thread that runs its head backward on another stream (teacher + student, a side stream) gets its own (56 MB each).
     None (no split: bit-reproducible sums) under SM_DETERMINISTIC=1"""
     if DETERMINISTIC_SCORES:
         return None
-    ws = _DT_WS.get(device.index)
+    key = (device.index, L.stream_ptr())
+    ws = _DT_WS.get(key)
     if ws is None:
-        ws = _DT_WS[device.index] = torch.zeros(L.load().sm_sparse_head_bwd_dt_ws_bytes() // 4, dtype=torch.float32, device=device)
+        ws = _DT_WS[key] = torch.zeros(L.load().sm_sparse_head_bwd_dt_ws_bytes() // 4, dtype=torch.float32, device=device)
     return ws
 
 
@@ -401,10 +403,17 @@ def sparse_head_bwd_dt_ln(grad_rep: Tensor, rep: Tensor, argmax: Tensor, E: Tens
         return None
     dft = torch.empty_like(gelu_of)
     ws = _dt_workspace(E.device) if split_tail else None
-    ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(E.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
-                         L.ptr(dft), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                         L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), int(x32), L.ptr(ws) if ws is not None else None,
-                         ws.numel() * 4 if ws is not None else 0, L.stream_ptr())
+    try:
+        ok = L.call_optional("sm_sparse_head_bwd_dt_ln", L.dtype_code(E.dtype), L.ptr(grad_rep), L.ptr(rep), L.ptr(argmax), L.ptr(E),
+                             L.ptr(dft), B, S, H, V, int(use_l0), _rag_ref(rag), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                             L.ptr(gelu_of), L.ptr(dgamma), L.ptr(dbeta), int(x32), L.ptr(ws) if ws is not None else None,
+                             ws.numel() * 4 if ws is not None else 0, L.stream_ptr())
+    except Exception:
+        # a launch that failed between the split kernel and the tail kernel may have left partial sums behind: the workspace is
+        # dropped (the next call allocates a zeroed one) rather than trusted
+        if ws is not None:
+            _DT_WS.pop((E.device.index, L.stream_ptr()), None)
+        raise
     return dft if ok else None
 
 

@@ -131,3 +131,55 @@ def test_full_bench_batch_gradients_of_the_fast_path_agree_with_the_fp32_parity_
         a, b = g16[o:o + n], g32[o:o + n]
         r = float((a - b).norm() / b.norm())
         assert r <= 0.3, (name, r)
+
+
+def test_c5_full_per_gpu_shape_step_properties_fp8_gradient_caching():
+    """BASELINE.json configs[4] at its FULL per-GPU shape -- bert-base student, 64 queries x 31 documents of up to 512 tokens, KL
+    distillation on precomputed scores, fp8 operands in the encoder linears, rep-level gradient caching in 8 chunks of 248 documents
+    (what tools/c5_shape_smoke.py and bench.py's c5_per_gpu leg time) -- as a PROPERTY test (the oracle covers one chunk of it in
+    tests/test_baseline_configs_gpu.py): every step finite, pass 2 of every chunk bit-identical to its pass 1 (the cached
+    representation gradients belong to exactly the activations the second pass recomputes; config_kd.yaml:9-16), and the
+    loss falls over three steps on a fixed batch."""
+    from scripts.args import DataTrainingArguments, ModelArguments, TrainingArguments
+    from scripts.dataset.synthetic import PreTokenizedCollator, SyntheticTriplesDataset
+    from scripts.model.sparse_encoders import SparseModel
+    from scripts.train.loss import LOSS_CLS_MAP
+    from scripts.train.trainer import SparseModelTrainer
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    bs, k, S, chunk = 64, 31, 512, 248
+    cfg = BertConfigLite(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
+    ds = SyntheticTriplesDataset(bs, k, S, 32, 30522, seed=3, with_scores=True, len_mean=300, len_std=120)
+    bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=0, fp8=True)
+    model = SparseModel(bb, idf=torch.ones(30522), use_l0=False)
+    margs = ModelArguments(model_name_or_path="x", inf_free=True)
+    dargs = DataTrainingArguments(loss_types=["kldiv"], use_in_batch_negatives=False, flops_d_lambda=0.05, flops_d_T=100, data_type="kd",
+                                  grad_cache_chunk=chunk)
+    targs = TrainingArguments(output_dir="/tmp/sm_c5_prop", logging_steps=10 ** 9, bf16=True, learning_rate=1e-4, warmup_steps=0, max_steps=1000,
+                              check_finite=True)
+    tr = SparseModelTrainer(model_args=margs, data_args=dargs, model=model, args=targs,
+                            loss_functions=[LOSS_CLS_MAP["kldiv"](use_in_batch_negatives=False, weight=1, temperature=1.0)])
+    batch = tr._prepare_inputs(PreTokenizedCollator()([ds[i] for i in range(bs)]))
+    nchunks = len(batch["docs"][0]["packed_chunks"])
+    assert nchunks == bs * k // chunk == 8
+    seen, real = [], HipBertMLM.encode
+
+    def spy(self, *a, **kw):
+        rep = real(self, *a, **kw)
+        if rep.shape[0] == chunk:  # (document chunks only; 16-bit checksums would do, the tensors are 30 MB each)
+            seen.append(rep.detach().clone())
+        return rep
+    losses = []
+    HipBertMLM.encode = spy
+    try:
+        for step in range(3):
+            del seen[:]
+            losses.append(float(tr.training_step(batch)))  # check_finite: raises on a non-finite gradient or parameter
+            torch.cuda.synchronize()
+            assert len(seen) == 2 * nchunks, len(seen)
+            for c in range(nchunks):
+                assert torch.equal(seen[c], seen[nchunks + c]), f"step {step}: pass 2 of chunk {c} differs from pass 1"
+    finally:
+        HipBertMLM.encode = real
+    print(f"[c5 full per-GPU shape, fp8] losses {losses}")
+    assert all(l == l and abs(l) < 1e6 for l in losses)
+    assert losses[2] < losses[0], losses

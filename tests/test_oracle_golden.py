@@ -264,3 +264,53 @@ def test_g9_postprocess_rows_match_reference():
         n = int(g["nnz"][i])
         assert ids == g["cols"][i, :n].tolist()
         np.testing.assert_allclose(np.array(w, dtype=np.float32), g["vals"][i, :n], rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The device's dropout compares ONE BYTE of a hash with an 8-bit threshold (include/sparse_hip.h: p quantised to 1/256), so
+# the reference's p = 0.1 (hf BertConfig hidden_dropout_prob / attention_probs_dropout_prob behind sparse_encoders.py:108) runs as
+# 26/256 = 0.1016.  What that does to the training objective, on the oracle:
+class _CommonRandomDrop(O.DropMasks):
+    """inverted dropout with probability p from a stream of uniforms that does not depend on p (common random numbers)"""
+
+    def __init__(self, p, seed):
+        self.p, self.gen = p, torch.Generator().manual_seed(seed)
+
+    def apply(self, x):
+        u = torch.rand(x.shape, generator=self.gen)
+        return x * (u >= self.p).to(x.dtype) / (1.0 - self.p)
+
+
+def test_dropout_rate_quantised_to_one_256th_leaves_the_expected_loss_where_it_was():
+    """(1) inverted dropout at ANY rate is mean-preserving: E[keep / (1 - p)] = 1 exactly at p = 26/256 as at p = 0.1 -- the
+    quantisation changes only the variance of the multiplicative noise, p / (1 - p): 0.11111 -> 0.11304 (+1.7 %).
+    (2) measured on the oracle's training loss (InfoNCE with in-batch negatives + FLOPS, all four dropout sites on, 64 mask draws
+    with common random numbers): the mean loss at p = 26/256 differs from the mean loss at p = 0.1 by far less than the spread of
+    the loss over mask draws at either rate -- the bound asserted is a tenth of that standard deviation and 2e-3 of the loss."""
+    p_ref = 0.1
+    t = int(p_ref * 256.0 + 0.5)           # csrc/common.h make_drop
+    p_dev = t / 256.0
+    assert t == 26 and abs(p_dev - 0.1015625) < 1e-12
+    assert abs((1 - p_dev) * (256.0 / (256.0 - t)) - 1.0) < 1e-12  # keep probability x scale = 1: unbiased
+    assert abs(p_dev / (1 - p_dev) / (p_ref / (1 - p_ref)) - 1.0) < 0.018
+    cfg = O.BertShape(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                      max_position_embeddings=32)
+    p = O.init_params(cfg, seed=3, std=0.05)
+    g = torch.Generator().manual_seed(4)
+    nq, k, S = 4, 4, 24
+    d_ids = torch.randint(104, 520, (nq * k, S), generator=g)
+    d_mask = (torch.arange(S)[None, :] < torch.randint(8, S + 1, (nq * k, 1), generator=g)).long()
+    q_ids = torch.randint(104, 520, (nq, 8), generator=g)
+    idf = torch.exp(torch.rand(520, generator=g) * 4 - 2)
+    lc = O.LossConfig(loss_types=("infonce",), use_in_batch_negatives=True, flops_d_lambda=0.05, flops_d_T=200)
+    losses = {p_ref: [], p_dev: []}
+    with torch.no_grad():
+        for seed in range(64):
+            for rate in (p_ref, p_dev):
+                losses[rate].append(float(O.compute_loss(p, cfg, idf, SPECIAL, q_ids, torch.ones_like(q_ids), d_ids, d_mask, None, lc, 100,
+                                                         dropout_p=rate, gen=_CommonRandomDrop(rate, 1000 + seed))[0]))
+    a, b = np.array(losses[p_ref]), np.array(losses[p_dev])
+    shift, spread = abs(a.mean() - b.mean()), min(a.std(), b.std())
+    print(f"mean loss at p = 0.1: {a.mean():.6f}, at p = 26/256: {b.mean():.6f}; shift {shift:.2e}, spread over mask draws {spread:.2e}")
+    assert spread > 0
+    assert shift <= 0.1 * spread and shift <= 2e-3 * abs(a.mean()), (shift, spread, a.mean())
