@@ -138,8 +138,24 @@ class GemmRoofline:
     the kernel runs on; the weight-gradient GEMMs run on the side stream and share the GPU with the backward chain,
     exactly as in the measured step).  Reported per op: launches / step, executed FLOPs, achieved TFLOP/s in the step."""
 
+    MAX_STAMPS = 4096
+
     def __init__(self, ops):
         self.ops, self.rec, self.orig = ops, {}, {}
+        # shader-clock stamps (sm_clock_stamp, ABI 7): per XCD a (s_memtime, s_memrealtime) pair before and after every timed launch,
+        # on the launch's own stream -> the clock the chip held under that kernel (the verdict's "clock as a measured quantity")
+        from sparse_hip import lib as L
+        self.L = L
+        self.stamps = torch.zeros(self.MAX_STAMPS * 16, dtype=torch.int64, device="cuda")
+        self.nstamp = 0
+        self.extra = set()
+
+    def _stamp(self):
+        if self.nstamp >= self.MAX_STAMPS:
+            return None
+        slot, self.nstamp = self.nstamp, self.nstamp + 1
+        self.L.call("sm_clock_stamp", self.L.ptr(self.stamps), slot, self.L.stream_ptr())
+        return slot
 
     def _wrap(self, name, flops, label=None):
         orig = getattr(self.ops, name)
@@ -147,14 +163,26 @@ class GemmRoofline:
 
         def wrapped(*a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0 = self._stamp()
             e0.record()
             out = orig(*a, **kw)
             e1.record()
+            s1 = self._stamp()
             if out is not None and out is not False:  # (a fused entry point that declines the shape returns None / False and its caller runs the unfused ops, which
                 key = name if label is None else label(*a, **kw)                     # are counted themselves)
-                self.rec.setdefault(key, []).append((e0, e1, flops(*a, **kw)))
+                self.rec.setdefault(key, []).append((e0, e1, flops(*a, **kw), s0, s1))
             return out
         setattr(self.ops, name, wrapped)
+
+    def _clock_ghz(self, st, s0, s1):
+        """mean over the XCDs that both stamps saw of d(s_memtime) / d(s_memrealtime) x 100 MHz"""
+        if s0 is None or s1 is None:
+            return None
+        a, b = st[s0], st[s1]  # [8, 2]
+        ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1])
+        if not bool(ok.any()):
+            return None
+        return float(((b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double()).mean() * 0.1)
 
     @staticmethod
     def _nt_label(A, B, *a, n=None, **k):
@@ -177,6 +205,10 @@ class GemmRoofline:
         self._wrap("ffn_pc_fwd", lambda z1, g1, b1, eps, w1f, bias1, *a, **k: 4.0 * z1.shape[0] * z1.shape[1] * bias1.shape[0])
         # ... and its backward (dF1 GEMM + FFN-up input gradient, with GELU', the LayerNorm-1 backward and the residual gradient)
         self._wrap("ffn_pc_bwd", lambda dy, dres, f1, *a, **k: 4.0 * dy.shape[0] * dy.shape[1] * f1.shape[1] * 32)
+        # the other matrix-pipe kernels of the step, for their CLOCK only (not part of the encoder-GEMM roofline sums)
+        for extra in ("sparse_head_fwd", "sparse_head_bwd_dt_ln", "attention_fwd", "attention_bwd"):
+            self.extra.add(extra)
+            self._wrap(extra, lambda *a, **k: 0.0)
         return self
 
     def __exit__(self, *exc):
@@ -185,12 +217,22 @@ class GemmRoofline:
 
     def summary(self, steps, peak):
         out = []
+        st = self.stamps.cpu().view(self.MAX_STAMPS, 8, 2)
+        self.other = []
         for name, rec in self.rec.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-            fl = sum(f for _, _, f in rec)
-            if ms > 0:
+            ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+            fl = sum(r[2] for r in rec)
+            clk = [c for c in (self._clock_ghz(st, r[3], r[4]) for r in rec) if c is not None]
+            if name in self.extra:
+                self.other.append({"op": name, "launches_per_step": len(rec) / steps, "ms_per_step": ms / steps,
+                                   "clock_ghz": sum(clk) / len(clk) if clk else None})
+            elif ms > 0:
                 out.append({"op": name, "launches_per_step": len(rec) / steps, "gflop_per_step": fl / steps / 1e9,
-                            "ms_per_step": ms / steps, "achieved_tflops": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / peak})
+                            "ms_per_step": ms / steps, "achieved_tflops": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / peak,
+                            # shader clock under the op's launches (stamps around each launch, on its stream); at 2.4 GHz the
+                            # dense bf16 MFMA peak is 2.5 PFLOP/s, so the op's rate against what ITS clock allows is frac_at_clock
+                            "clock_ghz": sum(clk) / len(clk) if clk else None,
+                            "frac_at_clock": (fl / (ms * 1e-3) / (peak * (sum(clk) / len(clk)) / 2.4)) if clk else None})
         return out
 
 
@@ -593,10 +635,26 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
+    # N > 1: `value` is measured with north_star's exchange -- the reference's RCCL all-gather of the document representations
+    # (SM_EXCHANGE=gather, scripts/utils.py:16-23) -- whatever the caller's environment says; the score-block exchange
+    # (sparse_hip.functional.distributed_loss) is timed right after it on the same ranks and reported BESIDE it.
+    env_exchange = os.environ.get("SM_EXCHANGE")
+    if world > 1:
+        os.environ["SM_EXCHANGE"] = "gather"
     with KernelTimer(ops, "sparse_head_fwd") as kt:
         elapsed = timed(args.layout, kt)   # <- the line's `value`
         head_ms = kt.mean_ms()
         rows = list(kt.rows)
+    elapsed_scores = None
+    if world > 1:
+        os.environ["SM_EXCHANGE"] = "scores"
+        try:
+            elapsed_scores = timed(args.layout)
+            live["scores_exchange"] = live[args.layout]
+        finally:
+            os.environ["SM_EXCHANGE"] = "gather"
+        live[args.layout] = None
+        elapsed_again = timed(args.layout)  # liveness record of the value layout in gather mode again (and a second gather sample)
     elapsed_other = float("nan") if args.only_value_layout else timed(other)  # the other layout, outside the headline region
     gemm_lines = gemm_lines_serial = None
     if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
@@ -606,6 +664,7 @@ def main():
                 trainer.training_step(bs_[i % len(bs_)])
             torch.cuda.synchronize()
         gemm_lines = gr.summary(3, MFMA_PEAK[args.dtype])
+        other_clock_lines = gr.other
         # the same three steps with the weight-gradient launches on the main queue: every GEMM alone on the chip.  In the
         # overlapped step a GEMM's time includes what its neighbour on the other queue takes from it.
         wg = getattr(trainer.model.sparse_model.backbone, "_wgrad", None)
@@ -618,6 +677,7 @@ def main():
                         trainer.training_step(bs_[i % len(bs_)])
                     torch.cuda.synchronize()
                 gemm_lines_serial = gr2.summary(3, MFMA_PEAK[args.dtype])
+                other_clock_serial = gr2.other
             finally:
                 wg.enabled = True
     barrier()
@@ -656,19 +716,22 @@ def main():
                                   "identical outputs); value_dense_layout computes all of them" if args.layout == "ragged" else
                                   f"dense layout: all {T_padded} token rows computed (attention skips key tiles that hold only masked keys: exact); value_ragged_layout skips padding tokens"),
                    "global_batch": world * args.bs, "docs_per_query": k, "seq_len": args.seq,
-                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks over RCCL, exchange mode "
-                                                      + os.environ.get("SM_EXCHANGE", "gather") + ": scores = all-gather of the queries (under "
-                                                      "the document encoder) and of the score blocks + all-reduce of the FLOPS column means, "
-                                                      "gather = the reference's all-gather of the representations; flat-gradient all-reduce "
-                                                      "in slices overlapped with backward)")},
+                   "parallelism": f"dp{world}" + ("" if world == 1 else " (in-batch negatives across ranks over RCCL; `value`: exchange mode "
+                                                      "gather = the reference's all-gather of the document representations, every rank "
+                                                      "evaluates the loss head on the gathered batch; value_scores_exchange: all-gather of the "
+                                                      "queries (under the document encoder) and of the score blocks + all-reduce of the FLOPS "
+                                                      "column means; both: flat-gradient all-reduce in slices overlapped with backward)")},
     }
     if world > 1:  # self-describing multi-GPU record: what carried the collectives
         try:
             ver = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception as e:  # noqa: BLE001  (a build without the binding: say so instead of failing the run)
             ver = f"unavailable ({type(e).__name__})"
+        result["value_scores_exchange"] = sps(elapsed_scores)
+        result["ms_per_step_scores_exchange"] = elapsed_scores / args.steps * 1e3
+        result["value_gather_second_sample"] = sps(elapsed_again)
         result["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
-                          "exchange": os.environ.get("SM_EXCHANGE", "gather"), "gpus_visible": ndev,
+                          "exchange": "gather (value), scores (value_scores_exchange)", "exchange_env_at_start": env_exchange, "gpus_visible": ndev,
                           "env": {k: os.environ[k] for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_ALGO", "NCCL_PROTO") if k in os.environ}}
     head_line = {"kernel": "fused MLM decoder + seq-max + log1p(relu) (sm_sparse_head_fwd)", "bound": "mfma",
                  "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -684,7 +747,10 @@ def main():
         result["roofline"] = {"kernel": "encoder GEMMs, in-step (all launches of sm_gemm_nt / sm_gemm_nt_ln_bwd / sm_gemm_tn_acc / sm_gemm_tn_group / "
                                         "sm_ffn_pc_fwd / sm_ffn_pc_bwd of one training step)",
                               "bound": "mfma", "achieved": fl / ms, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / ms * 1e12 / peak,
-                              "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines}
+                              "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines,
+                              "other_kernels_clock": other_clock_lines,
+                              "clock_how": "sm_clock_stamp before and after every launch on its stream: d(s_memtime) / d(s_memrealtime) x 100 MHz, "
+                                           "mean over the XCDs; in-step = both queues running; one_queue.per_op_clock_ghz = each kernel alone"}
         if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
             tr, src, tgit, tk = latest_gemm_traffic(args.layout)
             result["roofline"].update({"traffic": tr, "traffic_unit": "bytes/step over all encoder GEMM launches (HBM-side reads x2-corrected "
@@ -696,6 +762,7 @@ def main():
             result["roofline"]["one_queue"] = {
                 "how": "same ops, weight-gradient launches on the main queue (no kernel shares the chip with another)",
                 "per_op_tflops": {g["op"]: g["achieved_tflops"] for g in gemm_lines_serial},
+                "per_op_clock_ghz": {g["op"]: g["clock_ghz"] for g in gemm_lines_serial + other_clock_serial},
                 "gflop_per_step": fl2, "ms_per_step": ms2, "achieved": fl2 / ms2, "frac": fl2 / ms2 * 1e12 / peak}
         result["roofline_head_fwd"] = head_line
     else:  # N > 1 or --no-gemm-roofline: the largest single kernel of the step

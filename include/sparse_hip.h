@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 6
+#define SM_ABI_VERSION 7
 #define SM_F32 0
 #define SM_BF16 1
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
@@ -387,6 +387,13 @@ int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream);
  * (global_load_lds, 16 bytes per lane, `depth` in flight per wave) from its workgroup's window of `span_per_block` bytes
  * into LDS.  Bytes moved = blocks * waves * iters * 1024.  waves in {1,2,4,8,16}, depth in {8,16,32}. */
 int sm_peak_lds_dma(const void* src, size_t span_per_block, int blocks, int waves, int depth, int iters, float* sink, void* stream);
+/* ABI 7 -- shader-clock stamp (bench.py / tools only): one tiny launch (32 workgroups of one wave) whose workgroups write, per XCD,
+ * the pair (s_memtime, s_memrealtime) into out[slot][xcc = 0..7][2] (64-bit words, 16-byte store by one lane).  Two stamps
+ * bracketing a kernel on its stream give the AVERAGE SHADER CLOCK the chip held under it, per XCD:
+ * (memtime_after - memtime_before) / (memrealtime_after - memrealtime_before) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6, taken
+ * around the kernel instead of inside it: no diagnostic build of the kernel itself is needed; the few microseconds between the
+ * stamps and the kernel are inside the interval). */
+int sm_clock_stamp(unsigned long long* out, int slot, void* stream);
 
 #ifdef __cplusplus
 }

@@ -158,45 +158,56 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
   PC_STAMP(w >> 2, 0);
 
-  // ---------------------------------------------------------------- prologue: LayerNorm 1 by all eight waves, row-major and
-  // coalesced (16 lanes per row, 3 chunks of 8 columns per lane); x1 goes to memory in bf16 (operand of the W1 weight gradient)
-  // and, in the operand type, into LDS in the producers' B-fragment order ((group, k-step, lane) -> 16 bytes)
+  // ---------------------------------------------------------------- prologue: LayerNorm 1 by all eight waves, row-major.  Lane =
+  // (token tl = lane & 7, chunk group cg = lane >> 3): a wave covers 8 rows x 8 chunks of 8 columns per load instruction (per row
+  // 8 pieces of 16 bytes at a 32-byte stride, both halves of a chunk by consecutive instructions: whole 128-byte lines), 6 chunks
+  // per lane and row.  The EIGHT CONSECUTIVE LANES of a ds_write_b128 lane group hold 8 consecutive tokens of ONE chunk, i.e. 128
+  // contiguous bytes of the producers' B-fragment image ((group, k-step, lane) -> 16 bytes): conflict free.  (Rounds 3-5 had 16
+  // lanes per row: the 8 lanes of a group then wrote 8 different k-steps of one token, 512 bytes apart -- the same four banks,
+  // 8-way, 12 writes per lane -- most of the kernel's SQ_LDS_BANK_CONFLICT.)  x1 goes to memory in bf16 (operand of the W1 weight
+  // gradient) and, in the operand type, into LDS.
   {
-    const int sl = lane & 15, sub = lane >> 4;
-    // the four row groups' z1 reads are all in flight before the first is used (96 registers that nothing else needs yet): one
-    // read latency (~4 k cycles) for the prologue instead of four
-    f32x4 zin[4][3][2];
+    const int tl = lane & 7, cg = lane >> 3;
+    // both row groups' z1 reads are in flight before the first is used (96 registers that nothing else needs yet): one read
+    // latency (~4 k cycles) for the prologue instead of two
+    f32x4 zin[2][6][2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const float* zr = a.z1 + (size_t)min(blk_row0 + it * 32 + w * 4 + sub, T - 1) * PC_H;
+    for (int it = 0; it < 2; ++it) {
+      const float* zr = a.z1 + (size_t)min(blk_row0 + it * 64 + w * 8 + tl, T - 1) * PC_H;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        zin[it][i][0] = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8);
-        zin[it][i][1] = *reinterpret_cast<const f32x4*>(zr + (sl + 16 * i) * 8 + 4);
+      for (int i = 0; i < 6; ++i) {
+        zin[it][i][0] = *reinterpret_cast<const f32x4*>(zr + (cg + 8 * i) * 8);
+        zin[it][i][1] = *reinterpret_cast<const f32x4*>(zr + (cg + 8 * i) * 8 + 4);
       }
     }
+    auto row_sum = [](float v) __attribute__((always_inline)) {  // over the 8 lanes of a row: lane bits 3, 4, 5
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      return v;
+    };
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = it * 32 + w * 4 + sub, grow = blk_row0 + rl;
+    for (int it = 0; it < 2; ++it) {
+      const int rl = it * 64 + w * 8 + tl, grow = blk_row0 + rl;
       const bool live = grow < T;
-      float v[3][8];
+      float v[6][8];
       float s1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 6; ++i) {
         const f32x4 lo = zin[it][i][0], hi = zin[it][i][1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[i][k] = lo[k]; v[i][4 + k] = hi[k]; s1 += lo[k] + hi[k]; }
       }
-      const float mu = pc_lanes_sum<16>(s1) * (1.f / PC_H);
+      const float mu = row_sum(s1) * (1.f / PC_H);
       float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
-      const float rs = rsqrtf(pc_lanes_sum<16>(q) * (1.f / PC_H) + a.eps);
+      const float rs = rsqrtf(row_sum(q) * (1.f / PC_H) + a.eps);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ch = sl + 16 * i, c0 = ch * 8;
+      for (int i = 0; i < 6; ++i) {
+        const int ch = cg + 8 * i, c0 = ch * 8;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
         const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
         float o[8];
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
         const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
         pc_lds_write<V>(fa, OP::pack(o));
       }
-      if (live && sl == 0) { a.m1[grow] = mu; a.r1[grow] = rs; }
+      if (live && cg == 0) { a.m1[grow] = mu; a.r1[grow] = rs; }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -649,22 +660,24 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
   const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
   PC_STAMP(w >> 2, 0);
 
-  // ---- prologue: dy rows of the workgroup -> the producers' B-fragment order in LDS (row-major, coalesced 16-byte loads) ----
+  // ---- prologue: dy rows of the workgroup -> the producers' B-fragment order in LDS.  Lane = (token lane & 7, chunk group
+  //      lane >> 3) as in the forward: the 8 lanes of a ds_write_b128 lane group write 8 consecutive tokens of one chunk = 128
+  //      contiguous bytes of the image (conflict free; 16 lanes per row wrote 8 k-steps of one token, 8-way) ----
   {
-    const int sl = lane & 15, sub = lane >> 4;
-    bf16x8 din[4][3];
+    const int tl = lane & 7, cg = lane >> 3;
+    bf16x8 din[2][6];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const bf16* dr = a.dy + (size_t)min(blk_row0 + it * 32 + w * 4 + sub, T - 1) * PC_H;
+    for (int it = 0; it < 2; ++it) {
+      const bf16* dr = a.dy + (size_t)min(blk_row0 + it * 64 + w * 8 + tl, T - 1) * PC_H;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) din[it][i] = *reinterpret_cast<const bf16x8*>(dr + (sl + 16 * i) * 8);
+      for (int i = 0; i < 6; ++i) din[it][i] = *reinterpret_cast<const bf16x8*>(dr + (cg + 8 * i) * 8);
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = it * 32 + w * 4 + sub;
+    for (int it = 0; it < 2; ++it) {
+      const int rl = it * 64 + w * 8 + tl;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ch = sl + 16 * i;
+      for (int i = 0; i < 6; ++i) {
+        const int ch = cg + 8 * i;
         const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
         pc_lds_write<V>(fa, din[it][i]);
       }

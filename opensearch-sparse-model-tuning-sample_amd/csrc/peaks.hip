@@ -73,7 +73,24 @@ __global__ __launch_bounds__(WAVES * 64) void peak_lds_dma_kernel(const char* __
   if (v == 123.456f) sink[threadIdx.x & 1023] = v;
 }
 
+// (s_memtime, s_memrealtime) of the XCD this workgroup landed on -> out[xcc][0..1], one 16-byte store by lane 0
+__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned long long mt = __builtin_amdgcn_s_memtime(), rt = __builtin_amdgcn_s_memrealtime();
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u64x2*>(out + 2 * (xcc & 7u)) = u64x2{mt, rt};
+}
+
 }  // namespace
+
+extern "C" int sm_clock_stamp(unsigned long long* out, int slot, void* stream) {
+  SM_REQUIRE(out != nullptr && slot >= 0 && ((uintptr_t)out % 16) == 0, "sm_clock_stamp: bad arguments");
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(32), dim3(64), 0, (hipStream_t)stream, out + (size_t)slot * 16);
+  SM_LAUNCH_CHECK();
+  return SM_OK;
+}
 
 // Bytes moved by the launch = blocks * waves * iters * 1024.  waves in {1, 2, 4, 8, 16}, depth (loads in flight per wave) in {8, 16, 32}.
 extern "C" int sm_peak_lds_dma(const void* src, size_t span_per_block, int blocks, int waves, int depth, int iters, float* sink, void* stream) {

@@ -225,17 +225,22 @@ class SparseModelTrainer:
         ids, mask = enc["input_ids"], enc["attention_mask"]
         return [(ids[a:a + n], mask[a:a + n], None) for a in range(0, ids.shape[0], n)]
 
-    def _use_score_exchange(self) -> bool:
-        """N > 1: data_args.dist_exchange = "gather" (default) is the reference's form and the one north_star names -- RCCL all-gather
-        of the document representations (utils.py:16-23), every rank evaluates the whole loss.  "scores" (opt-in, SM_EXCHANGE=scores)
-        exchanges queries, score blocks and FLOPS column means instead (sparse_hip.functional.distributed_loss: same loss, same
-        gradients, ~100x less traffic, every V-length loss kernel stays on the local documents)."""
-        if self.accelerator.num_processes <= 1:
-            return False
+    def _exchange_mode(self) -> str:
+        """N > 1: data_args.dist_exchange / SM_EXCHANGE.
+        "gather" (default) is the reference's form and the one north_star names -- RCCL all-gather of the document representations
+        (utils.py:16-23) -- run as ONE autograd node (sparse_hip.functional.distributed_loss, exchange = "gather"): the all-gather goes
+        out in row chunks and each chunk's FLOPS column sums and score block are computed while the next chunk is on the wire.
+        "gather_ref" is the same exchange written exactly as the reference writes it (gather_rep of both representations, then the
+        loss objects on the gathered batch): the parity form, also what a user-supplied loss class gets.
+        "scores" (opt-in) exchanges queries, score blocks and FLOPS column means instead: same loss, same gradients, ~100x less
+        traffic, every V-length loss kernel stays on the local documents."""
         mode = os.environ.get("SM_EXCHANGE", getattr(self.data_args, "dist_exchange", "gather"))
-        if mode not in ("scores", "gather"):
+        if mode not in ("scores", "gather", "gather_ref"):
             raise KeyError(mode)
-        return mode == "scores"
+        return mode
+
+    def _use_score_exchange(self) -> bool:
+        return self.accelerator.num_processes > 1 and self._exchange_mode() == "scores"
 
     _BUILTIN_LOSSES = {InfoNCELoss: "infonce", KLDivLoss: "kldiv", MarginMSELoss: "marginmse"}
 
@@ -246,7 +251,7 @@ class SparseModelTrainer:
         with its own get_loss takes the reference-form path)."""
         if any(type(lf) not in self._BUILTIN_LOSSES for lf in self.loss_functions) or len(self.loss_functions) > 4:
             return False
-        return self.accelerator.num_processes <= 1 or self._use_score_exchange()
+        return self.accelerator.num_processes <= 1 or self._exchange_mode() in ("scores", "gather")
 
     def _compute_loss_fused(self, d_rep, q_rep, inputs, cap, return_outputs):
         losses = [(self._BUILTIN_LOSSES[type(lf)], lf.weight, bool(lf.use_in_batch_negatives), float(getattr(lf, "temperature", 1.0)))
@@ -257,7 +262,7 @@ class SparseModelTrainer:
             teacher = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
         # (the moving average ma = 0.01 * ranking + 0.99 * ma of trainer.py:120-122 is updated by the same launch)
         cfg = {"losses": losses, "q_cap": cap, "flops_threshold": self.data_args.flops_threshold, "moving_avg": self._ma,
-               "q_all": self._take_q_prefetch(),
+               "q_all": self._take_q_prefetch(), "exchange": self._exchange_mode() if n > 1 else None,
                "lambda_d": self.get_lambda(self.data_args.flops_d_lambda, self.data_args.flops_d_T),
                "lambda_q": None if self.model_args.inf_free else self.get_lambda(self.data_args.flops_q_lambda,
                                                                                  self.data_args.flops_q_T)}

@@ -209,9 +209,30 @@ class _DistLossFn(torch.autograd.Function):
         else:
             q_all = q
 
+        # exchange "gather" (north_star's form, scripts/utils.py:16-23): the document representations are all-gathered -- in C
+        # ROW CHUNKS, every collective issued up front on the communication queue, each chunk consumed as it lands while the next
+        # one is still on the wire: its FLOPS column sums and its block of the score matrix are all the loss head ever needs of a
+        # remote document (round 5 evaluated the loss kernels on the gathered [N * B_d, V] tensor AFTER the whole all-gather:
+        # 2.1 ms at N = 8 behind a 437 MB collective that nothing overlapped).  Gradients flow to the LOCAL documents only
+        # (gather_rep's backward is the local slice), so the backward below is the score exchange's.
+        gather = N > 1 and cfg.get("exchange") == "gather"
+        gathered = None
+        if gather:
+            C = int(cfg.get("gather_chunks", 4))
+            while C > 1 and (nd % (C * k) or nd // C < k):
+                C -= 1
+            rc = nd // C
+            gathered = []
+            for c in range(C):
+                buf = torch.empty((N * rc, V), dtype=torch.float32, device=d.device)
+                work = dist.all_gather_into_tensor(buf, d[c * rc:(c + 1) * rc], group=group, async_op=True)
+                gathered.append((buf, work))
+
         # FLOPS regulariser: global column means = mean of the per-rank column means (equal local batch sizes)
         d_flops, cm_d, keep_d = ops.flops_fwd(d, k, thr)
-        if N > 1:
+        if gather:
+            cm_d = None  # summed over the gathered chunks below (every chunk holds whole queries of every rank)
+        elif N > 1:
             dist.all_reduce(cm_d, group=group)
             cm_d.div_(N)
             d_flops = (cm_d * cm_d).sum().reshape(1)
@@ -234,13 +255,26 @@ class _DistLossFn(torch.autograd.Function):
 
         if any(ibn for _, _, ibn, _ in losses):
             csr_all = ops.row_compact(q_all, int(cap)) if cap else None
-            s_r = ops.scores_csr_fwd(csr_all, d, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, d, pairs=False)
-            if N > 1:
-                s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
-                dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
-                scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
+            if gather:
+                scores = torch.empty((N * nq, N * nd), dtype=torch.float32, device=d.device)
+                sv = scores.view(N * nq, N, len(gathered), nd // len(gathered))  # column = (rank, chunk, row of the chunk)
+                for c, (buf, work) in enumerate(gathered):
+                    work.wait()  # the current stream waits for THIS chunk; the later ones are still in flight
+                    cm_c = ops.flops_fwd(buf, k, thr)[1]
+                    cm_d = cm_c if cm_d is None else cm_d.add_(cm_c)
+                    s_c = ops.scores_csr_fwd(csr_all, buf, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, buf, pairs=False)
+                    sv[:, :, c, :].copy_(s_c.view(N * nq, N, -1))
+                cm_d.div_(len(gathered))
+                d_flops = (cm_d * cm_d).sum().reshape(1)
+                gathered = None
             else:
-                scores = s_r
+                s_r = ops.scores_csr_fwd(csr_all, d, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, d, pairs=False)
+                if N > 1:
+                    s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
+                    dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
+                    scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
+                else:
+                    scores = s_r
             ds_full, owned = None, False
             for kind, w, ibn, tau in losses:
                 if not ibn:
@@ -255,6 +289,14 @@ class _DistLossFn(torch.autograd.Function):
                 terms.append((l, float(w)))
                 ds_full = weighted(ds_full, g, w)
             ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous() if N > 1 else ds_full
+        if gathered is not None:  # no in-batch-negative loss consumed the chunks: the FLOPS column sums still need them
+            for buf, work in gathered:
+                work.wait()
+                cm_c = ops.flops_fwd(buf, k, thr)[1]
+                cm_d = cm_c if cm_d is None else cm_d.add_(cm_c)
+            cm_d.div_(len(gathered))
+            d_flops = (cm_d * cm_d).sum().reshape(1)
+            gathered = None
         lp_terms = []
         if any(not ibn for _, _, ibn, _ in losses):
             csr_loc = ops.row_compact(q, int(cap)) if cap else None

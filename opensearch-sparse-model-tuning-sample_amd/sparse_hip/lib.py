@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
 SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
-ABI_VERSION = 6  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
+ABI_VERSION = 7  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
 
 
 class SmDropout(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "sm_peak_mfma_bf16": [_p, _i, _i, _p],
     "sm_peak_copy": [_p, _p, C.c_size_t, _p],
     "sm_peak_lds_dma": [_p, C.c_size_t, _i, _i, _i, _i, _p, _p],
+    "sm_clock_stamp": [_p, _i, _p],
 }
 
 _lib = None

@@ -52,13 +52,17 @@ def test_cli_defaults_follow_the_measurement_protocol():
 
 @pytest.mark.gpu
 def test_bench_one_gpu_line():
-    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], timeout=420)
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], timeout=540)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     # the two records that ride beside `value` (round 5): the step at ~1 % live activations, configs[4]'s per-GPU shape on one GPU
     sr, c5 = j["sparse_regime"], j["c5_per_gpu"]
     assert "error" not in sr and 0.003 < sr["alive_fraction"] < 0.03 and sr["alive_fraction_random_init"] > 0.5 and sr["ms_per_step"] > 0, sr
     assert "error" not in c5 and c5["ms_per_step"] > 0 and c5["peak_memory_gib"] < 200, c5
+    # round 6: the same model and token count per step at the reference's shipped sequence lengths (config_infonce.yaml:9)
+    sw = j["seq_sweep"]
+    for key in ("seq256", "seq512"):
+        assert "error" not in sw[key] and sw[key]["finite"] and sw[key]["tokens_per_sec"] > 0.3 * sw["seq128"]["tokens_per_sec"], sw
     assert REQUIRED <= set(j), REQUIRED - set(j)
     assert j["n_gpus"] == 1 and j["steps"] == 4 and j["unit"] == "samples/sec" and j["dtype"] == "bf16" and j["vs_baseline"] is None
     assert abs(j["value"] - 32 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]
@@ -79,12 +83,16 @@ def test_bench_one_gpu_line():
 def test_bench_two_ranks_on_one_gpu_over_gloo():
     """the N > 1 launch contract (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, barrier + max over ranks, one line
     from rank 0); RCCL needs one GPU per rank, so on the single test GPU the transport is gloo (SM_BENCH_BACKEND)"""
-    env = dict(os.environ, SM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_FAULTHANDLER_S="90")
+    env = dict(os.environ, SM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_FAULTHANDLER_S="240")
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
               "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-              "--warmup", "1"], env=env)
+              "--warmup", "1"], env=env, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and j["scaling"] == "weak"
     assert "cpu_baseline" not in j and j["value"] > 0 and j["finite"] is True
-    assert j["dist"]["world_size"] == 2 and j["dist"]["backend"] == "gloo" and j["dist"]["exchange"] == "gather"  # self-describing N > 1 record
+    assert j["dist"]["world_size"] == 2 and j["dist"]["backend"] == "gloo" and j["dist"]["exchange"].startswith("gather (value)")  # self-describing N > 1 record
+    # both exchange modes in one command (round 6): `value` = north_star's all-gather of the representations, the score-block
+    # exchange beside it, each with its own liveness record
+    assert j["value_scores_exchange"] > 0 and j["ms_per_step_scores_exchange"] > 0 and j["value_gather_second_sample"] > 0
+    assert j["liveness"]["scores_exchange"]["finite"] is True

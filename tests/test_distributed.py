@@ -290,7 +290,9 @@ def _two_rank_case(tmp_path, case, backend, ports):
     r1 = _run([sys.executable, str(script), ROOT, PKG, one], env)
     assert r1.returncode == 0, r1.stdout + r1.stderr
     a = np.load(one)
-    for port, mode in zip(ports, ("gather", "scores")):
+    # "gather": the chunked all-gather consumed chunk by chunk inside one autograd node (the default); "gather_ref": the same
+    # exchange written as the reference writes it (gather_rep + the loss objects on the gathered batch); "scores": score blocks
+    for port, mode in zip((ports[0], ports[1], ports[0] + 500), ("gather", "scores", "gather_ref")):
         two = str(tmp_path / f"two_{mode}.npz")
         r2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                    "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two], dict(env, SM_EXCHANGE=mode))
@@ -316,7 +318,8 @@ def test_two_rank_gradients_match_the_reference_two_process_run(tmp_path, name):
     script = tmp_path / "worker.py"
     script.write_text(G7_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_TEST_CASE=name)
-    for port, mode in ((29561 if name == "infonce_ibn" else 29565, "gather"), (29563 if name == "infonce_ibn" else 29567, "scores")):
+    for port, mode in ((29561 if name == "infonce_ibn" else 29565, "gather"), (29563 if name == "infonce_ibn" else 29567, "scores"),
+                       (30061 if name == "infonce_ibn" else 30065, "gather_ref")):
         two = str(tmp_path / f"two_{mode}.npz")
         r2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                    "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, two], dict(env, SM_EXCHANGE=mode))
@@ -435,7 +438,7 @@ def test_four_and_eight_rank_steps_equal_the_single_process_step(tmp_path, world
     assert r1.returncode == 0, r1.stdout + r1.stderr
     a = np.load(one)
     base = 29600 + 10 * world + 2 * N_CASES[world].index(case)
-    for port, mode in ((base, "gather"), (base + 1, "scores")):
+    for port, mode in ((base, "gather"), (base + 1, "scores"), (base + 500, "gather_ref")):
         many = str(tmp_path / f"n_{mode}.npz")
         r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                   "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG, many], dict(env, SM_EXCHANGE=mode))
