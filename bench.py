@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--negs", type=int, default=15)
     ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--len-scale", type=float, default=None, help="document lengths ~N(80, 30) x this factor (the seq_sweep leg: seq / 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-roofline", action="store_true", help="skip the post-run per-GEMM timing steps")
     ap.add_argument("--no-extras", action="store_true", help="skip the sparse-regime leg and the configs[4] per-GPU-shape leg (N = 1 only)")
