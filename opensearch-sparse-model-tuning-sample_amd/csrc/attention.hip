@@ -15,6 +15,9 @@
 #ifndef ATTN_SKIP
 #define ATTN_SKIP 1
 #endif
+#ifndef ATTN_BWD_NW_LONG
+#define ATTN_BWD_NW_LONG 16  // waves per workgroup of the two-phase backward on paired heads (head dim 32) for documents > 128 tokens
+#endif
 
 namespace {
 
@@ -791,10 +794,15 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
     const size_t lds = fwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
     const bool tail = ATTN_SKIP && doc_off == nullptr;
-    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true, 4> : attn_fwd_kernel<T, DH, NKT, 2, true, false, 4>)
-                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true, 4> : attn_fwd_kernel<T, DH, NKT, 2, false, false, 4>);
+    // documents longer than 128 tokens (the reference's shipped max_seq_length 256 / 512, config_infonce.yaml:9): the pair's K / V images
+    // take 64 / 128 KiB, i.e. one or two workgroups per CU -- with 4 waves that was one wave per SIMD and nothing to overlap its
+    // QK^T -> softmax -> PV chain with (round 5 gave the head-dim-64 kernels 8 waves for the same reason; the paired head-dim-32
+    // path was left at 4)
+    constexpr int NWP = NKT >= 16 ? 8 : 4;
+    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true, NWP> : attn_fwd_kernel<T, DH, NKT, 2, true, false, NWP>)
+                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true, NWP> : attn_fwd_kernel<T, DH, NKT, 2, false, false, NWP>);
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
+    hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(64 * NWP), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
     return SM_OK;
   }
   const size_t lds = fwd_lds<T, DH, 1>(S);
@@ -830,6 +838,12 @@ int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* 
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = bwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
+    if (sizeof(T) == 2 && S > 128) {  // long documents: 16 waves share the pair's images (one workgroup per CU at S = 512)
+      auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 2, true, ATTN_BWD_NW_LONG> : attn_bwd_kernel<T, DH, 2, false, ATTN_BWD_NW_LONG>;
+      SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(64 * ATTN_BWD_NW_LONG), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);
+      return SM_OK;
+    }
     auto kern = d.thresh16 ? attn_bwd_kernel<T, DH, 2, true, 4> : attn_bwd_kernel<T, DH, 2, false, 4>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(256), lds, st, (const T*)qkv, km, (const T*)ctx, (const T*)dctx, lse, (T*)dqkv, S, A, d, doc_off);

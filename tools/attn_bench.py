@@ -6,7 +6,7 @@ if os.environ.get("SM_LIB"):
     _L._LIB_PATH = os.environ["SM_LIB"]
 from sparse_hip import ops, lib
 rng = np.random.default_rng(0)
-B, A, dh, S = 512, int(os.environ.get("A", 12)), int(os.environ.get("DH", 32)), int(os.environ.get("S", 128))
+B, A, dh, S = int(os.environ.get("B", 512)), int(os.environ.get("A", 12)), int(os.environ.get("DH", 32)), int(os.environ.get("S", 128))
 H = A * dh
 lens = np.clip(np.rint(rng.normal(80 * S / 128, 30 * S / 128, B)), 16, S).astype(np.int64)
 L16 = (lens + 15) // 16 * 16

@@ -3,9 +3,10 @@
 import ctypes as C, os, subprocess, sys, numpy as np, torch
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 csrc = os.path.join(root, "opensearch-sparse-model-tuning-sample_amd", "csrc")
-so = os.path.join(root, "tools", "_libpc_dbg.so")
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DPC_STAMPS", "-shared", "-o", so,
-                       os.path.join(csrc, "ffn_pc.hip"), os.path.join(csrc, "api.cpp")])
+defs = os.environ.get("PC_DEFS", "").split()
+so = os.path.join(root, "tools", "_libpc_bdbg" + ("_alt" if os.environ.get("PC_SRC") else "") + "".join(d.replace("-D", "_") for d in defs) + ".so")
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DPC_STAMPS", *defs, "-I", csrc, "-I", os.path.join(root, "include"), "-shared", "-o", so,
+                       os.environ.get("PC_SRC", os.path.join(csrc, "ffn_pc.hip")), os.path.join(csrc, "api.cpp")])
 sys.path.insert(0, os.path.join(root, "opensearch-sparse-model-tuning-sample_amd"))
 from sparse_hip import lib as L, ops
 dbg = C.CDLL(so)

@@ -7,10 +7,10 @@ root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 csrc = os.path.join(root, "opensearch-sparse-model-tuning-sample_amd", "csrc")
 # PC_DEFS="-DPC_X_NOGELU ...": timing experiments (the kernel's results are wrong with any of them; only the clock is read)
 defs = os.environ.get("PC_DEFS", "").split()
-so = os.path.join(root, "tools", "_libpc_dbg" + "".join(d.replace("-D", "_") for d in defs) + ".so")
+so = os.path.join(root, "tools", "_libpc_dbg" + ("_alt" if os.environ.get("PC_SRC") else "") + "".join(d.replace("-D", "_") for d in defs) + ".so")
 if not os.path.exists(so):
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DPC_STAMPS", *defs, "-shared", "-o", so,
-                           os.path.join(csrc, "ffn_pc.hip"), os.path.join(csrc, "api.cpp")])
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-DPC_STAMPS", *defs, "-I", csrc, "-I", os.path.join(root, "include"), "-shared", "-o", so,
+                           os.environ.get("PC_SRC", os.path.join(csrc, "ffn_pc.hip")), os.path.join(csrc, "api.cpp")])
 sys.path.insert(0, os.path.join(root, "opensearch-sparse-model-tuning-sample_amd"))
 from sparse_hip import lib as L, ops
 dbg = C.CDLL(so)
