@@ -139,7 +139,7 @@ class GemmRoofline:
     the kernel runs on; the weight-gradient GEMMs run on the side stream and share the GPU with the backward chain,
     exactly as in the measured step).  Reported per op: launches / step, executed FLOPs, achieved TFLOP/s in the step."""
 
-    MAX_STAMPS = 4096
+    MAX_STAMPS, STAMP_WORDS = 1024, 4096  # SM_CLOCK_STAMP_WORDS of include/sparse_hip.h: 2048 (XCD, CU) units x 2 words
 
     def __init__(self, ops):
         self.ops, self.rec, self.orig = ops, {}, {}
@@ -147,7 +147,7 @@ class GemmRoofline:
         # on the launch's own stream -> the clock the chip held under that kernel (the verdict's "clock as a measured quantity")
         from sparse_hip import lib as L
         self.L = L
-        self.stamps = torch.zeros(self.MAX_STAMPS * 16, dtype=torch.int64, device="cuda")
+        self.stamps = torch.zeros(self.MAX_STAMPS * self.STAMP_WORDS, dtype=torch.int64, device="cuda")
         self.nstamp = 0
         self.extra = set()
 
@@ -176,14 +176,15 @@ class GemmRoofline:
         setattr(self.ops, name, wrapped)
 
     def _clock_ghz(self, st, s0, s1):
-        """mean over the XCDs that both stamps saw of d(s_memtime) / d(s_memrealtime) x 100 MHz"""
+        """median over the compute units that both stamps reached of d(s_memtime) / d(s_memrealtime) x 100 MHz (counters of
+        different units are not aligned: only same-unit pairs are differenced)"""
         if s0 is None or s1 is None:
             return None
-        a, b = st[s0], st[s1]  # [8, 2]
-        ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1])
-        if not bool(ok.any()):
+        a, b = st[s0], st[s1]  # [2048 units, 2]
+        ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1]) & (b[:, 0] > a[:, 0])
+        if int(ok.sum()) < 8:
             return None
-        return float(((b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double()).mean() * 0.1)
+        return float(((b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double()).median() * 0.1)
 
     @staticmethod
     def _nt_label(A, B, *a, n=None, **k):
@@ -218,7 +219,7 @@ class GemmRoofline:
 
     def summary(self, steps, peak):
         out = []
-        st = self.stamps.cpu().view(self.MAX_STAMPS, 8, 2)
+        st = self.stamps.cpu().view(self.MAX_STAMPS, self.STAMP_WORDS // 2, 2)
         self.other = []
         for name, rec in self.rec.items():
             ms = sum(r[0].elapsed_time(r[1]) for r in rec)
@@ -751,7 +752,7 @@ def main():
                               "traffic": None, "gflop_per_step": fl, "ms_per_step": ms, "per_op": gemm_lines,
                               "other_kernels_clock": other_clock_lines,
                               "clock_how": "sm_clock_stamp before and after every launch on its stream: d(s_memtime) / d(s_memrealtime) x 100 MHz, "
-                                           "mean over the XCDs; in-step = both queues running; one_queue.per_op_clock_ghz = each kernel alone"}
+                                           "median over the compute units both stamps reached; in-step = both queues running; one_queue.per_op_clock_ghz = each kernel alone"}
         if args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
             tr, src, tgit, tk = latest_gemm_traffic(args.layout)
             result["roofline"].update({"traffic": tr, "traffic_unit": "bytes/step over all encoder GEMM launches (HBM-side reads x2-corrected "

@@ -387,12 +387,14 @@ int sm_peak_copy(const void* src, void* dst, size_t bytes, void* stream);
  * (global_load_lds, 16 bytes per lane, `depth` in flight per wave) from its workgroup's window of `span_per_block` bytes
  * into LDS.  Bytes moved = blocks * waves * iters * 1024.  waves in {1,2,4,8,16}, depth in {8,16,32}. */
 int sm_peak_lds_dma(const void* src, size_t span_per_block, int blocks, int waves, int depth, int iters, float* sink, void* stream);
-/* ABI 7 -- shader-clock stamp (bench.py / tools only): one tiny launch (32 workgroups of one wave) whose workgroups write, per XCD,
- * the pair (s_memtime, s_memrealtime) into out[slot][xcc = 0..7][2] (64-bit words, 16-byte store by one lane).  Two stamps
- * bracketing a kernel on its stream give the AVERAGE SHADER CLOCK the chip held under it, per XCD:
+/* ABI 7 -- shader-clock stamp (bench.py / tools only): one tiny launch (1024 workgroups of one wave) whose workgroups write, per
+ * compute unit they land on, the pair (s_memtime, s_memrealtime) into out[slot * SM_CLOCK_STAMP_WORDS + 2 * (xcc * 256 + HW_ID[15:8])]
+ * (64-bit words, one 16-byte store by one lane; `out` zeroed by the caller, SM_CLOCK_STAMP_WORDS words per slot).  Two stamps
+ * bracketing a kernel on its stream give the AVERAGE SHADER CLOCK the chip held under it: for every unit both stamps reached,
  * (memtime_after - memtime_before) / (memrealtime_after - memrealtime_before) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6, taken
- * around the kernel instead of inside it: no diagnostic build of the kernel itself is needed; the few microseconds between the
- * stamps and the kernel are inside the interval). */
+ * around the kernel instead of inside it: no diagnostic build of the kernel itself; the few microseconds between the stamps and
+ * the kernel are inside the interval).  Counters of different units are not aligned: never difference across units. */
+#define SM_CLOCK_STAMP_WORDS 4096
 int sm_clock_stamp(unsigned long long* out, int slot, void* stream);
 
 #ifdef __cplusplus

@@ -15,6 +15,9 @@
 #ifndef ATTN_SKIP
 #define ATTN_SKIP 1
 #endif
+#ifndef ATTN_BWD2
+#define ATTN_BWD2 1  // head dim 32, documents of 129 .. 512 tokens: the single-pass backward attn_bwd2_kernel (0: the two-phase kernel)
+#endif
 #ifndef ATTN_BWD_NW_LONG
 #define ATTN_BWD_NW_LONG 16  // waves per workgroup of the two-phase backward on paired heads (head dim 32) for documents > 128 tokens
 #endif
@@ -773,6 +776,209 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)(dq[qt][dt][r] * scale);
 }
+// ------------------------------------------------------------------------------------
+// Single-pass backward for documents of 129 .. 512 tokens at head dim 32 (bf16) -- the reference's shipped sequence lengths
+// (max_seq_length 256 / 512: config_infonce.yaml:9, config_l0.yaml:9, config_kd.yaml:9) on the v2-mini width.  attn_bwd1 above cannot
+// take them: one wave would hold dQ of up to 32 query tiles (256 registers).  The two-phase kernel evaluates every (query, key)
+// element twice and is bound by exactly that vector work (952 us per launch at 128 documents x 512 tokens, round 5's path).
+// Here ONE WORKGROUP of eight waves owns a (document, head); the QUERY tiles are dealt to the waves in pairs (wave w: pairs w, w + 8),
+// so a wave's dQ is at most 4 tiles = 32 registers, and every wave walks ALL key blocks in S orientation exactly as attn_bwd1 does
+// (exp, keep bit and dS of an element once; dS turned around through the wave's LDS patch for the dQ product).  What crosses
+// waves is dK / dV of the key block: each wave's partial [16 keys x 32] tiles (16 registers) go to a double-buffered LDS
+// area, ONE barrier per key block, then the eight partials are summed in a fixed order by the lanes that store them (no atomics:
+// bit-reproducible).  K / V fragments of a block come straight from global memory (L2: all eight waves and the neighbouring head's
+// workgroup read the same rows); Q and dO share one 128-byte-row XOR-swizzled image (Q in bytes 0-63, dO in 64-127: the conflict-free
+// layout of the paired-head kernels).  LDS at S = 512: 64 KiB image + 64 KiB partials + 9 KiB = one workgroup per CU, two waves per SIMD.
+template <int NPW, bool DROP, bool TAIL>  // NPW: query-tile pairs per wave (1: S <= 256, 2: S <= 512)
+__global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+                                                        const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int S, int A, DropCfg drop,
+                                                        const int32_t* __restrict__ doc_off) {
+  using T = bf16;
+  constexpr int DH = 32, NW = 8, RS = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  const int H = A * DH;
+  const size_t ld = 3 * (size_t)H;
+  const int b = blockIdx.x / A, h = blockIdx.x % A;
+  const int row0 = doc_off ? doc_off[b] : b * S;
+  const int Lr = doc_off ? doc_off[b + 1] - row0 : S;
+  const int nblk = Lr / 16;
+  const int nt = (nblk + 1) & ~1;
+  char* sQD = smem;                                             // [S][Q 64 B | dO 64 B], swizzled
+  float* sLse = reinterpret_cast<float*>(sQD + (size_t)S * RS);  // [S], log2 domain
+  float* sDelta = sLse + S;                                      // [S]
+  f32x4* sRed = reinterpret_cast<f32x4*>(sDelta + S);            // [2 parities][8 waves][4 vectors][64 lanes]
+  char* sPatch0 = reinterpret_cast<char*>(sRed + 2 * NW * 4 * 64);  // [8 waves][16 keys][16 queries] bf16
+  uint8_t* sM = reinterpret_cast<uint8_t*>(sPatch0 + NW * 512);
+  const T* base = qkv + (size_t)row0 * ld + h * DH;
+  const T* dob = dctx + (size_t)row0 * H + h * DH;
+  const T* ob = ctx + (size_t)row0 * H + h * DH;
+  __shared__ int s_lastw[NW];
+  {
+    // Q, dO -> the shared image, delta = rowsum(dO . O): a thread stages chunk (row, c) of Q and of dO and loads the same chunk of O;
+    // the four 16-byte chunks of a head's row sit in adjacent lanes
+    constexpr int MAXIT = 2 * NPW;  // S * 4 chunks / 512 threads
+    uint4 vq[MAXIT], vd[MAXIT], vo[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * 512, r = idx >> 2, c = idx & 3;
+      const bool live = r < Lr;
+      vq[it] = live ? *reinterpret_cast<const uint4*>(base + (size_t)r * ld + c * 8) : make_uint4(0, 0, 0, 0);
+      vd[it] = live ? *reinterpret_cast<const uint4*>(dob + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
+      vo[it] = live ? *reinterpret_cast<const uint4*>(ob + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+    int mylast = -1;
+    for (int i0 = 0; i0 < nt * 16; i0 += 512) {
+      const int i = i0 + threadIdx.x;
+      const bool on = i < nt * 16 && i < Lr && keymask[(size_t)row0 + i] != 0;
+      if constexpr (TAIL) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+        if (m != 0) mylast = i0 + (int)(threadIdx.x & ~63u) + 63 - __builtin_clzll(m);
+      }
+      if (i >= nt * 16) continue;
+      sM[i] = on ? 1 : 0;
+      sLse[i] = i < Lr ? lse[(size_t)(b * A + h) * S + i] * 1.4426950408889634f : 0.f;
+    }
+    if (TAIL && (threadIdx.x & 63) == 0) s_lastw[threadIdx.x >> 6] = mylast;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int idx = threadIdx.x + it * 512, r = idx >> 2, c = idx & 3;
+      const T* ea = reinterpret_cast<const T*>(&vd[it]);
+      const T* eo = reinterpret_cast<const T*>(&vo[it]);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)ea[j] * (float)eo[j];
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if (r < nt * 16) {
+        *reinterpret_cast<uint4*>(sQD + img_off<true>(r, RS, c * 16)) = vq[it];
+        *reinterpret_cast<uint4*>(sQD + img_off<true>(r, RS, 64 + c * 16)) = vd[it];
+        if (c == 0) sDelta[r] = d;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  const float scale = rsqrtf((float)DH), scale2 = scale * 1.4426950408889634f;
+  const Drop8 d8(drop);
+  T* dq_out = dqkv + (size_t)row0 * ld + h * DH;
+  char* patch = sPatch0 + w * 512;
+  char* patch_w = patch + li * 32 + ((g ^ ((li >> 3) << 1)) * 8);
+  const int prow = 4 * g + (li >> 2);
+  const lds_v4* patch_r = (const lds_v4*)(patch + prow * 32 + (((li & 3) ^ ((prow >> 3) << 1)) * 8));
+  const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+  f32x4 dq[NPW][2][2];
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+    for (int hh2 = 0; hh2 < 2; ++hh2)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[pi][hh2][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nblk_on = nblk;
+  if constexpr (TAIL) {
+    int s_last = -1;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s_last = max(s_last, s_lastw[i]);
+    nblk_on = min(nblk, (s_last >> 4) + 1);
+  }
+  // key blocks behind the last attended key: dK = dV = 0 (one 8-byte store per thread and 128 bytes of a row)
+  for (int idx = nblk_on * 16 * 16 + threadIdx.x; idx < nblk * 16 * 16; idx += 512) {
+    const int key = idx >> 4, c = idx & 15;  // 16 pieces of 4 columns: 8 of dK, 8 of dV
+    store4<T>(dq_out + (size_t)key * ld + (c < 8 ? H : 2 * H) + (c & 7) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+  const int rvec = w >> 1;                       // the vector this wave's active half sums: 0, 1 = dK tiles, 2, 3 = dV tiles
+  const bool ractive = (lane >> 5) == (w & 1);
+  for (int kb = 0; kb < nblk_on; ++kb) {
+    const int key = kb * 16 + li;
+    const bf16x8 fk = grow_frag<T>(base + H, ld, key, 0, g), fv = grow_frag<T>(base + 2 * H, ld, key, 0, g);
+    s16x4 kB[2];  // B operand of the dQ product: K[key = kb*16 + 4g + r][d = dt*16 + li]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kB[dt][r] = *reinterpret_cast<const short*>(base + H + (size_t)(kb * 16 + 4 * g + r) * ld + dt * 16 + li);
+    const bool kvalid = sM[key] != 0;
+    f32x4 dv[2], dk[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int pi = 0; pi < NPW; ++pi) {
+      const int t2 = w + NW * pi;
+      if (2 * t2 < nt) {
+        bf16x4 pd[2], ds[2];
+#pragma unroll
+        for (int hh2 = 0; hh2 < 2; ++hh2) {
+          const int qt = 2 * t2 + hh2;
+          bf16x8 fkk[1] = {fk}, fvv[1] = {fv};
+          const f32x4 sv = dh_product<T, DH, true>(sQD, RS, 0, qt * 16 + li, g, fkk);
+          const f32x4 dp = dh_product<T, DH, true>(sQD, RS, 64, qt * 16 + li, g, fvv);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + 4 * g);
+          uint32_t hq[2] = {0u, 0u};
+          if constexpr (DROP) {
+            const uint32_t blk = (uint32_t)((qt * 8 + 2 * g) * (S >> 1) + (key >> 1));
+            hq[0] = drop_block_hash(ukey, blk);
+            hq[1] = drop_block_hash(ukey, blk + (uint32_t)(S >> 1));
+          }
+          f32x4 pdv, dsv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = kvalid ? __builtin_amdgcn_exp2f(fmaf(sv[r], scale2, -l4[r])) : 0.f;
+            float keepf = 1.f;
+            if constexpr (DROP) keepf = drop_keep_byte(hq[r >> 1], 16u * (r & 1) + 8u * (li & 1), d8.th8) ? d8.scale : 0.f;
+            pdv[r] = pv * keepf;
+            dsv[r] = pv * (dp[r] * keepf - d4[r]);  // (the 1/sqrt(dh) factor of dS is applied to dQ and dK when they are stored)
+          }
+          pd[hh2] = PT<T>::pack(pdv);
+          ds[hh2] = PT<T>::pack(dsv);
+          *reinterpret_cast<bf16x4*>(patch_w) = ds[hh2];
+          const s16x4 dsT = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)patch_r);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) dq[pi][hh2][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, kB[dt], dq[pi][hh2][dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = SeqPair<T, true>::acc(dv[dt], sQD, RS, 64, dt * 16, g, li, pd[0], pd[1], t2);
+          dk[dt] = SeqPair<T, true>::acc(dk[dt], sQD, RS, 0, dt * 16, g, li, ds[0], ds[1], t2);
+        }
+      }
+    }
+    // the wave's partial dK / dV tiles of this key block -> sRed[kb & 1][w][vector][lane]; one barrier; fixed-order sum and store
+    f32x4* mine = sRed + (((kb & 1) * NW + w) * 4) * 64 + lane;
+    mine[0] = dk[0];
+    mine[64] = dk[1];
+    mine[128] = dv[0];
+    mine[192] = dv[1];
+    __syncthreads();
+    if (ractive) {
+      const f32x4* src = sRed + (((kb & 1) * NW) * 4 + rvec) * 64 + lane;
+      f32x4 sum = src[0];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) sum += src[ww * 4 * 64];
+      const bool isk = rvec < 2;
+      store4<T>(dq_out + (size_t)key * ld + (isk ? H : 2 * H) + (rvec & 1) * 16 + 4 * g, isk ? sum * scale : sum);
+    }
+  }
+  // dQ accumulators: rows = queries 4g + r, col = d = li
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+    for (int hh2 = 0; hh2 < 2; ++hh2) {
+      const int qt = 2 * (w + NW * pi) + hh2;
+      if (qt < nblk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)(dq[pi][hh2][dt][r] * scale);
+    }
+}
+size_t bwd2_lds(int S) { return (size_t)S * 128 + 8 * (size_t)S + 2 * 8 * 4 * 64 * 16 + 8 * 512 + S; }
+
 template <int DH, int HP>
 size_t bwd1_lds(int S) { return 2 * (size_t)S * Lay<bf16, HP * DH>::RS + HP * 8 * (size_t)S + HP * 512 + S; }
 
@@ -829,11 +1035,26 @@ int launch_bwd1(const void* qkv, const uint8_t* km, const void* ctx, const void*
   return SM_OK;
 }
 
+template <int NPW>
+int launch_bwd2(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
+  const size_t lds = bwd2_lds(S);
+  const bool tail = ATTN_SKIP && doc_off == nullptr;
+  auto kern = d.thresh16 ? (tail ? attn_bwd2_kernel<NPW, true, true> : attn_bwd2_kernel<NPW, true, false>)
+                         : (tail ? attn_bwd2_kernel<NPW, false, true> : attn_bwd2_kernel<NPW, false, false>);
+  SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(512), lds, st, (const bf16*)qkv, km, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, S, A, d, doc_off);
+  return SM_OK;
+}
+
 template <typename T, int DH>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
   if constexpr (sizeof(T) == 2 && DH == 32) {  // single pass: dQ of 8 query tiles in registers
     if (S <= 128 && pair_heads<T, DH>(A, S)) return launch_bwd1<DH, 2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
+    // longer documents: single pass with the query tiles dealt to the eight waves of a (document, head) workgroup
+    if (ATTN_BWD2 && S > 128 && S <= 512) return S <= 256 ? launch_bwd2<1>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
+                                                          : launch_bwd2<2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
   }
   if (pair_heads<T, DH>(A, S)) {
     const size_t lds = bwd_lds<T, DH, 2>(S);

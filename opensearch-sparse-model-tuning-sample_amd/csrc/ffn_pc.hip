@@ -87,23 +87,19 @@ template <int I, int N, typename F> __device__ __forceinline__ void pc_static_fo
 // 24 MFMAs of one chunk: fragment k (1 KiB at `base` + 1024 k), PC_D reads in flight; `apply(k, frag)` issues the MFMA,
 // `hook(k)` runs behind it (the consumer puts one LDS-DMA piece behind every second MFMA: an LDS-DMA instruction blocks its wave
 // for ~80 cycles, during which the MFMA just issued and the partner wave keep the matrix pipe busy)
-// EVEN_FIRST: the pieces are streamed in the order 0, 2, .., 22, 1, 3, .., 23 (position i -> piece pc_piece<true>(i)): for a
-// [12 tiles][2 k-steps] operand, all first k-steps before any second one -- the forward's consumer needs the second k-step's B
-// fragment (the half of the GELU it computes itself) only from position 12 on
-template <bool EVEN_FIRST> constexpr int pc_piece(int i) { return EVEN_FIRST ? (i < 12 ? 2 * i : 2 * (i - 12) + 1) : i; }
-template <typename V, bool EVEN_FIRST = false, typename Apply, typename Hook>
+template <typename V, typename Apply, typename Hook>
 __device__ __forceinline__ void pc_stream24(uint32_t base, Apply&& apply, Hook&& hook) {
   V frag[PC_RING];
   pc_static_for<0, PC_D>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
-    frag[j % PC_RING] = pc_lds_read<V, pc_piece<EVEN_FIRST>(j) * 1024>(base);
+    frag[j % PC_RING] = pc_lds_read<V, j * 1024>(base);
   });
   pc_static_for<0, 24>([&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value, j = k + PC_D;
 #ifdef PC_X_NOLDS  // timing experiments (tools/ffn_pc_stamps.py): results are wrong with any PC_X_* switch
     if constexpr (j < 24) asm volatile("" : "=v"(frag[j % PC_RING]));
 #else
-    if constexpr (j < 24) frag[j % PC_RING] = pc_lds_read<V, pc_piece<EVEN_FIRST>(j < 24 ? j : 0) * 1024>(base);
+    if constexpr (j < 24) frag[j % PC_RING] = pc_lds_read<V, j * 1024>(base);
 #endif
     constexpr int ahead = 23 - k < PC_D ? 23 - k : PC_D;
     pc_wait_frag<ahead>(frag[k % PC_RING]);
@@ -162,7 +158,6 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
   PC_STAMP(w >> 2, 0);
 
-#ifdef PC_PROLOGUE16  // the 16-lanes-per-row prologue of rounds 3-5, kept for same-box A/B runs (tools/ffn_pc_stamps.py, PC_DEFS)
   // ---------------------------------------------------------------- prologue: LayerNorm 1 by all eight waves, row-major and
   // coalesced (16 lanes per row, 3 chunks of 8 columns per lane); x1 goes to memory in bf16 (operand of the W1 weight gradient)
   // and, in the operand type, into LDS in the producers' B-fragment order ((group, k-step, lane) -> 16 bytes)
@@ -223,79 +218,6 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
       if (live && sl == 0) { a.m1[grow] = mu; a.r1[grow] = rs; }
     }
   }
-#else
-  // ---------------------------------------------------------------- prologue: LayerNorm 1 by all eight waves, row-major.  Lane =
-  // (token tl = lane & 7, chunk group cg = lane >> 3): a wave covers 8 rows x 8 chunks of 8 columns per load instruction (per row
-  // 8 pieces of 16 bytes at a 32-byte stride, both halves of a chunk by consecutive instructions: whole 128-byte lines), 6 chunks
-  // per lane and row.  The EIGHT CONSECUTIVE LANES of a ds_write_b128 lane group hold 8 consecutive tokens of ONE chunk, i.e. 128
-  // contiguous bytes of the producers' B-fragment image ((group, k-step, lane) -> 16 bytes): conflict free.  (Rounds 3-5 had 16
-  // lanes per row: the 8 lanes of a group then wrote 8 different k-steps of one token, 512 bytes apart -- the same four banks,
-  // 8-way, 12 writes per lane -- most of the kernel's SQ_LDS_BANK_CONFLICT.)  x1 goes to memory in bf16 (operand of the W1 weight
-  // gradient) and, in the operand type, into LDS.
-  {
-    const int tl = lane & 7, cg = lane >> 3;
-    // both row groups' z1 reads are in flight before the first is used (96 registers that nothing else needs yet): one read
-    // latency (~4 k cycles) for the prologue instead of two
-    f32x4 zin[2][6][2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const float* zr = a.z1 + (size_t)min(blk_row0 + it * 64 + w * 8 + tl, T - 1) * PC_H;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        zin[it][i][0] = *reinterpret_cast<const f32x4*>(zr + (cg + 8 * i) * 8);
-        zin[it][i][1] = *reinterpret_cast<const f32x4*>(zr + (cg + 8 * i) * 8 + 4);
-      }
-    }
-    auto row_sum = [](float v) __attribute__((always_inline)) {  // over the 8 lanes of a row: lane bits 3, 4, 5
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      return v;
-    };
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int rl = it * 64 + w * 8 + tl, grow = blk_row0 + rl;
-      const bool live = grow < T;
-      float v[6][8];
-      float s1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const f32x4 lo = zin[it][i][0], hi = zin[it][i][1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[i][k] = lo[k]; v[i][4 + k] = hi[k]; s1 += lo[k] + hi[k]; }
-      }
-      const float mu = row_sum(s1) * (1.f / PC_H);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
-      const float rs = rsqrtf(row_sum(q) * (1.f / PC_H) + a.eps);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int ch = cg + 8 * i, c0 = ch * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0), g1 = *reinterpret_cast<const f32x4*>(a.ln1_g + c0 + 4);
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0), e1 = *reinterpret_cast<const f32x4*>(a.ln1_b + c0 + 4);
-        float o[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          o[k] = (v[i][k] - mu) * rs * g0[k] + e0[k];
-          o[4 + k] = (v[i][4 + k] - mu) * rs * g1[k] + e1[k];
-        }
-        if (live) {
-          bf16x8 xo;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) xo[k] = (bf16)o[k];
-          *reinterpret_cast<bf16x8*>(a.x1 + (size_t)grow * PC_H + c0) = xo;
-        }
-        // chunk ch = k-step ch >> 1, lane half ch & 1 of token rl & 31 of group rl >> 5
-        const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
-        pc_lds_write<V>(fa, OP::pack(o));
-      }
-      if (live && cg == 0) { a.m1[grow] = mu; a.r1[grow] = rs; }
-    }
-  }
-#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // A: the B fragments of all four groups are in LDS
   asm volatile("" ::: "memory");
@@ -457,58 +379,23 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
       if (u < 6) dma(w2f + (size_t)min(st + 1, NC - 1) * PC_CHUNK + u * 1024, d2 + ((st + 1) % 3) * PC_CHUNK + u * 1024);
       else dma(w1f + (size_t)min(st + 3, NC - 1) * PC_CHUNK + (u - 6) * 1024, d1 + (st % 3) * PC_CHUNK + (u - 6) * 1024);
     };
-    // Round 6: the GELU of a chunk is SPLIT between the two waves of the pair.  The stamps of round 5 (profiles/r6_ffn_stamps.txt)
-    // had the consumer finished 0.4-0.6 k cycles of every 2.55 k-cycle step before its producer: the producer's instruction
-    // stream (299 instructions per step, 150 of them the GELU of 16 elements per lane) was the pair's critical path while this wave's
-    // vector pipe idled behind its LDS-DMA.  The producer now finishes accumulator registers 0-7 (the B fragment of the first
-    // k-step) and hands registers 8-15 over RAW (pre-activation, in the operand type: 16 bytes per lane, the slot the second
-    // fragment had); this wave applies the GELU to them behind the twelve first-k-step MFMAs (streamed first: pc_piece) and has
-    // its own second fragment by the thirteenth.  In fp16 mode the pre-activation is rounded to fp16 before the GELU instead of
-    // the GELU's value after it: the same 2^-11 once either way (bf16 mode: the GELU of the bf16 f1 the backward reads).
-    float c_o[8], c_x2 = 0.f, c_p = 0.f, c_u = 0.f, c_d = 1.f;
     auto gemm2 = [&](int c, int st) __attribute__((always_inline)) {  // st < 0: no refill
       const uint32_t gb = lbase + PC_G_OFF + (uint32_t)(((c & 1) * 4 + t) * 2048);
-      V g0 = pc_lds_read<V, 0>(gb), xr = pc_lds_read<V, 1024>(gb);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(xr) : : "memory");
-      float xf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = (float)xr[j];
-      V g1;
-      pc_stream24<V, true>(lbase + PC_W2_OFF + (uint32_t)((c % 3) * PC_CHUNK),
+      V g0 = pc_lds_read<V, 0>(gb), g1 = pc_lds_read<V, 1024>(gb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0), "+v"(g1) : : "memory");
+      pc_stream24<V>(lbase + PC_W2_OFF + (uint32_t)((c % 3) * PC_CHUNK),
                      [&](auto kc, V fr) __attribute__((always_inline)) {
-                       constexpr int pc = pc_piece<true>(decltype(kc)::value);
+                       constexpr int k = decltype(kc)::value;
 #ifdef PC_X_NOCMFMA
-                       pc_touch(acc[pc >> 1], fr);
+                       pc_touch(acc[k >> 1], fr);
 #else
-                       acc[pc >> 1] = OP::mma(fr, (pc & 1) ? g1 : g0, acc[pc >> 1]);
+                       acc[k >> 1] = OP::mma(fr, (k & 1) ? g1 : g0, acc[k >> 1]);
 #endif
                      },
                      [&](auto kc) __attribute__((always_inline)) {
                        constexpr int k = decltype(kc)::value;
-                       // the sigmoid-form GELU (gelu_sig of common.h) of element e in four stages over gaps e .. e + 3, as in the producer
-                       if constexpr (k >= 3 && k <= 10) {
-                         c_o[k - 3] = xf[k - 3] * __builtin_amdgcn_rcpf(c_d);
-                         asm volatile("" : "+v"(c_o[k - 3]));
-                       }
-                       if constexpr (k >= 2 && k <= 9) {
-                         c_d = 1.0f + __builtin_amdgcn_exp2f(c_u);
-                         asm volatile("" : "+v"(c_d));
-                       }
-                       if constexpr (k >= 1 && k <= 8) {
-                         c_u = xf[k - 1] * fmaf(c_p, c_x2, -2.30112135f);
-                         asm volatile("" : "+v"(c_u));
-                       }
-                       if constexpr (k < 8) {
-                         c_x2 = fminf(xf[k] * xf[k], 81.0f);
-                         c_p = fmaf(c_x2, 1.01426436e-3f, -1.06775740e-1f);
-                         asm volatile("" : "+v"(c_x2), "+v"(c_p));
-                       }
-                       if constexpr (k == 11) {
-                         g1 = OP::pack(c_o);
-                         asm volatile("" : "+v"(g1));
-                       }
-                       if constexpr (k & 1) {  // a piece behind every second MFMA: all twelve of the step
-                         if (st >= 0) piece(st, k >> 1);
+                       if constexpr (k & 1) {  // a piece behind every second MFMA: all twelve of the step (the producer wave is
+                         if (st >= 0) piece(st, k >> 1);  // the issue-bound one of the pair)
                        }
                      });
     };
@@ -611,39 +498,38 @@ __global__ __launch_bounds__(512) void ffn_pc_fwd_kernel(FfnPcFwdArgs a) {
   auto fin_piece = [&](auto kc, const f32x16& X, int c) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
 #ifdef PC_X_NOGELU
-    if constexpr (k < 8) o[k] = X[k];
+    if constexpr (k < 16) o[k] = X[k];
 #else
     // (an empty volatile statement per result: the optimiser would otherwise sink the whole GELU to its first use, behind the
     //  last MFMA -- sched_barrier only binds the machine scheduler)
-    // (round 6: elements 0-7 only -- the consumer applies the GELU to registers 8-15 itself, see its gemm2)
-    if constexpr (k >= 3 && k <= 10) {
+    if constexpr (k >= 3 && k <= 18) {
       o[k - 3] = X[k - 3] * __builtin_amdgcn_rcpf(c_d);
       asm volatile("" : "+v"(o[k - 3]));
     }
-    if constexpr (k >= 2 && k <= 9) {
+    if constexpr (k >= 2 && k <= 17) {
       c_d = 1.0f + __builtin_amdgcn_exp2f(b_u);
       asm volatile("" : "+v"(c_d));
     }
-    if constexpr (k >= 1 && k <= 8) {
+    if constexpr (k >= 1 && k <= 16) {
       b_u = X[k - 1] * fmaf(a_p, a_x2, -2.30112135f);  // -(x (c0 + c1 x^2 + c2 x^4)) log2(e): gelu_sig of common.h
       asm volatile("" : "+v"(b_u));
     }
-    if constexpr (k < 8) {
+    if constexpr (k < 16) {
       a_x2 = fminf(X[k] * X[k], 81.0f);
       a_p = fmaf(a_x2, 1.01426436e-3f, -1.06775740e-1f);
       asm volatile("" : "+v"(a_x2), "+v"(a_p));
     }
 #endif
-    if constexpr (k == 11) {
+    if constexpr (k == 19) {
       float lo8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) lo8[j] = o[j];
       glo = OP::pack(lo8);
       asm volatile("" : "+v"(glo));
-    } else if constexpr (k == 12) {  // registers 8-15 RAW in the operand type: the consumer's half of the GELU
+    } else if constexpr (k == 20) {
       float hi8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hi8[j] = X[8 + j];
+      for (int j = 0; j < 8; ++j) hi8[j] = o[8 + j];
       ghi = OP::pack(hi8);
       asm volatile("" : "+v"(ghi));
     } else if constexpr (k == 21 || k == 22) {
@@ -763,7 +649,6 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
   const uint32_t lbase = lds0 + (uint32_t)(lane * 16);
   PC_STAMP(w >> 2, 0);
 
-#ifdef PC_PROLOGUE16
   // ---- prologue: dy rows of the workgroup -> the producers' B-fragment order in LDS (row-major, coalesced 16-byte loads) ----
   {
     const int sl = lane & 15, sub = lane >> 4;
@@ -785,31 +670,6 @@ __global__ __launch_bounds__(512) void ffn_pc_bwd_kernel(FfnPcBwdArgs a) {
       }
     }
   }
-#else
-  // ---- prologue: dy rows of the workgroup -> the producers' B-fragment order in LDS.  Lane = (token lane & 7, chunk group
-  //      lane >> 3) as in the forward: the 8 lanes of a ds_write_b128 lane group write 8 consecutive tokens of one chunk = 128
-  //      contiguous bytes of the image (conflict free; 16 lanes per row wrote 8 k-steps of one token, 8-way) ----
-  {
-    const int tl = lane & 7, cg = lane >> 3;
-    bf16x8 din[2][6];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const bf16* dr = a.dy + (size_t)min(blk_row0 + it * 64 + w * 8 + tl, T - 1) * PC_H;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) din[it][i] = *reinterpret_cast<const bf16x8*>(dr + (cg + 8 * i) * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int rl = it * 64 + w * 8 + tl;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int ch = cg + 8 * i;
-        const uint32_t fa = lds0 + (uint32_t)(((((rl >> 5) * PC_KS + (ch >> 1)) * 64) + (ch & 1) * 32 + (rl & 31)) * 16);
-        pc_lds_write<V>(fa, din[it][i]);
-      }
-    }
-  }
-#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // A
   asm volatile("" ::: "memory");

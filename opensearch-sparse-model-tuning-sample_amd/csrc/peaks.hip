@@ -73,21 +73,25 @@ __global__ __launch_bounds__(WAVES * 64) void peak_lds_dma_kernel(const char* __
   if (v == 123.456f) sink[threadIdx.x & 1023] = v;
 }
 
-// (s_memtime, s_memrealtime) of the XCD this workgroup landed on -> out[xcc][0..1], one 16-byte store by lane 0
+// (s_memtime, s_memrealtime) of the CU this workgroup landed on -> out[xcc * 256 + HW_ID[15:8]] (HW_ID bits 15:8 = CU, shader array and
+// shader engine), one 16-byte store by lane 0.  The first version of this kernel indexed by XCD only and produced garbage (negative
+// and 20 GHz "clocks"): s_memtime counters of different CUs / shader engines are not mutually aligned, so a pair of stamps is only
+// meaningful when both come from the SAME unit -- the host side takes the median over the units both stamps reached.
 __global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* __restrict__ out) {
   if (threadIdx.x != 0) return;
-  uint32_t xcc;
+  uint32_t xcc, hwid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
   const unsigned long long mt = __builtin_amdgcn_s_memtime(), rt = __builtin_amdgcn_s_memrealtime();
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<u64x2*>(out + 2 * (xcc & 7u)) = u64x2{mt, rt};
+  *reinterpret_cast<u64x2*>(out + 2 * ((xcc & 7u) * 256u + ((hwid >> 8) & 255u))) = u64x2{mt, rt};
 }
 
 }  // namespace
 
 extern "C" int sm_clock_stamp(unsigned long long* out, int slot, void* stream) {
   SM_REQUIRE(out != nullptr && slot >= 0 && ((uintptr_t)out % 16) == 0, "sm_clock_stamp: bad arguments");
-  hipLaunchKernelGGL(clock_stamp_kernel, dim3(32), dim3(64), 0, (hipStream_t)stream, out + (size_t)slot * 16);
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1024), dim3(64), 0, (hipStream_t)stream, out + (size_t)slot * SM_CLOCK_STAMP_WORDS);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

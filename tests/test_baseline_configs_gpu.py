@@ -465,6 +465,18 @@ def test_c2_slice_with_every_dropout_site_on_as_in_the_bench_step(varlen):
                   hidden_dropout=0.1, attn_dropout=0.1, varlen=varlen)
 
 
+@pytest.mark.parametrize("S,nq,varlen", [(256, 2, True), (256, 2, False), (512, 1, True), (512, 1, False), (384, 1, True)])
+def test_c2_model_at_the_shipped_sequence_lengths_with_every_dropout_site_on(S, nq, varlen):
+    """configs[1]'s model and recipe at the sequence lengths the reference's recipes ship with (max_seq_length 256 / 512 and
+    longest-in-batch padding in between: config_infonce.yaml:9, config_l0.yaml:9, config_kd.yaml:9; collator.py:158-175), every dropout
+    site on with the device's masks fed to the oracle: nq queries x 8 documents of up to S tokens.  These shapes take the kernels
+    round 6 added for them -- the vocabulary-stationary head forward with 9 position bits, the long-document attention forward with
+    8 waves per workgroup and the SINGLE-PASS attention backward attn_bwd2_kernel (its keep bits must be the forward's: a wrong bit
+    shows up as an O(1) error in the gradients) -- outputs, loss, routed and un-routed gradients as at S = 128."""
+    _student_step(MINI, torch.bfloat16, nq=nq, k=8, S=S, Sq=32, recipe=INFONCE, seed=21 + S // 128, hidden_dropout=0.1, attn_dropout=0.1,
+                  varlen=varlen, what=f"c2 model at seq {S}, all dropout sites 0.1, varlen={varlen}")
+
+
 @pytest.mark.parametrize("varlen,scatter", [(True, False), (True, True), (False, True)])
 def test_c2_slice_at_trained_checkpoint_statistics(varlen, scatter):
     """config_infonce.yaml:5 fine-tunes a TRAINED sparse encoder: outlier hidden dimensions (x20), LayerNorm gains up to 5, about

@@ -1,6 +1,6 @@
 """profiles/rN_clocks.txt from a bench line: the shader clock the chip held under every matrix-pipe kernel class of the step
 (roofline.per_op[*].clock_ghz: sm_clock_stamp before and after each launch on its stream, d(s_memtime) / d(s_memrealtime) x 100 MHz,
-mean over the XCDs), in the step (both queues running) and alone (weight gradients on the main queue).
+median over the compute units both stamps reached), in the step (both queues running) and alone (weight gradients on the main queue).
     python tools/clocks_report.py gpurun_out/r6/bench2.json > profiles/r6_clocks.txt"""
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
