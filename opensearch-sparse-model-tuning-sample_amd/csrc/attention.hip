@@ -18,6 +18,9 @@
 #ifndef ATTN_BWD2
 #define ATTN_BWD2 1  // head dim 32, documents of 129 .. 512 tokens: the single-pass backward attn_bwd2_kernel (0: the two-phase kernel)
 #endif
+#ifndef ATTN_BWD2_MIN_S
+#define ATTN_BWD2_MIN_S 128  // ... for documents longer than this (set from the A/B run)
+#endif
 #ifndef ATTN_BWD_NW_LONG
 #define ATTN_BWD_NW_LONG 16  // waves per workgroup of the two-phase backward on paired heads (head dim 32) for documents > 128 tokens
 #endif
@@ -891,14 +894,25 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__
   }
   const int rvec = w >> 1;                       // the vector this wave's active half sums: 0, 1 = dK tiles, 2, 3 = dV tiles
   const bool ractive = (lane >> 5) == (w & 1);
+  // the K / V operands of a key block are fetched ONE BLOCK AHEAD (global memory, L2): used where they are loaded, every wave paid a
+  // full L2 round trip per key block with one other wave on its SIMD to cover it
+  bf16x8 fk_n, fv_n;
+  s16x4 kB_n[2];
+  auto fetch_kv = [&](int kb) __attribute__((always_inline)) {
+    const int kbs = min(kb, max(nblk - 1, 0));  // (past the end: the last block again, never used)
+    fk_n = grow_frag<T>(base + H, ld, kbs * 16 + li, 0, g);
+    fv_n = grow_frag<T>(base + 2 * H, ld, kbs * 16 + li, 0, g);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)  // B operand of the dQ product: K[key = kb*16 + 4g + r][d = dt*16 + li]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kB_n[dt][r] = *reinterpret_cast<const short*>(base + H + (size_t)(kbs * 16 + 4 * g + r) * ld + dt * 16 + li);
+  };
+  fetch_kv(0);
   for (int kb = 0; kb < nblk_on; ++kb) {
     const int key = kb * 16 + li;
-    const bf16x8 fk = grow_frag<T>(base + H, ld, key, 0, g), fv = grow_frag<T>(base + 2 * H, ld, key, 0, g);
-    s16x4 kB[2];  // B operand of the dQ product: K[key = kb*16 + 4g + r][d = dt*16 + li]
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) kB[dt][r] = *reinterpret_cast<const short*>(base + H + (size_t)(kb * 16 + 4 * g + r) * ld + dt * 16 + li);
+    const bf16x8 fk = fk_n, fv = fv_n;
+    const s16x4 kB[2] = {kB_n[0], kB_n[1]};
+    fetch_kv(kb + 1);
     const bool kvalid = sM[key] != 0;
     f32x4 dv[2], dk[2];
 #pragma unroll
@@ -996,7 +1010,7 @@ constexpr size_t LDS_MAX = 160 * 1024;
 template <typename T, int DH, int NKT>
 int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B, int S, int A, const DropCfg& d, const int32_t* doc_off,
                hipStream_t st) {
-  if (pair_heads<T, DH>(A, S)) {
+  if constexpr (sizeof(T) == 2 && DH == 32) if (pair_heads<T, DH>(A, S)) {  // (constexpr: no dead fp32 / head-dim-64 instantiations of the paired kernels)
     const size_t lds = fwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
     const bool tail = ATTN_SKIP && doc_off == nullptr;
@@ -1053,10 +1067,12 @@ int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* 
   if constexpr (sizeof(T) == 2 && DH == 32) {  // single pass: dQ of 8 query tiles in registers
     if (S <= 128 && pair_heads<T, DH>(A, S)) return launch_bwd1<DH, 2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
     // longer documents: single pass with the query tiles dealt to the eight waves of a (document, head) workgroup
-    if (ATTN_BWD2 && S > 128 && S <= 512) return S <= 256 ? launch_bwd2<1>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
-                                                          : launch_bwd2<2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
+    // (same-box A/B against the two-phase kernel with 16 waves, profiles/r6_attn_ab.txt: the single pass wins where documents are long
+    //  and the key loop is long enough to amortise its per-block barrier and partial-sum exchange)
+    if (ATTN_BWD2 && S > ATTN_BWD2_MIN_S && S <= 512) return S <= 256 ? launch_bwd2<1>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
+                                                                       : launch_bwd2<2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
   }
-  if (pair_heads<T, DH>(A, S)) {
+  if constexpr (sizeof(T) == 2 && DH == 32) if (pair_heads<T, DH>(A, S)) {
     const size_t lds = bwd_lds<T, DH, 2>(S);
     SM_REQUIRE(lds <= LDS_MAX, "sm_attention_bwd: S=%d dh=%d needs %zu B of LDS (max %zu)", S, DH, lds, LDS_MAX);
     if (sizeof(T) == 2 && S > 128) {  // long documents: 16 waves share the pair's images (one workgroup per CU at S = 512)
