@@ -376,11 +376,19 @@ def measured_peaks(device):
     st = L.stream_ptr()
     L.call("sm_peak_mfma_bf16", L.ptr(sink), blocks, 64, st)  # warm
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the shader clock under the bare loop (sm_clock_stamp, ABI 7): the loop issues an MFMA in every matrix-pipe slot, so its rate over
+    # the vendor peak x 2.4 GHz must be the clock the stamps read -- the cross-check of the stamps themselves
+    stamps = torch.zeros(2 * 4096, dtype=torch.int64, device=device)
+    L.call("sm_clock_stamp", L.ptr(stamps), 0, st)
     e0.record()
     L.call("sm_peak_mfma_bf16", L.ptr(sink), blocks, iters, st)
     e1.record()
+    L.call("sm_clock_stamp", L.ptr(stamps), 1, st)
     torch.cuda.synchronize()
     mfma = blocks * 4 * iters * 16 * 16384 / (e0.elapsed_time(e1) * 1e-3)
+    sa, sb = stamps.cpu().view(2, 2048, 2)
+    ok = (sa[:, 1] > 0) & (sb[:, 1] > sa[:, 1]) & (sb[:, 0] > sa[:, 0])
+    clk = float(((sb[ok, 0] - sa[ok, 0]).double() / (sb[ok, 1] - sa[ok, 1]).double()).median() * 0.1) if int(ok.sum()) >= 8 else None
     n = 1 << 30
     src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
     dst = torch.empty_like(src)
@@ -394,6 +402,7 @@ def measured_peaks(device):
         best = min(best, e0.elapsed_time(e1))
     del src, dst
     return {"mfma_bf16_tflops": mfma / 1e12, "hbm_copy_gbs": 2 * n / (best * 1e-3) / 1e9,
+            "mfma_loop_clock_ghz": clk, "mfma_loop_clock_implied_by_its_rate_ghz": mfma / 2.5e15 * 2.4,
             "how": "bare v_mfma_f32_16x16x32_bf16 loop, random operands in registers, 1024 WGs x 4 waves; float4 copy of 1 GiB (read + write bytes)"}
 
 

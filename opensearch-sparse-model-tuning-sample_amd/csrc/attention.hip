@@ -19,7 +19,7 @@
 #define ATTN_BWD2 1  // head dim 32, documents of 129 .. 512 tokens: the single-pass backward attn_bwd2_kernel (0: the two-phase kernel)
 #endif
 #ifndef ATTN_BWD2_MIN_S
-#define ATTN_BWD2_MIN_S 128  // ... for documents longer than this (set from the A/B run)
+#define ATTN_BWD2_MIN_S 256  // ... from this padded length on, dense layout (set from the A/B run, see launch_bwd)
 #endif
 #ifndef ATTN_BWD_NW_LONG
 #define ATTN_BWD_NW_LONG 16  // waves per workgroup of the two-phase backward on paired heads (head dim 32) for documents > 128 tokens
@@ -1067,9 +1067,12 @@ int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* 
   if constexpr (sizeof(T) == 2 && DH == 32) {  // single pass: dQ of 8 query tiles in registers
     if (S <= 128 && pair_heads<T, DH>(A, S)) return launch_bwd1<DH, 2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
     // longer documents: single pass with the query tiles dealt to the eight waves of a (document, head) workgroup
-    // (same-box A/B against the two-phase kernel with 16 waves, profiles/r6_attn_ab.txt: the single pass wins where documents are long
-    //  and the key loop is long enough to amortise its per-block barrier and partial-sum exchange)
-    if (ATTN_BWD2 && S > ATTN_BWD2_MIN_S && S <= 512) return S <= 256 ? launch_bwd2<1>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
+    // Same-box A/B against the two-phase kernel with 16 waves (profiles/r6_attn_ab.txt; dropout on, us per launch at 65 k padded rows):
+    // DENSE layout S = 256 / 320 / 384 / 448 / 512: 282 / 318 / 338 / 402 / 390 against 296 / 357 / 403 / 487 / 492 (the single pass also
+    // skips the key blocks behind a document's last attended key); S = 160 / 192: 281 / 283 against 237 / 253.  RAGGED layout
+    // (no padding inside a document): the two-phase kernel wins up to S = 448 (short documents leave most of the eight waves of a
+    // single-pass workgroup without query tiles) and ties at 512 -- it keeps the ragged layout.
+    if (ATTN_BWD2 && doc_off == nullptr && S >= ATTN_BWD2_MIN_S && S <= 512) return S <= 256 ? launch_bwd2<1>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st)
                                                                        : launch_bwd2<2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
   }
   if constexpr (sizeof(T) == 2 && DH == 32) if (pair_heads<T, DH>(A, S)) {
