@@ -73,6 +73,11 @@ def test_bench_one_gpu_line():
     assert j["value_ragged_layout"] > j["value_dense_layout"] > 0
     # the roofline object is the step's dominant kernel class, the encoder GEMMs in-step; the head forward rides beside it
     assert rf["kernel"].startswith("encoder GEMMs, in-step") and 0 < rf["one_queue"]["frac"] < 1 and len(rf["per_op"]) >= 3
+    # round 6: the shader clock under every GEMM op (sm_clock_stamp around each launch) and the cross-check on the bare MFMA loop,
+    # whose rate fixes its clock (rate / 2.5 PFLOP/s x 2.4 GHz): the stamps must read that clock
+    for g in rf["per_op"]:
+        assert 0.8 < g["clock_ghz"] < 2.6 and 0 < g["frac_at_clock"] < 1, g
+    assert abs(pm["mfma_loop_clock_ghz"] - pm["mfma_loop_clock_implied_by_its_rate_ghz"]) < 0.15 * pm["mfma_loop_clock_ghz"], pm
     assert j["value_layout"] == "dense" and abs(j["value"] - j["value_dense_layout"]) < 1e-9
     assert j["finite"] is True and j["loss_first"] == j["loss_first"] and j["loss_first"] != j["loss_last"]  # the timed region trained
     hd = j["roofline_head_fwd"]
