@@ -18,6 +18,9 @@
 #ifndef ATTN_BWD2
 #define ATTN_BWD2 1  // head dim 32, documents of 129 .. 512 tokens: the single-pass backward attn_bwd2_kernel (0: the two-phase kernel)
 #endif
+#ifndef ATTN_BWD2_S128
+#define ATTN_BWD2_S128 0  // experiment: documents of 65 .. 128 tokens through attn_bwd2_kernel with four waves instead of attn_bwd1_kernel
+#endif
 #ifndef ATTN_BWD2_MIN_S
 #define ATTN_BWD2_MIN_S 256  // ... from this padded length on, dense layout (set from the A/B run, see launch_bwd)
 #endif
@@ -792,13 +795,13 @@ __global__ __launch_bounds__(64 * HP) void attn_bwd1_kernel(const bf16* __restri
 // bit-reproducible).  K / V fragments of a block come straight from global memory (L2: all eight waves and the neighbouring head's
 // workgroup read the same rows); Q and dO share one 128-byte-row XOR-swizzled image (Q in bytes 0-63, dO in 64-127: the conflict-free
 // layout of the paired-head kernels).  LDS at S = 512: 64 KiB image + 64 KiB partials + 9 KiB = one workgroup per CU, two waves per SIMD.
-template <int NPW, bool DROP, bool TAIL>  // NPW: query-tile pairs per wave (1: S <= 256, 2: S <= 512)
-__global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ keymask,
+template <int NPW, bool DROP, bool TAIL, int NW = 8>  // NPW: query-tile pairs per wave (1: S <= 16 NW, 2: S <= 32 NW); NW waves per workgroup (4: S <= 128 experiment)
+__global__ __launch_bounds__(64 * NW) void attn_bwd2_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                         const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int S, int A, DropCfg drop,
                                                         const int32_t* __restrict__ doc_off) {
   using T = bf16;
-  constexpr int DH = 32, NW = 8, RS = 128;
+  constexpr int DH = 32, RS = 128, NT_ = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
   const int H = A * DH;
@@ -821,18 +824,18 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__
   {
     // Q, dO -> the shared image, delta = rowsum(dO . O): a thread stages chunk (row, c) of Q and of dO and loads the same chunk of O;
     // the four 16-byte chunks of a head's row sit in adjacent lanes
-    constexpr int MAXIT = 2 * NPW;  // S * 4 chunks / 512 threads
+    constexpr int MAXIT = 2 * NPW;  // S * 4 chunks / (64 NW) threads, S <= 32 NW NPW
     uint4 vq[MAXIT], vd[MAXIT], vo[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const int idx = threadIdx.x + it * 512, r = idx >> 2, c = idx & 3;
+      const int idx = threadIdx.x + it * NT_, r = idx >> 2, c = idx & 3;
       const bool live = r < Lr;
       vq[it] = live ? *reinterpret_cast<const uint4*>(base + (size_t)r * ld + c * 8) : make_uint4(0, 0, 0, 0);
       vd[it] = live ? *reinterpret_cast<const uint4*>(dob + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
       vo[it] = live ? *reinterpret_cast<const uint4*>(ob + (size_t)r * H + c * 8) : make_uint4(0, 0, 0, 0);
     }
     int mylast = -1;
-    for (int i0 = 0; i0 < nt * 16; i0 += 512) {
+    for (int i0 = 0; i0 < nt * 16; i0 += NT_) {
       const int i = i0 + threadIdx.x;
       const bool on = i < nt * 16 && i < Lr && keymask[(size_t)row0 + i] != 0;
       if constexpr (TAIL) {
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__
     if (TAIL && (threadIdx.x & 63) == 0) s_lastw[threadIdx.x >> 6] = mylast;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const int idx = threadIdx.x + it * 512, r = idx >> 2, c = idx & 3;
+      const int idx = threadIdx.x + it * NT_, r = idx >> 2, c = idx & 3;
       const T* ea = reinterpret_cast<const T*>(&vd[it]);
       const T* eo = reinterpret_cast<const T*>(&vo[it]);
       float d = 0.f;
@@ -888,12 +891,12 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__
     nblk_on = min(nblk, (s_last >> 4) + 1);
   }
   // key blocks behind the last attended key: dK = dV = 0 (one 8-byte store per thread and 128 bytes of a row)
-  for (int idx = nblk_on * 16 * 16 + threadIdx.x; idx < nblk * 16 * 16; idx += 512) {
+  for (int idx = nblk_on * 16 * 16 + threadIdx.x; idx < nblk * 16 * 16; idx += NT_) {
     const int key = idx >> 4, c = idx & 15;  // 16 pieces of 4 columns: 8 of dK, 8 of dV
     store4<T>(dq_out + (size_t)key * ld + (c < 8 ? H : 2 * H) + (c & 7) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
   }
-  const int rvec = w >> 1;                       // the vector this wave's active half sums: 0, 1 = dK tiles, 2, 3 = dV tiles
-  const bool ractive = (lane >> 5) == (w & 1);
+  const int rvec = NW == 8 ? w >> 1 : w;         // the vector this wave (NW = 8: its active half) sums: 0, 1 = dK tiles, 2, 3 = dV tiles
+  const bool ractive = NW == 8 ? (lane >> 5) == (w & 1) : true;
   // the K / V operands of a key block are fetched ONE BLOCK AHEAD (global memory, L2): used where they are loaded, every wave paid a
   // full L2 round trip per key block with one other wave on its SIMD to cover it
   bf16x8 fk_n, fv_n;
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16* __restrict__
           for (int r = 0; r < 4; ++r) dq_out[(size_t)(qt * 16 + 4 * g + r) * ld + dt * 16 + li] = (bf16)(dq[pi][hh2][dt][r] * scale);
     }
 }
-size_t bwd2_lds(int S) { return (size_t)S * 128 + 8 * (size_t)S + 2 * 8 * 4 * 64 * 16 + 8 * 512 + S; }
+size_t bwd2_lds(int S, int NW = 8) { return (size_t)S * 128 + 8 * (size_t)S + 2 * (size_t)NW * 4 * 64 * 16 + (size_t)NW * 512 + S; }
 
 template <int DH, int HP>
 size_t bwd1_lds(int S) { return 2 * (size_t)S * Lay<bf16, HP * DH>::RS + HP * 8 * (size_t)S + HP * 512 + S; }
@@ -1049,15 +1052,15 @@ int launch_bwd1(const void* qkv, const uint8_t* km, const void* ctx, const void*
   return SM_OK;
 }
 
-template <int NPW>
+template <int NPW, int NW = 8>
 int launch_bwd2(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                 int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
-  const size_t lds = bwd2_lds(S);
+  const size_t lds = bwd2_lds(S, NW);
   const bool tail = ATTN_SKIP && doc_off == nullptr;
-  auto kern = d.thresh16 ? (tail ? attn_bwd2_kernel<NPW, true, true> : attn_bwd2_kernel<NPW, true, false>)
-                         : (tail ? attn_bwd2_kernel<NPW, false, true> : attn_bwd2_kernel<NPW, false, false>);
+  auto kern = d.thresh16 ? (tail ? attn_bwd2_kernel<NPW, true, true, NW> : attn_bwd2_kernel<NPW, true, false, NW>)
+                         : (tail ? attn_bwd2_kernel<NPW, false, true, NW> : attn_bwd2_kernel<NPW, false, false, NW>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(B * A), dim3(512), lds, st, (const bf16*)qkv, km, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, S, A, d, doc_off);
+  hipLaunchKernelGGL(kern, dim3(B * A), dim3(64 * NW), lds, st, (const bf16*)qkv, km, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, S, A, d, doc_off);
   return SM_OK;
 }
 
@@ -1065,6 +1068,7 @@ template <typename T, int DH>
 int launch_bwd(const void* qkv, const uint8_t* km, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                int B, int S, int A, const DropCfg& d, const int32_t* doc_off, hipStream_t st) {
   if constexpr (sizeof(T) == 2 && DH == 32) {  // single pass: dQ of 8 query tiles in registers
+    if (ATTN_BWD2_S128 && S <= 128 && S > 64) return launch_bwd2<1, 4>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);  // (experiment: A/B against attn_bwd1)
     if (S <= 128 && pair_heads<T, DH>(A, S)) return launch_bwd1<DH, 2>(qkv, km, ctx, dctx, lse, dqkv, B, S, A, d, doc_off, st);
     // longer documents: single pass with the query tiles dealt to the eight waves of a (document, head) workgroup
     // Same-box A/B against the two-phase kernel with 16 waves (profiles/r6_attn_ab.txt; dropout on, us per launch at 65 k padded rows):
