@@ -86,6 +86,23 @@ __global__ void vs_blkinfo_kernel(const int32_t* __restrict__ blk_doc, const int
 }
 __device__ __forceinline__ int vs_doc(uint32_t w) { return (int)(w & 0xFFFFFu); }
 
+// The packed comparison orders equal VALUES by their complemented position -- for POSITIVE floats.  A NEGATIVE raw maximum (the bias
+// is added afterwards, so the activation can still be alive) orders its low bits the other way round: among exact ties the HIGHEST
+// position wins.  Exact ties are what the loaders create: padded rows are copies of the first row of their 8-row half-block, so a
+// negative maximum that sits on that first row comes out at the half-block's LAST row, position | 7 -- a padded row whose gradient
+// the backward then drops.  (Found in round 6 by running the ragged head test through this kernel: documents of 3 and 5 tokens had
+// 3-8 live columns each with position 7.)  Where the activation is alive, the maximum negative and the position ends in 7, the
+// row's mask byte decides: padded -> the half-block's first row, which holds the same value.  Two dependent loads on a path that a
+// trained model (about 1 % alive) takes for one (document, column) in a thousand.
+__device__ __forceinline__ uint32_t vs_true_position(uint32_t p, uint32_t bits, float y, int doc, const uint8_t* __restrict__ mask,
+                                                     const int32_t* __restrict__ doc_off, int S) {
+  if (y > 0.f && (int)bits < 0 && (p & 7u) == 7u) {
+    const long row = (doc_off ? (long)doc_off[doc] : (long)doc * S) + p;
+    if (!mask[row]) p &= ~7u;
+  }
+  return p;
+}
+
 template <int N> __device__ __forceinline__ void vs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int PPW> __device__ __forceinline__ void vs_wait_stages(int younger) {  // at most `younger` stages (PPW loads each) in flight
   switch (younger) {
@@ -138,7 +155,7 @@ template <int H, bool F16>
 __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
     const bf16* __restrict__ Tn, const bf16* __restrict__ E, const float* __restrict__ bias, const uint8_t* __restrict__ mask,
     const uint32_t* __restrict__ info, float* __restrict__ rep, uint16_t* __restrict__ argmax, int V, int use_l0, int rows,
-    uint32_t idx_mask) {
+    uint32_t idx_mask, const int32_t* __restrict__ doc_off, int S) {
   using C = VsCfg<H>;
   constexpr int KS = C::KS, NST = VS_NST, D = VS_D;
   constexpr int BAR_KS = KS - D < 4 ? KS - D : 4;  // barrier(s) sits behind MFMA BAR_KS of step s, in front of the first read of stage s + 1
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(512) void sparse_head_fwd_vs_kernel(
     if (col < V) {
       const size_t o = (size_t)doc * V + col;
       if (h == 0) rep[o] = y;
-      else argmax[o] = (uint16_t)(idx_mask - (bits & idx_mask));  // the position travels complemented: lower positions win ties
+      else argmax[o] = (uint16_t)vs_true_position(idx_mask - (bits & idx_mask), bits, y, doc, mask, doc_off, S);  // complemented: lower positions win ties
     }
   };
 
@@ -519,7 +536,7 @@ int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* ma
   auto kern = sparse_head_fwd_vs_kernel<H, F16>;
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
   hipLaunchKernelGGL(kern, dim3(sm_cdiv(V, 128)), dim3(512), C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, (const uint32_t*)info, rep,
-                     argmax, V, use_l0, rows, idx_mask);
+                     argmax, V, use_l0, rows, idx_mask, rag ? rag->doc_off : nullptr, S);
   SM_LAUNCH_CHECK();
   return SM_OK;
 }

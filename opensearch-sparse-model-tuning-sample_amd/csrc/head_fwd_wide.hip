@@ -111,7 +111,7 @@ template <int H, bool RAG, bool F16>
 __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_kernel(
     const bf16* __restrict__ Tn, const bf16* __restrict__ E, const float* __restrict__ bias, const uint8_t* __restrict__ mask,
     float* __restrict__ rep, uint16_t* __restrict__ argmax, int S, int V, int use_l0, const int32_t* __restrict__ blk_doc,
-    const int32_t* __restrict__ pos_ids, int rows, uint32_t idx_mask) {
+    const int32_t* __restrict__ pos_ids, int rows, uint32_t idx_mask, const int32_t* __restrict__ doc_off) {
   using C = VsCfg<H>;
   constexpr int KS = C::KS, NST = C::NST, PPW = C::PPW, D = VS_D;
   constexpr int BAR_KS = KS - D < 4 ? KS - D : 4;  // barrier(s) sits behind MFMA BAR_KS of step s, in front of the first read of stage s + 1
@@ -143,7 +143,15 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
     if (col < V) {
       const size_t o = (size_t)doc * V + col;
       if (h == 0) rep[o] = y;
-      else argmax[o] = (uint16_t)pos;
+      else {
+        // a NEGATIVE raw maximum ties towards the HIGHER position: a padded copy of its half-block's first row (head_fwd.hip,
+        // vs_true_position) -- the mask byte of the row decides
+        if (y > 0.f && (int)bits < 0 && (pos & 7u) == 7u) {
+          const long row = (doc_off ? (long)doc_off[doc] : (long)doc * S) + pos;
+          if (!mask[row]) pos &= ~7u;
+        }
+        argmax[o] = (uint16_t)pos;
+      }
     }
   };
   // lanes that store rep (lower half) / argmax (upper half) for a finished document, as exec masks
@@ -322,6 +330,12 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
       finish_value(__float_as_uint(run), e.y, e.opos);
     } else if constexpr (k == 2) {
       const bool fire = e.newdoc && cur >= 0;
+      if (fire) {  // (wave-uniform; once per document) a negative raw maximum ties towards a padded copy: see store_doc
+        if (e.y > 0.f && (int)__float_as_uint(run) < 0 && (e.opos & 7u) == 7u) {
+          const long row = (doc_off ? (long)doc_off[cur] : (long)cur * S) + e.opos;
+          if (!mask[row]) e.opos &= ~7u;
+        }
+      }
       const size_t o = (size_t)(cur < 0 ? 0 : cur) * V + col;
       asm volatile("s_mov_b64 exec, %2\n\tglobal_store_dword %0, %1, off\n\ts_mov_b64 exec, -1" ::"v"(rep + o), "v"(e.y), "s"(fire ? rep_lanes : 0ull) : "memory");
       asm volatile("s_mov_b64 exec, %2\n\tglobal_store_short %0, %1, off\n\ts_mov_b64 exec, -1" ::"v"(argmax + o), "v"(e.opos), "s"(fire ? arg_lanes : 0ull) : "memory");
@@ -466,7 +480,9 @@ __global__ __launch_bounds__(VsCfg<H>::DED ? 512 : 256) void sparse_head_fwd_vs_
 
 // scratch bytes the (dtype, shape, layout) combination needs from the caller: the vocabulary-stationary bf16 kernel needs none
 bool vs_eligible(int dtype, int H, int S, const void* t, const void* E) {
-  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 512 || H == 768) && S <= 256 &&
+  // S <= 512 since round 6 (9 position bits, as head_fwd.hip): configs[4]'s 512-token documents took the generic kernel (5.4 ms per
+  // 127 k-row chunk against 5.2 ms here, round 5's measurement)
+  return (dtype == SM_BF16 || dtype == SM_F16) && (H == 512 || H == 768) && S <= 512 &&
          ((uintptr_t)t % 16) == 0 && ((uintptr_t)E % 16) == 0;
 }
 
@@ -483,12 +499,12 @@ int vs_launch(const void* t, const void* E, const float* bias, const uint8_t* ma
     auto kern = sparse_head_fwd_vs_kernel<H, true, F16>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     hipLaunchKernelGGL(kern, grid, block, C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, S, V, use_l0, rag->blk_doc,
-                       rag->pos_ids, rows, idx_mask);
+                       rag->pos_ids, rows, idx_mask, rag->doc_off);
   } else {
     auto kern = sparse_head_fwd_vs_kernel<H, false, F16>;
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     hipLaunchKernelGGL(kern, grid, block, C::LDS, st, (const bf16*)t, (const bf16*)E, bias, mask, rep, argmax, S, V, use_l0,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, rows, idx_mask);
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, rows, idx_mask, (const int32_t*)nullptr);
   }
   SM_LAUNCH_CHECK();
   return SM_OK;

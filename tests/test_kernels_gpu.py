@@ -616,13 +616,18 @@ def test_sparse_head_fwd_bwd(ops, dtype, B, S, H, V, use_l0):
     ref = O.sparse_activation(logits, mask.long(), use_l0)
     tol = TOL[dtype] * 2
     close(rep, ref, tol, "rep")
-    # argmax must point at a position that attains the max (ties are measure zero)
+    # argmax must point at an ATTENDED position that attains the max.  fp32: exactly (1e-4).  16-bit operands: the vocabulary-stationary
+    # kernels carry the position in the low 7-9 mantissa bits of the maximum, so two positions whose values agree to 2^-14 relative
+    # may swap (documented in csrc/head_fwd.hip) -- the bound asserted is four times that window, not round 5's 5e-2
     pos = am.cpu().long() & 0xFFFF
     masked = logits.detach().masked_fill(mask[:, :, None] == 0, -float("inf"))
     picked = torch.gather(masked, 1, pos[:, None, :]).squeeze(1)
     live = ref > 0
-    assert (picked[live] >= masked.max(1).values[live] - (1e-4 if dtype == torch.float32 else 5e-2)).all()
+    top = masked.max(1).values
+    assert (picked[live] >= top[live] - (1e-4 if dtype == torch.float32 else 2.0 ** -12 * (top[live].abs() + br.detach().abs().max() + 1))).all()
     up = rnd(B, V, seed=4)
+    if dtype != torch.float32:  # the reference gradient flows to the position the device chose among such near-ties (checked above)
+        ref = O.sparse_activation(logits, mask.long(), use_l0, route=pos)
     (ref * up).sum().backward()
     dE = torch.zeros(V, H, device="cuda")
     dbias = torch.zeros(V, device="cuda")
@@ -909,21 +914,28 @@ def test_sparse_head_ragged_layout(ops, dtype, H, use_l0):
     mask = torch.from_numpy(valid.astype(np.uint8))
     rep, am = ops.sparse_head_fwd(dev(t, dtype), dev(E, dtype), dev(bias), dev(mask), B, 512, V, use_l0, rag)
     tr, Er, br = t.clone().requires_grad_(True), E.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-    refs, tops = [], []
+    refs, tops, lgs = [], [], []
     for b in range(B):
         lg = tr[off[b]:off[b] + lens[b]] @ Er.t() + br
         refs.append(O.sparse_activation(lg[None], torch.ones(1, int(lens[b]), dtype=torch.long), use_l0)[0])
         tops.append(lg.detach())
+        lgs.append(lg)
     ref = torch.stack(refs)
     tol = TOL[dtype] * 2
     close(rep, ref, tol, "rep")
     posn = am.cpu().long() & 0xFFFF
     for b in range(B):
         live = ref[b] > 0
-        assert (posn[b][live] < int(lens[b])).all()
+        # (documents of 3 and 5 tokens: their padded rows are copies of row 0 inside the device's stage -- a NEGATIVE raw maximum on
+        #  row 0 must not come out at the copy in position 7; round 6 found exactly that in the vocabulary-stationary kernels)
+        assert (posn[b][live] < int(lens[b])).all(), (b, int(lens[b]), posn[b][live & (posn[b] >= int(lens[b]))][:8])
         picked = tops[b].gather(0, posn[b].clamp(max=int(lens[b]) - 1)[None])[0]
-        assert (picked[live] >= tops[b].max(0).values[live] - (1e-4 if dtype == torch.float32 else 6e-2)).all()
+        top = tops[b].max(0).values
+        assert (picked[live] >= top[live] - (1e-4 if dtype == torch.float32 else 2.0 ** -12 * (top[live].abs() + br.detach().abs().max() + 1))).all()
     up = rnd(B, V, seed=4)
+    if dtype != torch.float32:  # gradients flow to the position the device chose among near-ties (inside the window asserted above)
+        ref = torch.stack([O.sparse_activation(lgs[b][None], torch.ones(1, int(lens[b]), dtype=torch.long), use_l0,
+                                               route=posn[b].clamp(max=int(lens[b]) - 1)[None])[0] for b in range(B)])
     (ref * up).sum().backward()
     dE, dbias = torch.zeros(V, H, device="cuda"), torch.zeros(V, device="cuda")
     dt = ops.sparse_head_bwd(dev(up), rep, am, dev(t, dtype), dev(E, dtype), dE, dbias, B, 512, V, use_l0, rag)
