@@ -540,23 +540,26 @@ def test_attention_fwd_bwd(ops, dtype, B, S, A, dh):
     close(dqkv, xr.grad, tol * 2, "dqkv")
 
 
-def test_attention_dense_layout_skips_only_the_masked_tail(ops):
+@pytest.mark.parametrize("S", [128, 256, 512])
+def test_attention_dense_layout_skips_only_the_masked_tail(ops, S):
     """dense [B, S] batches: key tiles behind the LAST attended key are not computed (their probabilities are exactly zero).  Masks that
     are not prefixes (holes, a single attended key at the end, nothing attended at all, lengths on and off the 16 / 32 boundaries)
-    must give the same context rows and gradients as the full computation"""
-    B, S, A, dh = 8, 128, 2, 32
+    must give the same context rows and gradients as the full computation.  S = 256 / 512 (round 6): the 8-wave forward and the
+    single-pass backward attn_bwd2_kernel, whose key-block loop ends at the last attended key"""
+    B, A, dh = 8, 2, 32
     H = A * dh
+    f = S // 128
     dtype = torch.bfloat16
     qkv = q(rnd(B * S, 3 * H, seed=1), dtype)
     mask = torch.zeros(B, S, dtype=torch.uint8)
     mask[0, :] = 1
     mask[1, :16] = 1
-    mask[2, :33] = 1
-    mask[3, :96] = 1
-    mask[3, 20:70] = 0            # a hole
-    mask[4, 127] = 1              # only the last key
+    mask[2, :33 * f] = 1
+    mask[3, :96 * f] = 1
+    mask[3, 20 * f:70 * f] = 0    # a hole
+    mask[4, S - 1] = 1            # only the last key
     mask[5, :1] = 1               # only the first key
-    mask[6, :64] = 1
+    mask[6, :64 * f + (3 if f > 1 else 0)] = 1
     # document 7: nothing attended
     dctx = q(rnd(B * S, H, seed=2), dtype) * mask.view(-1, 1)
     ctx, lse = ops.attention_fwd(dev(qkv, dtype), dev(mask), B, S, A)
