@@ -537,21 +537,25 @@ def seq_sweep_leg(args, device, base_ms, steps=12, warmup=4):
         try:
             a = copy.copy(args)
             a.seq, a.bs, a.len_scale = S, args.bs * args.seq // S, S / 128.0
-            trainer, _, batches = build_trainer(a, device, 0, layouts=("dense",))
-            bs_ = batches["dense"]
-            for i in range(warmup):
-                trainer.training_step(bs_[i % len(bs_)])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            last = None
-            for i in range(steps):
-                last = trainer.training_step(bs_[i % len(bs_)])
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / steps * 1e3
+            trainer, _, batches = build_trainer(a, device, 0, layouts=("dense", "ragged"))
+            ms_of, last = {}, None
+            for layout in ("dense", "ragged"):  # dense = the headline's protocol; ragged (padding tokens skipped, identical outputs) beside it
+                trainer.model.sparse_model.backbone.varlen = layout == "ragged"
+                bs_ = batches[layout]
+                for i in range(warmup):
+                    trainer.training_step(bs_[i % len(bs_)])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    last = trainer.training_step(bs_[i % len(bs_)])
+                torch.cuda.synchronize()
+                ms_of[layout] = (time.perf_counter() - t0) / steps * 1e3
+            ms = ms_of["dense"]
             toks = a.bs * (a.negs + 1) * S
             out[f"seq{S}"] = {"queries": a.bs, "docs": a.bs * (a.negs + 1), "ms_per_step": ms, "tokens_per_sec": toks / (ms * 1e-3),
                               "vs_seq128": (toks / ms) / (args.bs * (args.negs + 1) * args.seq / base_ms), "loss": float(last),
-                              "finite": bool(torch.isfinite(last).item())}
+                              "finite": bool(torch.isfinite(last).item()), "ms_per_step_ragged_layout": ms_of["ragged"],
+                              "padded_tokens_per_sec_ragged_layout": toks / (ms_of["ragged"] * 1e-3)}
             del trainer, batches, bs_
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
