@@ -64,6 +64,9 @@ def parse():
                     help="all-bf16 activation storage instead of the default fp32 residual stream (+4.5 %% throughput; the sparse "
                          "activations then miss the elementwise 1e-2 bound on ~0.002 %% of the elements: DESIGN 4)")
     ap.add_argument("--only-value-layout", action="store_true", help="profiling runs: do not time the other layout")
+    ap.add_argument("--single-rank-rccl", action="store_true",
+                    help="N = 1 only: initialise a ONE-rank process group (backend nccl = RCCL) and run the step through the N > 1 code "
+                         "path (SM_DIST_SINGLE_RANK=1): every collective of the distributed step executes through RCCL on this GPU")
     return ap.parse_args()
 
 
@@ -597,12 +600,19 @@ def main():
     dev_index = local % max(1, ndev)  # SM_BENCH_BACKEND=gloo lets N ranks share one GPU (functional check of the N > 1 path)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    single = args.single_rank_rccl and world == 1
+    if single:  # the N > 1 code path with a communicator of one rank (scripts/train/trainer.py ProcessInfo.distributed)
+        os.environ["SM_DIST_SINGLE_RANK"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    dist_on = world > 1 or single
+    if dist_on:
         backend = os.environ.get("SM_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        kw = {"rank": 0, "world_size": 1} if single else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     if os.environ.get('SM_LIB'):  # A/B two builds of the shared library in one run (development aid)
@@ -613,7 +623,7 @@ def main():
     trainer, cfg, batches = build_trainer(args, device, rank, layouts=(args.layout,) if args.only_value_layout else (args.layout, other))
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -646,7 +656,7 @@ def main():
         if kt is not None:
             kt.enabled = False
         tmax = torch.tensor([el], device=device, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
@@ -654,14 +664,14 @@ def main():
     # (SM_EXCHANGE=gather, scripts/utils.py:16-23) -- whatever the caller's environment says; the score-block exchange
     # (sparse_hip.functional.distributed_loss) is timed right after it on the same ranks and reported BESIDE it.
     env_exchange = os.environ.get("SM_EXCHANGE")
-    if world > 1:
+    if dist_on:
         os.environ["SM_EXCHANGE"] = "gather"
     with KernelTimer(ops, "sparse_head_fwd") as kt:
         elapsed = timed(args.layout, kt)   # <- the line's `value`
         head_ms = kt.mean_ms()
         rows = list(kt.rows)
     elapsed_scores = None
-    if world > 1:
+    if dist_on:
         os.environ["SM_EXCHANGE"] = "scores"
         try:
             elapsed_scores = timed(args.layout)
@@ -672,7 +682,7 @@ def main():
         elapsed_again = timed(args.layout)  # liveness record of the value layout in gather mode again (and a second gather sample)
     elapsed_other = float("nan") if args.only_value_layout else timed(other)  # the other layout, outside the headline region
     gemm_lines = gemm_lines_serial = None
-    if world == 1 and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
+    if world == 1 and not single and not args.no_gemm_roofline:  # outside the timed region: does not touch `value`
         with GemmRoofline(ops) as gr:
             bs_ = batches[args.layout]
             for i in range(3):
@@ -737,7 +747,12 @@ def main():
                                                       "queries (under the document encoder) and of the score blocks + all-reduce of the FLOPS "
                                                       "column means; both: flat-gradient all-reduce in slices overlapped with backward)")},
     }
-    if world > 1:  # self-describing multi-GPU record: what carried the collectives
+    if single:
+        result["single_rank_rccl"] = ("the step through the N > 1 code path with a process group of ONE rank (SM_DIST_SINGLE_RANK=1): every collective "
+                                      "of the distributed step (query all-gather on the communication stream, loss-head exchange, slice-wise gradient "
+                                      "all-reduce from inside the backward) executed by the backend named in `dist`; no bytes cross a link -- this is "
+                                      "the cost of the distributed plumbing on one GPU, a lower bound of the N-GPU step, NOT a scaling number")
+    if dist_on:  # self-describing multi-GPU record: what carried the collectives
         try:
             ver = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception as e:  # noqa: BLE001  (a build without the binding: say so instead of failing the run)
@@ -782,7 +797,7 @@ def main():
         result["roofline_head_fwd"] = head_line
     else:  # N > 1 or --no-gemm-roofline: the largest single kernel of the step
         result["roofline"] = head_line
-    if world == 1 and not args.no_extras and args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
+    if world == 1 and not single and not args.no_extras and args.bs == 32 and args.negs == 15 and args.seq == 128 and args.dtype == "bf16":
         # two more records beside `value` (outside every timed region above; each guarded: a failure here never loses the line)
         result["sparse_regime"] = sparse_regime_leg(trainer, batches[args.layout], args.layout)
         result["c5_per_gpu"] = c5_leg()
@@ -793,10 +808,10 @@ def main():
             result["roofline"]["peak_measured"] = pm
             result["roofline"]["frac_of_measured_peak"] = (result["roofline"]["achieved"] / pm["mfma_bf16_tflops"]
                                                            if args.dtype == "bf16" else None)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not single and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if not result["finite"]:

@@ -84,6 +84,11 @@ class ProcessInfo:
             raise RuntimeError("multi-node runs are not supported (gather_rep indexes by local rank, utils.py:21)")
         self.is_main_process = self.process_index == 0
         self.device = device
+        # The N > 1 code path -- collectives on the communication stream, gradient slices all-reduced from inside the backward, the
+        # loss-head exchange -- with a communicator of ONE rank: SM_DIST_SINGLE_RANK=1 and an initialised process group.  Every collective
+        # then runs for real through the backend (RCCL with backend "nccl": the only way that path can execute on a one-GPU box) and the
+        # step must equal the plain single-process step.  Never set in production runs.
+        self.distributed = self.num_processes > 1 or (on and os.environ.get("SM_DIST_SINGLE_RANK", "0") == "1")
 
     def gather(self, t):
         return gather_rep(t.detach(), self)
@@ -120,7 +125,7 @@ class SparseModelTrainer:
         self._q_prefetch = None
         self._in_compute_loss = False
         self._step_done = []  # events at the end of the last steps (training_step: bounded host lead)
-        if self.accelerator.num_processes > 1:
+        if self.accelerator.distributed:
             self._setup_grad_overlap()
             if sparse_model.backbone.device.type == "cuda":
                 self.model.on_q_rep = self._prefetch_q_gather
@@ -240,7 +245,7 @@ class SparseModelTrainer:
         return mode
 
     def _use_score_exchange(self) -> bool:
-        return self.accelerator.num_processes > 1 and self._exchange_mode() == "scores"
+        return self.accelerator.distributed and self._exchange_mode() == "scores"
 
     _BUILTIN_LOSSES = {InfoNCELoss: "infonce", KLDivLoss: "kldiv", MarginMSELoss: "marginmse"}
 
@@ -251,7 +256,7 @@ class SparseModelTrainer:
         with its own get_loss takes the reference-form path)."""
         if any(type(lf) not in self._BUILTIN_LOSSES for lf in self.loss_functions) or len(self.loss_functions) > 4:
             return False
-        return self.accelerator.num_processes <= 1 or self._exchange_mode() in ("scores", "gather")
+        return not self.accelerator.distributed or self._exchange_mode() in ("scores", "gather")
 
     def _compute_loss_fused(self, d_rep, q_rep, inputs, cap, return_outputs):
         losses = [(self._BUILTIN_LOSSES[type(lf)], lf.weight, bool(lf.use_in_batch_negatives), float(getattr(lf, "temperature", 1.0)))
@@ -262,7 +267,8 @@ class SparseModelTrainer:
             teacher = gather_rep(inputs["scores"].to(d_rep.device, torch.float32), self.accelerator)
         # (the moving average ma = 0.01 * ranking + 0.99 * ma of trainer.py:120-122 is updated by the same launch)
         cfg = {"losses": losses, "q_cap": cap, "flops_threshold": self.data_args.flops_threshold, "moving_avg": self._ma,
-               "q_all": self._take_q_prefetch(), "exchange": self._exchange_mode() if n > 1 else None,
+               "q_all": self._take_q_prefetch(), "exchange": self._exchange_mode() if self.accelerator.distributed else None,
+               "distributed": self.accelerator.distributed,
                "lambda_d": self.get_lambda(self.data_args.flops_d_lambda, self.data_args.flops_d_T),
                "lambda_q": None if self.model_args.inf_free else self.get_lambda(self.data_args.flops_q_lambda,
                                                                                  self.data_args.flops_q_T)}
@@ -431,7 +437,7 @@ class SparseModelTrainer:
     def _finish_grad_reduce(self):
         sm = self.model.sparse_model
         bb = sm.backbone
-        if self.accelerator.num_processes == 1:
+        if not self.accelerator.distributed:
             return
         if bb._layer_hook is not None:
             self._reduce_slice_async("emb")

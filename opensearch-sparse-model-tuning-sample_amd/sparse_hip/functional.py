@@ -163,7 +163,7 @@ def gather_rep(rep: Tensor, accelerator=None, group=None, prefetched=None) -> Te
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
         world, rank = 1, 0
-    if world == 1:
+    if world == 1 and not _single_rank_dist():
         return rep
     return _GatherFn.apply(rep, rank, world, group, prefetched)
 
@@ -184,6 +184,13 @@ def _world(group):
     return 1, 0
 
 
+def _single_rank_dist() -> bool:
+    """SM_DIST_SINGLE_RANK=1 with an initialised process group: the collectives of the N > 1 path run with a one-rank communicator
+    (scripts/train/trainer.py ProcessInfo.distributed)"""
+    import os
+    return dist.is_available() and dist.is_initialized() and os.environ.get("SM_DIST_SINGLE_RANK", "0") == "1"
+
+
 class _DistLossFn(torch.autograd.Function):
     """One autograd node for the whole loss head.  N = 1 (also without torch.distributed): no collectives, and the scalar
     tail (weights, lambdas, moving average) is one launch (ops.loss_combine) -- as separate nodes the loss section of a step
@@ -193,6 +200,7 @@ class _DistLossFn(torch.autograd.Function):
     def forward(ctx, d_local: Tensor, q_local: Tensor, teacher: Optional[Tensor], cfg: dict):
         group = cfg.get("group")
         N, rank = _world(group)
+        D = N > 1 or (bool(cfg.get("distributed")) and _single_rank_dist())  # collectives on (also with a communicator of one rank)
         d, q = _f32c(d_local), _f32c(q_local)
         nq, nd, V = q.shape[0], d.shape[0], d.shape[1]
         if nd % nq:
@@ -200,10 +208,10 @@ class _DistLossFn(torch.autograd.Function):
         k = nd // nq
         thr, cap = cfg.get("flops_threshold"), cfg.get("q_cap")
         pre = cfg.pop("q_all", None)
-        if N > 1 and pre is not None and tuple(pre[0].shape) == (N * nq, V) and pre[0].dtype == torch.float32:
+        if D and pre is not None and tuple(pre[0].shape) == (N * nq, V) and pre[0].dtype == torch.float32:
             q_all, work = pre  # started on the communication stream before the document encoder ran
             work.wait()
-        elif N > 1:
+        elif D:
             q_all = torch.empty((N * nq, V), dtype=torch.float32, device=q.device)
             dist.all_gather_into_tensor(q_all, q, group=group)
         else:
@@ -215,7 +223,7 @@ class _DistLossFn(torch.autograd.Function):
         # remote document (round 5 evaluated the loss kernels on the gathered [N * B_d, V] tensor AFTER the whole all-gather:
         # 2.1 ms at N = 8 behind a 437 MB collective that nothing overlapped).  Gradients flow to the LOCAL documents only
         # (gather_rep's backward is the local slice), so the backward below is the score exchange's.
-        gather = N > 1 and cfg.get("exchange") == "gather"
+        gather = D and cfg.get("exchange") == "gather"
         gathered = None
         if gather:
             C = int(cfg.get("gather_chunks", 4))
@@ -232,14 +240,14 @@ class _DistLossFn(torch.autograd.Function):
         d_flops, cm_d, keep_d = ops.flops_fwd(d, k, thr)
         if gather:
             cm_d = None  # summed over the gathered chunks below (every chunk holds whole queries of every rank)
-        elif N > 1:
+        elif D:
             dist.all_reduce(cm_d, group=group)
             cm_d.div_(N)
             d_flops = (cm_d * cm_d).sum().reshape(1)
         cm_q = keep_q = q_flops = None
         if cfg.get("lambda_q") is not None:
             q_flops, cm_q, keep_q = ops.flops_fwd(q, 1, thr)
-            if N > 1:
+            if D:
                 dist.all_reduce(cm_q, group=group)
                 cm_q.div_(N)
                 q_flops = (cm_q * cm_q).sum().reshape(1)
@@ -269,7 +277,7 @@ class _DistLossFn(torch.autograd.Function):
                 gathered = None
             else:
                 s_r = ops.scores_csr_fwd(csr_all, d, pairs=False) if csr_all is not None else ops.scores_fwd(q_all, d, pairs=False)
-                if N > 1:
+                if D:
                     s_t = torch.empty((N * nd, N * nq), dtype=torch.float32, device=d.device)
                     dist.all_gather_into_tensor(s_t, s_r.t().contiguous(), group=group)
                     scores = s_t.t().contiguous()  # [N*nq, N*nd], document columns in rank order = the gathered layout
@@ -288,7 +296,7 @@ class _DistLossFn(torch.autograd.Function):
                     l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(scores, t, tau)
                 terms.append((l, float(w)))
                 ds_full = weighted(ds_full, g, w)
-            ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous() if N > 1 else ds_full
+            ds_ibn = ds_full[:, rank * nd:(rank + 1) * nd].contiguous() if D else ds_full
         if gathered is not None:  # no in-batch-negative loss consumed the chunks: the FLOPS column sums still need them
             for buf, work in gathered:
                 work.wait()
@@ -308,12 +316,12 @@ class _DistLossFn(torch.autograd.Function):
                     l, g = ops.infonce(sp, k, pairs=True)
                 else:
                     t = _f32c(teacher)
-                    if N > 1:
+                    if D:
                         t = t[rank * nq:(rank + 1) * nq].contiguous()  # teacher arrives gathered [N*bs, k]
                     l, g = (ops.kldiv if kind == "kldiv" else ops.marginmse)(sp, t, tau)
                 lp_terms.append((l, float(w)))
                 ds_pairs = weighted(ds_pairs, g, w)
-            if N > 1:  # mean over all queries = mean of the per-rank means
+            if D:  # mean over all queries = mean of the per-rank means
                 lp = lp_terms[0][0].reshape(()) * lp_terms[0][1]
                 for l, w in lp_terms[1:]:
                     lp = lp + l.reshape(()) * w
@@ -327,7 +335,7 @@ class _DistLossFn(torch.autograd.Function):
                                           float(cfg["lambda_q"]) if q_flops is not None else 0.0,
                                           cfg.get("moving_avg"), float(cfg.get("ma_new", 0.01)))
         cfg["out"] = {"d_flops": d_flops.reshape(()), "ranking": ranking}
-        ctx.cfg, ctx.N, ctx.rank, ctx.k = cfg, N, rank, k
+        ctx.cfg, ctx.N, ctx.rank, ctx.k, ctx.D = cfg, N, rank, k, D
         ctx.csr_all, ctx.csr_loc, ctx.group = csr_all, csr_loc, group
         ctx.has = (ds_ibn is not None, ds_pairs is not None, keep_d is not None, cm_q is not None, keep_q is not None)
         e = torch.empty(0, device=d.device)
@@ -356,7 +364,7 @@ class _DistLossFn(torch.autograd.Function):
                 ops.scores_bwd(q_all, d, ds, False, dq_all, dd, False)
             wrote = True
             if need_q:  # every rank holds the part of dL/dq_all that flows through ITS documents
-                if N > 1:
+                if ctx.D:
                     dist.all_reduce(dq_all, group=group)
                 dq.add_(dq_all[rank * nq:(rank + 1) * nq])
         if has_pairs:

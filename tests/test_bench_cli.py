@@ -101,3 +101,17 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # exchange beside it, each with its own liveness record
     assert j["value_scores_exchange"] > 0 and j["ms_per_step_scores_exchange"] > 0 and j["value_gather_second_sample"] > 0
     assert j["liveness"]["scores_exchange"]["finite"] is True
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_rccl_line():
+    """bench.py --single-rank-rccl: the N > 1 code path through RCCL with a communicator of one rank (the only RCCL execution a
+    one-GPU box allows): both exchange modes timed, the dist record names the backend and the RCCL version"""
+    r = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-rank-rccl", "--steps", "4", "--warmup", "2"], timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["finite"] is True and j["value"] > 0
+    d = j["dist"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["rccl_version"][0].isdigit(), d
+    assert j["value_scores_exchange"] > 0 and j["liveness"]["scores_exchange"]["finite"] is True
+    assert "single_rank_rccl" in j

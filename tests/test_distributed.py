@@ -348,6 +348,41 @@ def test_two_rank_step_equals_single_process_step_on_the_concatenated_batch(tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_one_rank_rccl_runs_the_distributed_step_and_equals_the_plain_step(tmp_path, case):
+    """RCCL on the one GPU a test box has: a process group of ONE rank with backend "nccl" (= RCCL) and SM_DIST_SINGLE_RANK=1, which
+    switches the trainer and the loss head to the N > 1 code path -- the all-gather of the queries on the communication stream, the
+    loss-head exchange of every mode (chunked all-gather of the document representations / score blocks + column means / the
+    reference-form gather_rep), the slice-wise gradient all-reduce from inside the backward, the waits in front of the optimiser --
+    with every collective executed by RCCL (scripts/utils.py:16-23, trainer.py:101-141 under torchrun with one process).  A one-rank
+    collective moves no bytes between GPUs, but it is the real backend, its stream semantics and its argument checks; the step must
+    reproduce the plain single-process step.  (Two ranks over RCCL need two GPUs: test_two_rank_step_over_rccl.)"""
+    script = tmp_path / "worker1.py"
+    script.write_text(WORKER.replace('if world > 1:\n    dist.init_process_group("gloo")',
+                                     'single = os.environ.get("SM_DIST_SINGLE_RANK") == "1"\nif world > 1 or single:\n    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))')
+                      .replace('rank = dist.get_rank() if world > 1 else 0', 'rank = dist.get_rank() if (world > 1 or single) else 0')
+                      .replace('if world > 1:\n    dist.barrier(); dist.destroy_process_group()', 'if world > 1 or single:\n    dist.barrier(); dist.destroy_process_group()'))
+    assert "single = os.environ" in script.read_text() and script.read_text().count("or single") == 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SM_TEST_CASE=case)
+    env.pop("SM_DIST_SINGLE_RANK", None)
+    one = str(tmp_path / "one.npz")
+    r1 = _run([sys.executable, str(script), ROOT, PKG, one], env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    a = np.load(one)
+    base = 29900 + 4 * CASES.index(case)
+    for port, mode in ((base, "gather"), (base + 1, "scores"), (base + 2, "gather_ref")):
+        out = str(tmp_path / f"rccl1_{mode}.npz")
+        r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port), str(script), ROOT, PKG, out], dict(env, SM_EXCHANGE=mode, SM_DIST_SINGLE_RANK="1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        b = np.load(out)
+        assert abs(float(b["loss"]) - float(a["loss"])) <= 2e-3 * abs(float(a["loss"])), (mode, float(b["loss"]), float(a["loss"]))
+        diff = np.abs(a["flat"] - b["flat"])
+        assert (diff > 1e-4).sum() <= 1e-3 * diff.size, (mode, int((diff > 1e-4).sum()))
+        assert diff.max() <= 2.5e-3, mode
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
 @pytest.mark.parametrize("case", ["infonce_ibn", "kd_pairs"])
 def test_two_rank_step_over_rccl(tmp_path, case):
