@@ -29,6 +29,12 @@ for _p in (ROOT, PKG):
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver supports dmabuf IPC only: without it RCCL's
                                                             # hipIpcGetMemHandle fails (multi-process GPU work)
+# N > 1: the step keeps FIVE HIP streams busy (backward chain, weight gradients, gradient all-reduce, RCCL's own, input prefetch); with the
+# runtime's default of 4 hardware queues two of them share one, and when the communication stream's wait for a layer's weight gradients
+# lands in the main stream's queue the backward chain stalls for the length of that weight-gradient kernel -- 275 us behind every layer,
+# 0.36 ms of a 12.4 ms step (measured with a one-rank RCCL communicator, profiles/r6_single_rank_rccl.txt).  Must be set before HIP starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--single-rank-rccl" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

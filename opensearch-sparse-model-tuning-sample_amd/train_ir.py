@@ -12,6 +12,12 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it (multi-process GPU work)
+# N > 1: the step keeps FIVE HIP streams busy (backward chain, weight gradients, gradient all-reduce, RCCL's own, input prefetch); with the
+# runtime's default of 4 hardware queues two of them share one, and when the communication stream's wait for a layer's weight gradients
+# lands in the main stream's queue the backward chain stalls for the length of that weight-gradient kernel -- 275 us behind every layer,
+# 0.36 ms of a 12.4 ms step (measured with a one-rank RCCL communicator, profiles/r6_single_rank_rccl.txt).  Must be set before HIP starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
