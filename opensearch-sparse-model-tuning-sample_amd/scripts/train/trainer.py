@@ -429,7 +429,10 @@ class SparseModelTrainer:
         """All-reduce one slice of the flat gradient on the communication stream, ordered after the backward
         kernels enqueued so far on the main stream and (``wgrad_event``) on the weight-gradient stream."""
         bb = self.model.sparse_model.backbone
-        a, b = self._slices[key]
+        if isinstance(key, tuple):  # two adjacent encoder layers whose weight gradients went out in one grouped launch
+            a, b = self._slices[min(key)][0], self._slices[max(key)][1]
+        else:
+            a, b = self._slices[key]
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._comm_stream):

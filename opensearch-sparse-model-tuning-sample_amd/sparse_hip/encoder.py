@@ -194,7 +194,7 @@ KERNEL_OPTIONS = {
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
     "fp8_emit": ("SM_FP8_EMIT", False, bool),                 # fp8 mode: the FFN-width GEMM epilogues write the next GEMM's fp8 operand themselves (byte-identical; measured +-0 on configs[4]: opt-in)
     "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
-    "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (single process: no per-layer gradient reduction)
+    "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (N > 1: the pair's two gradient slices are reduced by one collective)
     "encode_graph": ("SM_ENCODE_GRAPH", True, bool),          # small no-grad encodes replay a captured HIP graph
     "encode_graph_tokens": ("SM_ENCODE_GRAPH_TOKENS", 8192, int),
     "pc_infer_min_rows": ("SM_PC_INFER_MIN_ROWS", 6144, int),  # no-grad forwards below this many rows: unfused feed-forward launches
@@ -1060,6 +1060,7 @@ class _EncodeFn(torch.autograd.Function):
             dx = ops.gemm_nt(dft, st["tT"])
         if model._layer_hook is not None:
             model._layer_hook("head", wg.mark())
+        deferred_layer = None
         for l in reversed(range(cfg.num_hidden_layers)):
             p = f"bert.encoder.layer.{l}."
             x, qkv, ctxt, lse, z1, m1, r1, x1, f1, ga, z2, m2, r2 = ctx.saved["layers"][l]
@@ -1131,14 +1132,19 @@ class _EncodeFn(torch.autograd.Function):
             if pending is None and dz0 is None:
                 dx = model._lin(dqkv, f"qkvT{l}", grad=True, residual=dz1)
             # this layer's weight gradients: one fork of the side stream (a marker on the main queue: ~12-20 us between two kernels) and
-            # one grouped launch.  Without a gradient-reduction hook, inner layers go in PAIRS (8 products per launch: half the forks,
-            # half the atomic flushes); the first layer of the backward and the last one keep their own (the side queue starts
-            # early and the tail behind the backward chain stays one layer long)
+            # one grouped launch.  Inner layers go in PAIRS (8 products per launch: half the forks, half the atomic flushes); the
+            # first layer of the backward and the last one keep their own (the side queue starts early and the tail behind the
+            # backward chain stays one layer long).  With a gradient-reduction hook (N > 1) the pair's two slices of the flat
+            # gradient -- adjacent in the buffer -- are reduced by ONE collective behind the pair's launch (round 6; rounds 2-5
+            # flushed and reduced per layer whenever a hook was set).
             nl = cfg.num_hidden_layers
-            if model._layer_hook is not None or not model.tn_pair or l == nl - 1 or l == 0 or (nl - 1 - l) % 2 == 0:
+            if not model.tn_pair or l == nl - 1 or l == 0 or (nl - 1 - l) % 2 == 0:
                 wg.flush()
-            if model._layer_hook is not None:
-                model._layer_hook(l, wg.mark())
+                if model._layer_hook is not None:
+                    model._layer_hook(l if deferred_layer is None else (l, deferred_layer), wg.mark())
+                deferred_layer = None
+            else:
+                deferred_layer = l  # its products wait for the next layer's flush
         z0, m0, r0 = ctx.saved["emb"]
         if cfg.num_hidden_layers == 0 or dz0 is None:
             d_emb = model._drop(ph, training, seed, 0, _Site.EMB)

@@ -237,7 +237,10 @@ class _DistLossFn(torch.autograd.Function):
                 gathered.append((buf, work))
 
         # FLOPS regulariser: global column means = mean of the per-rank column means (equal local batch sizes)
-        d_flops, cm_d, keep_d = ops.flops_fwd(d, k, thr)
+        if gather and thr is None:
+            d_flops = cm_d = keep_d = None  # column sums come from the gathered chunks below; without a row threshold nothing local is needed
+        else:
+            d_flops, cm_d, keep_d = ops.flops_fwd(d, k, thr)
         if gather:
             cm_d = None  # summed over the gathered chunks below (every chunk holds whole queries of every rank)
         elif D:

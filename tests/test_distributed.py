@@ -163,12 +163,14 @@ from sparse_hip.encoder import BertConfigLite, HipBertMLM
 g1 = np.load(os.path.join(root, "tests", "golden", "g1_encode.npz"))
 g2 = np.load(os.path.join(root, "tests", "golden", "g2_inf_free.npz"))
 g6 = np.load(os.path.join(root, "tests", "golden", "g6_compute_loss.npz"))
-cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
-                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None)
-bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
-model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
 case = os.environ.get("SM_TEST_CASE", "infonce_ibn")
+layers = 5 if case == "infonce_ibn_5layers" else 2  # 5 layers: the weight gradients of layers (2, 3) and (0, 1) go out in PAIRS and each pair's
+cfg = BertConfigLite(vocab_size=520, hidden_size=64, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=128,  # two slices are reduced by one collective
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+bb = HipBertMLM(cfg, compute_dtype=torch.float32, device="cuda", init_seed=None if layers == 2 else 11)
+if layers == 2:
+    bb.load_hf_state_dict({k[3:]: torch.tensor(g1[k]) for k in g1.files if k.startswith("sd/")})
+model = SparseModel(bb, idf=torch.tensor(g2["idf_vector"]), use_l0=False)
 inf_free = case != "learned_queries"
 ibn = case != "kd_pairs"
 K = 3 if case == "infonce_ibn_k3" else 4  # k = 3 with 2 ranks: the rank count does not divide the documents per query
@@ -333,7 +335,7 @@ def test_two_rank_gradients_match_the_reference_two_process_run(tmp_path, name):
             assert err <= 2e-3 * max(1.0, np.abs(ref).max()), (mode, key, float(err))
 
 
-CASES = ["infonce_ibn", "infonce_ibn_k3", "kd_pairs", "learned_queries"]
+CASES = ["infonce_ibn", "infonce_ibn_k3", "kd_pairs", "learned_queries", "infonce_ibn_5layers"]
 
 
 @pytest.mark.gpu
