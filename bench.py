@@ -33,7 +33,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver s
 # runtime's default of 4 hardware queues two of them share one, and when the communication stream's wait for a layer's weight gradients
 # lands in the main stream's queue the backward chain stalls for the length of that weight-gradient kernel -- 275 us behind every layer,
 # 0.36 ms of a 12.4 ms step (measured with a one-rank RCCL communicator, profiles/r6_single_rank_rccl.txt).  Must be set before HIP starts.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--single-rank-rccl" in sys.argv:
+# (Only with one process per GPU: SM_BENCH_BACKEND=gloo puts N ranks on ONE GPU for functional checks, and two processes with 8 hardware
+# queues each on one device deadlocked in the first host-blocking gloo collective -- tools/r6_run15.sh.)
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--single-rank-rccl" in sys.argv) and os.environ.get("SM_BENCH_BACKEND", "nccl") == "nccl":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -126,7 +126,8 @@ class SparseModelTrainer:
         self._in_compute_loss = False
         self._step_done = []  # events at the end of the last steps (training_step: bounded host lead)
         if self.accelerator.distributed:
-            if sparse_model.backbone.device.type == "cuda" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            if (sparse_model.backbone.device.type == "cuda" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8
+                    and dist.get_backend() == "nccl"):  # (gloo = several ranks on one GPU in the tests: keep the default there)
                 # (train_ir.py and bench.py set it before HIP starts; a caller that builds the trainer itself has to)
                 logger.warning("N > 1 with GPU_MAX_HW_QUEUES < 8: the gradient all-reduce's wait for the weight gradients can share a hardware "
                                "queue with the backward chain and stall it (~0.3 ms per step); export GPU_MAX_HW_QUEUES=8 before the process starts")
