@@ -125,7 +125,8 @@ def make_trainer(args, seed=0):
     bb.mark_weights_dirty()
     bb.varlen = args.layout == "ragged"
     model = SparseModel(bb, use_l0=False)
-    ds = SyntheticTriplesDataset(args.queries, args.docs, 128, 32, 30522, seed=args.seed)
+    S = int(getattr(args, "seq", 128))  # round 6: the long-document kernels (S = 256 / 512)
+    ds = SyntheticTriplesDataset(args.queries, args.docs, S, 32, 30522, seed=args.seed, len_mean=80.0 * S / 128, len_std=30.0 * S / 128)
     batch = PreTokenizedCollator()([ds[i] for i in range(args.queries)])
     margs = ModelArguments(model_name_or_path="x", inf_free=True)
     dargs = DataTrainingArguments(loss_types=["infonce"], use_in_batch_negatives=True, flops_d_lambda=0.0, flops_d_T=1)
@@ -146,6 +147,7 @@ def main():
     ap.add_argument("--queries", type=int, default=8)
     ap.add_argument("--docs", type=int, default=4)
     ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--trace-ops", action="store_true")
     ap.add_argument("--fresh-gb", type=float, default=0.0,
                     help="before every trial: fill this many GiB with the poison pattern, free them and EMPTY the allocator's cache, so "

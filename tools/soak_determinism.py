@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--queries", type=int, default=8)
     ap.add_argument("--docs", type=int, default=4)
     ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--perturb", action="store_true")
     ap.add_argument("--sync-each-op", action="store_true")
     args = ap.parse_args()
