@@ -24,6 +24,9 @@
 #ifndef ATTN_BWD2_MIN_S
 #define ATTN_BWD2_MIN_S 256  // ... from this padded length on, dense layout (set from the A/B run, see launch_bwd)
 #endif
+#ifndef ATTN_FWD_SPLIT
+#define ATTN_FWD_SPLIT 1  // the bf16 forward walks 512-token documents as two key groups (online softmax) with 16 waves per workgroup; 0: one group, 8 waves
+#endif
 #ifndef ATTN_BWD_NW_LONG
 #define ATTN_BWD_NW_LONG 16  // waves per workgroup of the two-phase backward on paired heads (head dim 32) for documents > 128 tokens
 #endif
@@ -288,7 +291,9 @@ struct Lay {  // LDS row stride (bytes): 128-byte bf16 rows are XOR-swizzled (im
 // NW = waves per workgroup: the K / V images of a long document (S = 512, head dim 64: 128 KiB) leave room for ONE workgroup per CU,
 // and with 4 waves that is one wave per SIMD walking QK^T -> softmax -> PV with nothing to overlap its latencies (configs[4]: 110
 // TFLOP/s); 8 waves share the same images
-template <typename T, int DH, int NKT, int HP, bool DROP, bool TAIL, int NW>  // TAIL: dense layout, trailing masked key tiles are skipped
+// NSPLIT (round 6 experiment, long documents): the key tiles are walked in NSPLIT groups with a running maximum / sum (online softmax):
+// NKT / NSPLIT score tiles live in registers instead of NKT, so twice the waves fit a SIMD
+template <typename T, int DH, int NKT, int HP, bool DROP, bool TAIL, int NW, int NSPLIT = 1>  // TAIL: dense layout, trailing masked key tiles are skipped
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const T* __restrict__ qkv, const uint8_t* __restrict__ keymask,
                                                        T* __restrict__ ctx, float* __restrict__ lse, int S, int A, DropCfg drop,
                                                        const int32_t* __restrict__ doc_off) {
@@ -343,69 +348,87 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const T* __restrict__
     typename AT<T>::Frag fq[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fq[ks] = grow_frag<T>(base, ld, qb * 16 + li, ks, g);
-    f32x4 p[NKT];
-    float mx = -INFINITY;
+    constexpr int NKH = NKT / NSPLIT;
+    const int q = qb * 16 + li;
+    float m_run = -1e30f, l_run = 0.f;  // running maximum (log2 domain, clamped like mxs below) and sum over the key groups so far
+    f32x4 oacc[DH / 16];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
-        p[kt] = dh_product<T, DH, L::SWZ>(sK0, L::RS, cof, kt * 16 + li, g, fq);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + kt * 16 + 4 * g);
+    for (int dt = 0; dt < DH / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = fmaf(p[kt][r], scale2, bias[r]);
-          p[kt][r] = sc;
-          mx = fmaxf(mx, sc);
+    for (int sp = 0; sp < NSPLIT; ++sp) {
+      const int kt0 = sp * NKH;
+      if (NSPLIT > 1 && kt0 >= nkt) break;
+      f32x4 p[NKH];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKH; ++kt) {
+        if (kt0 + kt < nkt) {
+          p[kt] = dh_product<T, DH, L::SWZ>(sK0, L::RS, cof, (kt0 + kt) * 16 + li, g, fq);
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + (kt0 + kt) * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sc = fmaf(p[kt][r], scale2, bias[r]);
+            p[kt][r] = sc;
+            mx = fmaxf(mx, sc);
+          }
+        } else {
+          p[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-      } else {
-        p[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mxs = fmaxf(fmaxf(mx, m_run), -1e30f);  // a fully masked row: exp2(-inf - (-1e30)) = 0 without a select per element
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKH; ++kt)
+        if (kt0 + kt < nkt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(p[kt][r] - mxs);
+            p[kt][r] = e;
+            sum += e;
+          }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float alpha = NSPLIT > 1 ? __builtin_amdgcn_exp2f(m_run - mxs) : 0.f;  // rescales what the earlier groups accumulated
+      l_run = l_run * alpha + sum;
+      m_run = mxs;
+      // one group: the probabilities are normalised before they are rounded to bf16 (the kernel of rounds 1-5, bit for bit); several
+      // groups: the sum is not known yet, so the context row is normalised at the end (the keep mask does not depend on it)
+      const float pre = NSPLIT > 1 ? 1.f : (sum > 0.f ? 1.f / sum : 0.f);
+      const float pscale = DROP ? pre * d8.scale : pre;
+      if constexpr (DROP) {
+        const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
+        const uint32_t blk0 = (uint32_t)((q >> 1) * (S >> 1) + 2 * g), sh = 16u * (li & 1);
+#pragma unroll
+        for (int kt = 0; kt < NKH; ++kt)
+          if (kt0 + kt < nkt) {
+            const uint32_t h0 = drop_block_hash(ukey, blk0 + (kt0 + kt) * 8), h1 = drop_block_hash(ukey, blk0 + (kt0 + kt) * 8 + 1);
+            p[kt][0] *= drop_keep_byte(h0, sh, d8.th8) ? pscale : 0.f;
+            p[kt][1] *= drop_keep_byte(h0, sh + 8, d8.th8) ? pscale : 0.f;
+            p[kt][2] *= drop_keep_byte(h1, sh, d8.th8) ? pscale : 0.f;
+            p[kt][3] *= drop_keep_byte(h1, sh + 8, d8.th8) ? pscale : 0.f;
+          }
+      } else if (NSPLIT == 1) {
+#pragma unroll
+        for (int kt = 0; kt < NKH; ++kt)
+          if (kt0 + kt < nkt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[kt][r] *= pscale;
+      }
+      typename PT<T>::type pp[NKH];
+#pragma unroll
+      for (int kt = 0; kt < NKH; ++kt) pp[kt] = PT<T>::pack(p[kt]);
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const f32x4 o = SeqProd<T, NKH, L::SWZ>::run(sV0 + (size_t)kt0 * 16 * L::RS, L::RS, cof, dt * 16, g, li, pp, nkt - kt0);
+        oacc[dt] = NSPLIT > 1 ? oacc[dt] * alpha + o : o;
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mxs = fmaxf(mx, -1e30f);  // a fully masked row: exp2(-inf - (-1e30)) = 0 without a select per element
-    float sum = 0.f;
+    const float inv = NSPLIT > 1 ? (l_run > 0.f ? 1.f / l_run : 0.f) : 1.f;
+    if (g == 0) lse[(size_t)(b * A + h) * S + q] = m_run * 0.6931471805599453f + __logf(l_run);
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-      if (kt < nkt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(p[kt][r] - mxs);
-          p[kt][r] = e;
-          sum += e;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = sum > 0.f ? 1.f / sum : 0.f;
-    const int q = qb * 16 + li;
-    if constexpr (DROP) {
-      const uint32_t ukey = drop_unit_key(drop, (uint32_t)(b * A + h));
-      const uint32_t blk0 = (uint32_t)((q >> 1) * (S >> 1) + 2 * g), sh = 16u * (li & 1);
-      const float invd = inv * d8.scale;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
-          const uint32_t h0 = drop_block_hash(ukey, blk0 + kt * 8), h1 = drop_block_hash(ukey, blk0 + kt * 8 + 1);
-          p[kt][0] *= drop_keep_byte(h0, sh, d8.th8) ? invd : 0.f;
-          p[kt][1] *= drop_keep_byte(h0, sh + 8, d8.th8) ? invd : 0.f;
-          p[kt][2] *= drop_keep_byte(h1, sh, d8.th8) ? invd : 0.f;
-          p[kt][3] *= drop_keep_byte(h1, sh + 8, d8.th8) ? invd : 0.f;
-        }
-    } else {
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p[kt][r] *= inv;
-    }
-    if (g == 0) lse[(size_t)(b * A + h) * S + q] = mx * 0.6931471805599453f + __logf(sum);
-    typename PT<T>::type pp[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) pp[kt] = PT<T>::pack(p[kt]);
-#pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 o = SeqProd<T, NKT, L::SWZ>::run(sV0, L::RS, cof, dt * 16, g, li, pp, nkt);
-      store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, o);
-    }
+    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(ctx + ((size_t)row0 + q) * H + h * DH + dt * 16 + 4 * g, oacc[dt] * inv);
   }
 }
 
@@ -1021,9 +1044,10 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
     // take 64 / 128 KiB, i.e. one or two workgroups per CU -- with 4 waves that was one wave per SIMD and nothing to overlap its
     // QK^T -> softmax -> PV chain with (round 5 gave the head-dim-64 kernels 8 waves for the same reason; the paired head-dim-32
     // path was left at 4)
-    constexpr int NWP = NKT >= 16 ? 8 : 4;
-    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true, NWP> : attn_fwd_kernel<T, DH, NKT, 2, true, false, NWP>)
-                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true, NWP> : attn_fwd_kernel<T, DH, NKT, 2, false, false, NWP>);
+    constexpr int NSP = (ATTN_FWD_SPLIT && NKT >= 32) ? 2 : 1;
+    constexpr int NWP = NSP > 1 ? 16 : NKT >= 16 ? 8 : 4;
+    auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 2, true, true, NWP, NSP> : attn_fwd_kernel<T, DH, NKT, 2, true, false, NWP, NSP>)
+                           : (tail ? attn_fwd_kernel<T, DH, NKT, 2, false, true, NWP, NSP> : attn_fwd_kernel<T, DH, NKT, 2, false, false, NWP, NSP>);
     SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * A / 2), dim3(64 * NWP), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
     return SM_OK;
@@ -1032,9 +1056,10 @@ int launch_fwd(const void* qkv, const uint8_t* km, void* ctx, float* lse, int B,
   SM_REQUIRE(lds <= LDS_MAX, "sm_attention_fwd: S=%d dh=%d needs %zu B of LDS", S, DH, lds);
   const bool tail = ATTN_SKIP && doc_off == nullptr;
   // long documents in bf16: 8 waves per workgroup (one workgroup's images fill the CU's LDS)
-  constexpr int NW = (sizeof(T) == 2 && NKT >= 16) ? 8 : 4;
-  auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 1, true, true, NW> : attn_fwd_kernel<T, DH, NKT, 1, true, false, NW>)
-                         : (tail ? attn_fwd_kernel<T, DH, NKT, 1, false, true, NW> : attn_fwd_kernel<T, DH, NKT, 1, false, false, NW>);
+  constexpr int NSP = (ATTN_FWD_SPLIT && sizeof(T) == 2 && NKT >= 32) ? 2 : 1;
+  constexpr int NW = NSP > 1 ? 16 : (sizeof(T) == 2 && NKT >= 16) ? 8 : 4;
+  auto kern = d.thresh16 ? (tail ? attn_fwd_kernel<T, DH, NKT, 1, true, true, NW, NSP> : attn_fwd_kernel<T, DH, NKT, 1, true, false, NW, NSP>)
+                         : (tail ? attn_fwd_kernel<T, DH, NKT, 1, false, true, NW, NSP> : attn_fwd_kernel<T, DH, NKT, 1, false, false, NW, NSP>);
   SM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(B * A), dim3(64 * NW), lds, st, (const T*)qkv, km, (T*)ctx, lse, S, A, d, doc_off);
   return SM_OK;

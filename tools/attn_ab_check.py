@@ -24,5 +24,7 @@ dctx = (torch.randn(B * S, H, device="cuda", generator=g) * mask.view(-1, 1)).bf
 for p in (0.0, 0.1):
     drop = lib.dropout(p, 5, 9) if p else None
     ctx, lse = ops.attention_fwd(qkv, mask, B, S, A, drop)
+    out[f"dense fwd ctx p={p}"] = ctx.float().cpu() * mask.view(-1, 1).float().cpu()  # (padded query rows carry no defined context)
+    out[f"dense fwd lse p={p}"] = torch.where(mask.view(B, 1, S).bool().expand(B, A, S), lse.view(B, A, S), torch.zeros(())).cpu() if lse.numel() == B * A * S else lse.cpu()
     out[f"dense p={p}"] = ops.attention_bwd(qkv, mask, ctx, dctx, lse, B, S, A, drop).cpu()
 torch.save(out, sys.argv[2])
