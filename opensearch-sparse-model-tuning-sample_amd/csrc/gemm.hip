@@ -1708,7 +1708,8 @@ __global__ __launch_bounds__(512) void gemm_nt192_kernel(const bf16* __restrict_
 
 }  // namespace
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res = nullptr);  // gemm_ws.hip
+                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res = nullptr, const float* scale_a = nullptr,
+                    const float* scale_b = nullptr);  // gemm_ws.hip
 namespace {
 
 // rows per workgroup tile of gemm_nt192_kernel: 128 when rounds x height is lower that way by more than the smaller tile's lower
@@ -1914,6 +1915,18 @@ int launch_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, 
              ((uintptr_t)e.residual % (e.res32 ? 32 : vb) == 0) && ((uintptr_t)e.gelu_grad_of % vb == 0) && ((uintptr_t)e.gelu_out % vb == 0);
   const int q8rc = epi_q8(e, epi, C, N, !epi->out_f32);
   if (q8rc != 0) return q8rc;
+  // K = 768 (the bert-base width: QKV forward, attention-output forward and its input gradient) without a GELU in the epilogue: the
+  // weight-stationary kernel on fp8 operands (gemm_ws.hip, OPK 2 / 3); GELU epilogues stay here (their vector work per element exceeds the
+  // fp8 matrix time of K = 768, whatever wave evaluates it)
+  if (!e.q8 && !e.act && !e.preact && !e.gelu_grad_of && !e.gelu_out) {
+    const int dt = std::is_same<OP, fp8_op>::value ? SM_FP8 : SM_FP8_GRAD;
+    if (!e.drop.thresh16 && !e.residual && !e.out32 && !e.rl_mean) {
+      if (sm_gemm_ws_try(dt, A, lda, B, ldb, C, ldc, M, N, K, e.bias, nullptr, nullptr, st, nullptr, e.scale_a, e.scale_b)) return 0;
+    } else if (e.residual && e.res32 && e.out32 && e.vec_ok) {
+      WsResidual r{(const float*)e.residual, e.rl_mean, e.rl_rstd, e.rl_gamma, e.rl_beta, e.drop};
+      if (sm_gemm_ws_try(dt, A, lda, B, ldb, C, ldc, M, N, K, e.bias, nullptr, nullptr, st, &r, e.scale_a, e.scale_b)) return 0;
+    }
+  }
   dim3 grid(sm_cdiv(N, BN), (sm_cdiv(M, BM) + 7) / 8 * 8);
   hipLaunchKernelGGL((gemm_nt_kernel<bf16, true, OP>), grid, dim3(NTHREADS), 2 * 3 * GL_STAGE, st, (const OP*)A, lda, (const OP*)B, ldb, (bf16*)C, ldc, M, N,
                      K, e);

@@ -1,5 +1,7 @@
 // WEIGHT-STATIONARY NT GEMM for K = 384 (the encoder linears of the 384-wide models whose K is the hidden size: QKV forward, the
-// attention-output input gradient, the FFN-down input gradient dF1): C[M, N] = epi(A[M, 384] . W[N, 384]^T), 16-bit operands.
+// attention-output input gradient, the FFN-down input gradient dF1): C[M, N] = epi(A[M, 384] . W[N, 384]^T), 16-bit operands --
+// and (round 6) for K = 768 on fp8 operands, the same 768-byte rows (configs[4]'s bert-base width: QKV forward, attention-output
+// forward and input gradient; see ws_mma8 below).
 //
 // Why: at K = 384 the 128 x 128 tile kernel (gemm.hip) spends its time on the CU's vector-memory path (~30 B/clk, shared by the
 // LDS-DMA of three co-resident workgroups and their epilogues' loads / stores): 64 FLOP per loaded byte, a prologue and an epilogue
@@ -64,6 +66,18 @@ template <bool F16> __device__ __forceinline__ f32x16 ws_mma(bf16x8 a, bf16x8 b,
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// fp8 operands (OPK 2: e4m3 x e4m3, OPK 3: e5m2 x e4m3; round 6): the SAME byte movement with K = 768 one-byte elements per 768-byte
+// row -- loader, ring, fragment reads and the resident weight fragments do not change.  Two consecutive 16-byte fragments of a lane
+// (bytes [32 j + 16 h, + 16) of stage-row windows j = 2 m, 2 m + 1) feed ONE v_mfma_f32_32x32x64_f8f6f4: which 32 of the window pair's
+// 64 k-elements a lane half supplies is a permutation applied to A and B alike, so the sum over k is unchanged (gemm.hip's fp8 note).
+// 12 matrix instructions of 16 passes per step instead of 24 of 8: the step takes the same time and carries twice the FLOPs.
+typedef int ws_i32x8 __attribute__((ext_vector_type(8)));
+template <int CBSZ> __device__ __forceinline__ f32x16 ws_mma8(bf16x8 a0, bf16x8 a1, bf16x8 b0, bf16x8 b1, f32x16 c) {
+  struct P { bf16x8 lo, hi; };
+  const ws_i32x8 a = __builtin_bit_cast(ws_i32x8, P{a0, a1}), b = __builtin_bit_cast(ws_i32x8, P{b0, b1});
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, CBSZ, 0, 0, 0, 0, 0);  // (cbsz: A's format, 0 e4m3 / 1 e5m2; B e4m3; non-scaled)
+}
+
 // -DWS_STAMPS: shader-clock stamps of workgroup 8 (tools/gemm_ws_stamps.py); nothing in a normal build
 #ifdef WS_STAMPS
 __device__ unsigned long long ws_stamps[4][128];
@@ -86,10 +100,12 @@ struct WsArgs {
   const float* res32;   // [M, N] fp32
   const float *rl_mean, *rl_rstd, *rl_gamma, *rl_beta;
   DropCfg drop;
+  const float *scale_a, *scale_b;  // OPK >= 2: device scalars, the accumulator is multiplied by *scale_a * *scale_b (sm_quantize_fp8)
 };
 
 // EPI 0: C = acc + bias.  EPI 1: C = acc * gelu'(f1), ga = gelu(f1) (the fused forward's sigmoid-form GELU).  EPI 2: see WsArgs
-template <bool F16, int EPI>
+// OPK: operand kind -- 0 bf16, 1 fp16 (K = 384), 2 e4m3 x e4m3, 3 e5m2 x e4m3 (K = 768; A / W are passed as pointers to the same bytes)
+template <int OPK, int EPI>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
   constexpr int KS = WS_KS, NST = WS_NST, D = WS_D, BAR_KS = WS_BAR_KS;
   extern __shared__ __attribute__((aligned(256))) char ws_smem[];
@@ -117,6 +133,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
     float bv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bv[k] = (EPI != 1 && a.bias) ? a.bias[col + k] : 0.f;
+    float alpha = 1.f;
+    if constexpr (OPK >= 2) alpha = *a.scale_a * *a.scale_b;
     // EPI 2: this lane's eight columns of the LayerNorm parameters, and the residual words / row statistics of the step processed
     // NEXT (fetched one barrier early, like f1 below)
     float lg[8], lb[8];
@@ -183,8 +201,13 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
       for (int p = 0; p < 4; ++p) {
         const int row = row_base + s * 32 + sw * 16 + p * 4 + rq;
         float v[8];
+        if constexpr (OPK >= 2) {  // (gemm.hip's fp8 epilogue: the accumulator is scaled first, then the bias is added)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = lo[p][k] + bv[k]; v[4 + k] = hi[p][k] + bv[4 + k]; }
+          for (int k = 0; k < 4; ++k) { v[k] = lo[p][k] * alpha + bv[k]; v[4 + k] = hi[p][k] * alpha + bv[4 + k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[k] = lo[p][k] + bv[k]; v[4 + k] = hi[p][k] + bv[4 + k]; }
+        }
         if constexpr (EPI == 2) {
           if (a.drop.thresh16) drop_apply8(a.drop, (uint64_t)row * (uint64_t)a.N + col, v);
 #pragma unroll
@@ -335,14 +358,42 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
     constexpr bool FIRST = decltype(first_c)::value;
     ws_static_for<0, KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
+      if constexpr (OPK >= 2) {
+        // fp8: the matrix instruction of window pair (ks - 1, ks) sits at odd ks; both fragments are refilled behind it (six younger reads
+        // follow the pair's own, as in the 16-bit schedule); barrier and hand-over keep their k-step slots
+        if constexpr (ks % 2 == 1) {
+          ws_wait_pair<D - 2>(af[(ks - 1) % D], af[ks % D]);
+          if constexpr (ks == 1) {
+            f32x16 zero;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+            acc = ws_mma8<OPK - 2>(af[0], af[1], fb[0], fb[1], zero);
+          } else {
+            acc = ws_mma8<OPK - 2>(af[(ks - 1) % D], af[ks % D], fb[ks - 1], fb[ks], acc);
+          }
+          if constexpr (ks - 1 + D < KS) WS_READ(ks - 1 + D, SLOT);
+          else WS_READ(ks - 1 + D - KS, NEXT);
+          if constexpr (ks + D < KS) WS_READ(ks + D, SLOT);
+          else WS_READ(ks + D - KS, NEXT);
+        }
+        if constexpr (ks == BAR_KS && !FIRST) {
+          if (w == 0) WS_STAMP(0, 2 * s);
+          __builtin_amdgcn_s_barrier();  // B_s
+          asm volatile("" ::: "memory");
+          if (w == 0) WS_STAMP(0, 2 * s + 1);
+        }
+        if constexpr (!FIRST && ks > BAR_KS && ks <= BAR_KS + 16)
+          hand_over(std::integral_constant<int, ks - BAR_KS - 1>{}, prev, (s - 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
       if constexpr (ks % 2 == 0) ws_wait_pair<D - 2>(af[ks % D], af[(ks + 1) % D]);
       if constexpr (ks == 0) {
         f32x16 zero;
 #pragma unroll
         for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-        acc = ws_mma<F16>(af[0], fb[0], zero);
+        acc = ws_mma<OPK == 1>(af[0], fb[0], zero);
       } else {
-        acc = ws_mma<F16>(af[ks % D], fb[ks], acc);
+        acc = ws_mma<OPK == 1>(af[ks % D], fb[ks], acc);
       }
       if constexpr (ks == BAR_KS && !FIRST) {
         if (w == 0) WS_STAMP(0, 2 * s);
@@ -355,6 +406,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(WsArgs a) {
       if constexpr (!FIRST && ks > BAR_KS && ks <= BAR_KS + 16)
         hand_over(std::integral_constant<int, ks - BAR_KS - 1>{}, prev, (s - 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+      }
     });
   };
   constexpr std::true_type T_{};
@@ -406,16 +458,22 @@ extern "C" int sm_ws_debug_stamps(unsigned long long* host) { return (int)hipMem
 
 // false: shape not taken (the caller runs the 128 x 128 kernel)
 bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
-                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res) {
+                    const void* f1_tiled, void* ga, hipStream_t st, const WsResidual* res, const float* scale_a, const float* scale_b) {
 #ifdef SM_WS_DISABLE  // (A/B builds of tools/: the 128 x 128 kernel everywhere)
   return false;
 #endif
-  if ((dtype != SM_BF16 && dtype != SM_F16) || K != WS_H || lda != WS_H || ldb != WS_H || ldc != N || N % 128 != 0 || M < 8192) return false;
+  const bool f8 = dtype == SM_FP8 || dtype == SM_FP8_GRAD;
+  if (f8) {  // one-byte operands: K = 768 elements in the kernel's 768-byte rows
+    static const bool off8 = [] { const char* e = getenv("SM_WS_FP8"); return e != nullptr && e[0] == '0'; }();
+    if (off8 || f1_tiled || ga || scale_a == nullptr || scale_b == nullptr) return false;
+  } else if (dtype != SM_BF16 && dtype != SM_F16) return false;
+  const int rowe = f8 ? 2 * WS_H : WS_H;  // elements per row
+  if (K != rowe || lda != rowe || ldb != rowe || ldc != N || N % 128 != 0 || M < 8192) return false;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)f1_tiled | (uintptr_t)ga) % 16) return false;
   if (dtype == SM_F16 && f1_tiled) return false;
   if (res != nullptr) {
     static const bool off = [] { const char* e = getenv("SM_WS_RESIDUAL"); return e != nullptr && e[0] == '0'; }();
-    if (off || dtype != SM_BF16 || f1_tiled || res->residual == nullptr) return false;
+    if (off || (dtype != SM_BF16 && !f8) || f1_tiled || res->residual == nullptr) return false;
     if (((uintptr_t)res->residual | (uintptr_t)res->rl_gamma | (uintptr_t)res->rl_beta) % 16) return false;
   }
   WsArgs a{};
@@ -427,6 +485,8 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
   a.ga = (bf16*)ga;
   a.M = M;
   a.N = N;
+  a.scale_a = scale_a;
+  a.scale_b = scale_b;
   const int ncs = N / 128;
   int rs = WS_ROUNDS * 256 / ncs;  // WS_ROUNDS rounds of (at most) 256 workgroups
   const int steps_all = (M + 31) / 32;
@@ -434,9 +494,9 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
   if (rs < 1) rs = 1;
   a.rsplit = rs;
   const int total = ncs * rs, grid = ((total + 7) / 8) * 8;
-#define WS_GO(F16, EPI)                                                                                                 \
+#define WS_GO(OPK, EPI)                                                                                                 \
   do {                                                                                                                  \
-    auto kern = gemm_ws_kernel<F16, EPI>;                                                                               \
+    auto kern = gemm_ws_kernel<OPK, EPI>;                                                                               \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) != hipSuccess) return false; \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WS_LDS, st, a);                                                     \
   } while (0)
@@ -449,10 +509,14 @@ bool sm_gemm_ws_try(int dtype, const void* A, int lda, const void* W, int ldb, v
     a.rl_gamma = res->rl_gamma;
     a.rl_beta = res->rl_beta;
     a.drop = res->drop;
-    WS_GO(false, 2);
-  } else if (f1_tiled) WS_GO(false, 1);
+    if (dtype == SM_FP8) WS_GO(2, 2);
+    else if (dtype == SM_FP8_GRAD) WS_GO(3, 2);
+    else WS_GO(0, 2);
+  } else if (f1_tiled) WS_GO(0, 1);
   else if (dtype == SM_F16) return false;  // (no fp16-operand caller at K = 384 with a plain epilogue)
-  else WS_GO(false, 0);
+  else if (dtype == SM_FP8) WS_GO(2, 0);
+  else if (dtype == SM_FP8_GRAD) WS_GO(3, 0);
+  else WS_GO(0, 0);
 #undef WS_GO
   return true;
 }

@@ -1210,6 +1210,68 @@ def test_gemm_ws_plain_epilogue(ops, M, N, bias):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,bias", [(8192, 2304, True), (8192 + 300 + 9, 768, False), (20000, 768, True), (65536, 128, True)])
+@pytest.mark.parametrize("grad", [False, True])
+def test_gemm_ws_fp8_plain_epilogue(ops, M, N, bias, grad):
+    """round 6: C = (qA . qW^T) sa sb (+ bias) at K = 768, M >= 8192 on fp8 operands through the weight-stationary kernel (OPK 2: e4m3 x
+    e4m3, the QKV forward; OPK 3: e5m2 x e4m3, the attention-output input gradient): against the fp64 product of the DEQUANTISED operands
+    at bf16 rounding, and against the 128 x 128 fp8 kernel (taken below 8192 rows) on row slices -- the same exact products, another
+    summation order; rows that end inside a 32-row step"""
+    g = torch.Generator(device="cuda").manual_seed(M % 1000 + int(grad))
+    a = (torch.randn(M, 768, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+    w = (torch.randn(N, 768, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1 if bias else None
+    qa, sa, _ = ops.quantize_fp8(a, e5m2=grad)
+    qw, sw, _ = ops.quantize_fp8(w)
+    got = ops.gemm_nt(qa, qw, bias=b, scale_a=sa, scale_b=sw)
+    assert got.dtype == torch.bfloat16
+    torch.cuda.synchronize()
+    for sl in (slice(0, 4096), slice(M - 4096, M), slice(M // 2 - 1000, M // 2 + 1000)):
+        want = (qa[sl].float().double() @ qw.float().double().t()) * float(sa) * float(sw) + (b.double() if bias else 0)
+        err = (got[sl].double() - want).abs()
+        assert float((err / (want.abs() * 2 ** -7 + 2e-3)).max()) <= 1.0, float(err.max())
+        old = ops.gemm_nt(qa[sl].contiguous(), qw, bias=b, scale_a=sa, scale_b=sw)  # < 8192 rows: gemm_nt_kernel<.., fp8_op>
+        assert float((old.float() - got[sl].float()).abs().max()) <= 2 ** -6 * float(want.abs().max())
+    again = ops.gemm_nt(qa, qw, bias=b, scale_a=sa, scale_b=sw)
+    assert torch.equal(got, again), "two launches on the same inputs must agree bit for bit"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [8192, 8300])
+@pytest.mark.parametrize("with_ln", [False, True])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gemm_ws_fp8_fp32_residual_epilogue(ops, M, with_ln, p):
+    """round 6: the attention-output projection of the fp32 residual stream on fp8 operands at K = N = 768 (gemm_ws.hip, OPK 2, EPI 2):
+    fp32 out = dropout((qA . qW^T) sa sb + bias) + residual (or LayerNorm of it, recomputed), against fp64 on the dequantised operands
+    with the dropout mask the backward kernels regenerate"""
+    from sparse_hip import lib
+    dtype = torch.bfloat16
+    N = K = 768
+    A, B = dev(q(rnd(M, K, seed=1, scale=0.5), dtype), dtype), dev(q(rnd(N, K, seed=2, scale=0.05), dtype), dtype)
+    z = rnd(M, N, seed=3, scale=1.5) + 0.2
+    gamma, beta, bias = 1.0 + 0.1 * rnd(N, seed=4), 0.1 * rnd(N, seed=5), 0.1 * rnd(N, seed=6)
+    zd = dev(z)
+    drop = lib.dropout(p, 5, 2) if p else None
+    ln = None
+    res = z
+    if with_ln:
+        _, _, mean, rstd = ops.layernorm_fwd_res32(zd, dev(gamma), dev(beta), 1e-12, dtype)
+        ln = (mean, rstd, dev(gamma), dev(beta))
+        res = torch.nn.functional.layer_norm(z, (N,), gamma, beta, 1e-12)
+    qa, sa, _ = ops.quantize_fp8(A)
+    qb, sb, _ = ops.quantize_fp8(B)
+    got = ops.gemm_nt(qa, qb, bias=dev(bias), drop=drop, residual=zd, out_f32=True, residual_ln=ln, scale_a=sa, scale_b=sb)
+    lin = ((qa.float().double() @ qb.float().double().t()) * float(sa) * float(sb)).float().cpu() + bias
+    if p:
+        keep = ops.dropout_bwd(torch.ones(M, N, dtype=dtype, device="cuda"), drop).float().cpu() != 0
+        p_q = int(p * 256 + 0.5) / 256  # the rate actually applied (include/sparse_hip.h, sm_dropout)
+        lin = lin * keep / (1 - p_q)
+    want = lin + res
+    assert got.dtype == torch.float32
+    close(got, want, 2e-5 if not with_ln else 1e-4, "fp8 fp32-residual epilogue")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [8192, 43904, 20000 // 16 * 16])
 def test_gemm_ws_df1_epilogue(ops, M):
     """dF1 = (dy . W2) * gelu'(f1), ga = gelu(f1) with f1 in the fused feed-forward's tile-major layout (the forward's sigmoid-form
