@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SM_ABI_VERSION 7
+#define SM_ABI_VERSION 8
 #define SM_F32 0
 #define SM_BF16 1
 /* fp16 FORWARD operands of a bf16 run (same MFMA rate, 11 significant bits instead of 8): accepted where an entry point says so --
@@ -128,6 +128,14 @@ int sm_gemm_nt_q8_partials(int M, int N); /* floats sm_epilogue.q8_partials must
  *                     records max |x[i]| into *amax_next (atomic max; the caller zeroes it once per step): one pass instead of two */
 int sm_amax(int dtype, const void* x, long n, float* amax, void* stream);
 int sm_quantize_fp8(int dtype, const void* x, long n, const float* amax, int e5m2, void* q, float* scale, float* amax_next, void* stream);
+/* ABI 8 -- the GELU of an fp8 feed-forward linear (hf:336 and its backward) as ONE pass behind a plain sm_gemm_nt, bf16 tensors of n
+ * elements (n % 8 == 0), delayed scaling (*amax: an earlier step's maximum, taken with the margin of 2; this pass's maximum is joined
+ * into *amax_next; *scale receives the dequantisation scale):
+ *   backward = 0:  g = bf16(gelu(x[i]));           out16[i] = g (out16 may be NULL);  q[i] = e4m3(g * fmax / am)   -- x = the pre-activation
+ *   backward = 1:  d = bf16(x[i] * gelu'(f1[i]));  out16[i] = d (may alias x);        q[i] = e5m2(d * fmax / am)   -- x = dy . W2, f1 as above
+ * q / *scale / *amax_next are byte for byte what sm_quantize_fp8 gives on out16. */
+int sm_gelu_quantize_fp8(const void* x, const void* f1, long n, int backward, const float* amax, void* out16, void* q, float* scale,
+                         float* amax_next, void* stream);
 
 /* Input-gradient GEMM fused with the LayerNorm backward that consumes it (hf:293/351 backward):
  *   dy = A[M,K] . B[N,K]^T + residual;  dx = LN'(dy | x, gamma, mean, rstd);  dx_drop = dropout_bwd(dx) (optional);

@@ -192,6 +192,7 @@ KERNEL_OPTIONS = {
     "wgrad_stream": ("SM_WGRAD_STREAM", True, bool),          # weight gradients on a side stream
     "dt_scatter": ("SM_DT_SCATTER", True, bool),              # head backward w.r.t. the hidden states as a scatter over the live activations when few are alive
     "dt_scatter_density": ("SM_DT_SCATTER_DENSITY", 0.06, float),  # ... below this share of live (document, vocabulary) activations
+    "fp8_gelu_pass": ("SM_FP8_GELU_PASS", True, bool),        # fp8 mode, delayed scaling: plain FFN-up / dF1 GEMMs (weight-stationary at K = 768) + ONE fused GELU + quantise pass instead of GELU epilogues + a quantisation pass
     "fp8_emit": ("SM_FP8_EMIT", False, bool),                 # fp8 mode: the FFN-width GEMM epilogues write the next GEMM's fp8 operand themselves (byte-identical; measured +-0 on configs[4]: opt-in)
     "tn_group": ("SM_TN_GROUP", True, bool),                  # a layer's weight gradients in ONE grouped launch (csrc/gemm_tn2.hip)
     "tn_pair": ("SM_TN_PAIR", True, bool),                    # ... and the inner layers two at a time (N > 1: the pair's two gradient slices are reduced by one collective)
@@ -311,6 +312,7 @@ class HipBertMLM(torch.nn.Module):
         self.wgrad_stream = opt("wgrad_stream")
         self.tn_group = opt("tn_group")
         self.fp8_emit = opt("fp8_emit")
+        self.fp8_gelu_pass = opt("fp8_gelu_pass")
         self.tn_pair = opt("tn_pair")
         # Density-adaptive head backward: the share of live sparse activations of the PREVIOUS encode (counted on a sample of the
         # columns, read back without stalling: by the next step the copy has long landed) picks between the matrix form of dt = G . E
@@ -453,7 +455,7 @@ class HipBertMLM(torch.nn.Module):
     def kernel_options(self) -> dict:
         """the kernel-selection switches in force (KERNEL_OPTIONS), after the shape / dtype conditions"""
         return {"ffn_f16": self.pc_ffn and self.ffn_f16, "pc_ffn_bwd": self.pc_ffn_bwd, "ffn_fwd_f16": self.ffn_fwd_f16,
-                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "fp8_emit": self.fp8_emit, "tn_group": self.tn_group, "tn_pair": self.tn_pair, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
+                "fp8_delayed": self.fp8 and self._fp8_delayed, "wgrad_stream": self.wgrad_stream, "fp8_emit": self.fp8_emit, "fp8_gelu_pass": self.fp8 and self.fp8_gelu_pass, "tn_group": self.tn_group, "tn_pair": self.tn_pair, "dt_scatter": self.dt_scatter, "dt_scatter_density": self.dt_scatter_density, "encode_graph": self.graph_encode,
                 "encode_graph_tokens": self.graph_tokens, "pc_infer_min_rows": self.pc_infer_min_rows}
 
     def sync_weights(self) -> None:
@@ -569,6 +571,17 @@ class HipBertMLM(torch.nn.Module):
         r = ops.gemm_nt(a, st[key], **epi)
         return (r, None) if emit8 is not None else r
 
+    def _fp8_gelu_site(self, consumer_key: str, device):
+        """(amax, amax_next) of the fp8 operand site of `consumer_key` when the fused GELU + quantise pass may produce that operand:
+        fp8 mode with delayed scaling, the option on, and the site has a history (the first step measures just in time through the
+        GEMM-epilogue path); otherwise None"""
+        if not (self.fp8 and self._fp8_delayed and self.fp8_gelu_pass and not self.fp8_emit):
+            return None
+        j = self._fp8_site(consumer_key, device)
+        if j not in self._fp8_ready:
+            return None
+        return self._fp8_cur[j:j + 1], self._fp8_next[j:j + 1]
+
     @staticmethod
     def padded_len(S: int) -> int:
         for s in SUPPORTED_S:
@@ -664,8 +677,16 @@ class HipBertMLM(torch.nn.Module):
                 x1, m1, r1 = ops.layernorm_fwd(z1, v(p + "attention.output.LayerNorm.weight"),
                                                v(p + "attention.output.LayerNorm.bias"), eps)
                 res1, res1_ln = x1, None
-            f1 = torch.empty((x1.shape[0], cfg.intermediate_size), dtype=x1.dtype, device=x1.device) if save else None
-            if f16_ffn:  # fp16 operands (x1, W1, gelu(f1), W2); f1 is kept in bf16 for the backward, which re-creates gelu(f1) in bf16
+            gsite = None if f16_ffn else self._fp8_gelu_site(f"w2{l}", x1.device)
+            f1 = torch.empty((x1.shape[0], cfg.intermediate_size), dtype=x1.dtype, device=x1.device) if save and gsite is None else None
+            if gsite is not None:
+                # fp8, bert-base width: the GELU epilogue is vector-bound (978 us against 470 us for the plain product at 160 k rows), so
+                # the product goes through the weight-stationary kernel with its bias and ONE pass makes gelu(f1) and its e4m3 copy
+                pre = self._lin(x1, f"w1{l}", bias=v(p + "intermediate.dense.bias"))
+                ga, gq, gs = ops.gelu_quantize_fp8(pre, gsite[0], gsite[1], want16=save)
+                f1 = pre if save else None
+                z2 = self._lin((gq, gs), f"w2{l}", bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=r32, residual_ln=res1_ln)
+            elif f16_ffn:  # fp16 operands (x1, W1, gelu(f1), W2); f1 is kept in bf16 for the backward, which re-creates gelu(f1) in bf16
                 gah = ops.gemm_nt(x1h, st[f"w1h{l}"], bias=v(p + "intermediate.dense.bias"), act=1, preact=f1)
                 z2 = ops.gemm_nt(gah, st[f"w2h{l}"], bias=v(p + "output.dense.bias"), drop=d_h2, residual=res1, out_f32=True, residual_ln=res1_ln)
                 ga = None
@@ -1089,8 +1110,14 @@ class _EncodeFn(torch.autograd.Function):
                 pass
             elif ga is not None:
                 wg.run(a2, ga, g(p + "output.dense.weight"), g(p + "output.dense.bias"))
-                # (fp8: dF1 leaves this epilogue in bf16 for the weight gradient AND as the e5m2 operand of the FFN-up input gradient)
-                df1, df18 = model._lin(a2, f"w2T{l}", grad=True, emit8=f"w1T{l}", emit8_grad=True, gelu_grad_of=f1)
+                gsite = model._fp8_gelu_site(f"w1T{l}", a2.device) if f1.dim() == 2 else None
+                if gsite is not None:  # fp8: the plain product, then x gelu'(f1) and the e5m2 copy in one pass (the epilogue form: 1 213 against 469 us)
+                    raw = model._lin(a2, f"w2T{l}", grad=True)
+                    df1, dq, dsc = ops.gelu_quantize_fp8(raw, gsite[0], gsite[1], f1=f1, inplace=True)
+                    df18 = (dq, dsc)
+                else:
+                    # (fp8: dF1 leaves this epilogue in bf16 for the weight gradient AND as the e5m2 operand of the FFN-up input gradient)
+                    df1, df18 = model._lin(a2, f"w2T{l}", grad=True, emit8=f"w1T{l}", emit8_grad=True, gelu_grad_of=f1)
             else:  # the forward ran on fp16 operands and kept gelu(f1) in fp16 only: the dF1 epilogue re-creates it in bf16
                 ga = torch.empty((a2.shape[0], cfg.intermediate_size), dtype=f1.dtype, device=f1.device)
                 df1 = ops.gemm_nt(a2, st[f"w2T{l}"], gelu_grad_of=f1, gelu_out=ga, gelu_grad_tiled=f1.dim() == 4)

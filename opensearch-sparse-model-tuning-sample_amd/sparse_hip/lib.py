@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsparse_hip.so")
 
 SM_F32, SM_BF16, SM_F16, SM_FP8, SM_FP8_GRAD = 0, 1, 2, 3, 4
-ABI_VERSION = 7  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
+ABI_VERSION = 8  # SM_ABI_VERSION of include/sparse_hip.h this binding was written against
 
 
 class SmDropout(C.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "sm_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, C.POINTER(SmEpilogue), _p],
     "sm_amax": [_i, _p, _l, _p, _p],
     "sm_quantize_fp8": [_i, _p, _l, _p, _i, _p, _p, _p, _p],
+    "sm_gelu_quantize_fp8": [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p],
     "sm_gemm_nt_ln_bwd": [_i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(SmDropout), _p, _p, _p, _p, _i, C.POINTER(SmDropout), _p],
     "sm_gemm_tn_acc": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "sm_ffn_pc_stage": [_i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],

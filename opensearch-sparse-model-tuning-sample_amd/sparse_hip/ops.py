@@ -183,6 +183,20 @@ def quantize_fp8(x: Tensor, e5m2: bool = False, amax: Optional[Tensor] = None, a
     return q, scale, amax
 
 
+def gelu_quantize_fp8(x: Tensor, amax: Tensor, amax_next: Tensor, f1: Optional[Tensor] = None, want16: bool = True, inplace: bool = False):
+    """(out16, q, scale): the GELU of an fp8 feed-forward linear as one pass behind a plain GEMM (sm_gelu_quantize_fp8, delayed scaling).
+    f1 None: forward -- out16 = gelu(x) (None unless want16), q its e4m3 copy; f1 given: backward -- out16 = x * gelu'(f1) (written over
+    x with inplace), q its e5m2 copy.  bf16, contiguous."""
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and (f1 is None or (f1.dtype == x.dtype and f1.is_contiguous() and f1.shape == x.shape))
+    bwd = f1 is not None
+    out16 = (x if inplace else torch.empty_like(x)) if (want16 or bwd) else None
+    q = torch.empty(x.shape, dtype=torch.float8_e5m2 if bwd else torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.call("sm_gelu_quantize_fp8", L.ptr(x), L.ptr(f1), x.numel(), int(bwd), L.ptr(amax), L.ptr(out16), L.ptr(q), L.ptr(scale), L.ptr(amax_next),
+           L.stream_ptr())
+    return out16, q, scale
+
+
 # ---------------------------------------------------------------- fused feed-forward block (hidden 384)
 def ffn_pc_stage(w1_layer0: Tensor, w2_layer0: Tensor, layer_stride: int, layers: int, w1f: Optional[Tensor], w2f: Optional[Tensor],
                  w2tf: Optional[Tensor], w1tf: Optional[Tensor]):

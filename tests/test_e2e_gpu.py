@@ -579,6 +579,7 @@ def test_fp8_operand_from_the_producing_epilogue_changes_no_bit():
     ids = torch.randint(5, 2000, (6, 32), generator=g).cuda()
     mask = torch.ones(6, 32, dtype=torch.long).cuda()
     bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=3, fp8=True)
+    bb.fp8_gelu_pass = False  # (the fused GELU + quantise pass of round 6 replaces both forms compared here: next test)
     m = SparseModel(bb, use_l0=False)
     m.train()
     adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
@@ -613,6 +614,61 @@ def test_fp8_operand_from_the_producing_epilogue_changes_no_bit():
     assert torch.equal(out[True][3], out[False][3]), "recorded maxima differ"
     rel = float((out[True][2] - out[False][2]).norm() / out[False][2].norm())
     assert rel < 1e-6, rel  # (fp32 atomics in the weight-gradient and LayerNorm-gradient sums: order-dependent last bits)
+
+
+def test_fp8_gelu_pass_behind_plain_gemms_follows_the_epilogue_form():
+    """round 6, fp8 mode with delayed scaling: from the second step on the FFN-up product and the dF1 product are PLAIN GEMMs (the
+    weight-stationary kernel at the bert-base width) and ONE pass (sm_gelu_quantize_fp8) makes gelu(f1) + its e4m3 copy, resp.
+    x gelu'(f1) + the e5m2 copy, instead of GELU epilogues + separate quantisation passes.  The only arithmetic difference is that the
+    GELU sees the pre-activation (resp. the raw product) after its bf16 rounding, so representation, gradients and recorded maxima
+    follow the epilogue form to bf16 rounding -- with and without the no-grad forward of gradient caching, dropout on"""
+    from scripts.model.sparse_encoders import SparseModel
+    from sparse_hip import ops
+    from sparse_hip.encoder import BertConfigLite, HipBertMLM
+    cfg = BertConfigLite(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                         max_position_embeddings=64, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.0)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(5, 2000, (6, 32), generator=g).cuda()
+    mask = torch.ones(6, 32, dtype=torch.long).cuda()
+    bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=3, fp8=True)
+    assert bb.fp8_gelu_pass and bb.kernel_options()["fp8_gelu_pass"]
+    m = SparseModel(bb, use_l0=False)
+    m.train()
+    adam = {"m": torch.zeros_like(bb.flat_param), "v": torch.zeros_like(bb.flat_param)}
+
+    def passes(seed):
+        bb.flat_grad.zero_()
+        bb.set_dropout_seed(seed)
+        with torch.no_grad():
+            r0 = m(inf_free=False, input_ids=ids, attention_mask=mask).float().clone()
+        rep = m(inf_free=False, input_ids=ids, attention_mask=mask)
+        (rep * rep).sum().backward()
+        torch.cuda.synchronize()
+        return r0, rep.detach().float().clone(), bb.flat_grad.clone(), bb._fp8_next.clone()
+
+    passes(100)  # step 1: every site measures its maximum (the epilogue form, whatever the option says)
+    ops.adamw(bb.flat_param, bb.flat_grad, adam["m"], adam["v"], 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1.0)
+    bb.mark_weights_dirty()
+    calls = []
+    real = ops.gelu_quantize_fp8
+    ops.gelu_quantize_fp8 = lambda *a, **k: (calls.append(k.get("f1") is not None), real(*a, **k))[1]
+    try:
+        out = {}
+        for on in (True, False):
+            bb.fp8_gelu_pass = on
+            calls.clear()
+            out[on] = passes(101)
+            # two forwards and one backward per layer
+            assert calls.count(False) == (2 * cfg.num_hidden_layers if on else 0) and calls.count(True) == (cfg.num_hidden_layers if on else 0), calls
+    finally:
+        ops.gelu_quantize_fp8 = real
+    assert len(bb._fp8_ready) == 8 * cfg.num_hidden_layers
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    r_nograd, r_grad, r_g, r_max = (rel(out[True][i], out[False][i]) for i in range(4))
+    print(f"[fp8 GELU pass against the epilogue form] representation {r_grad:.3e} (no-grad pass {r_nograd:.3e}), gradients {r_g:.3e}, recorded maxima {r_max:.3e}")
+    print(f"   representation elements that differ: {int((out[True][1] != out[False][1]).sum())} of {out[True][1].numel()}; gradient elements: {int((out[True][2] != out[False][2]).sum())} of {out[True][2].numel()}")
+    assert 0 < r_grad < 2e-2 and 0 < r_nograd < 2e-2 and 0 < r_g < 6e-2 and r_max < 5e-2  # (0: the two forms were not both run)
+    assert float(bb._fp8_cur.min()) > 0
 
 
 def test_product_path_refuses_cpu_tensors():

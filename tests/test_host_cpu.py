@@ -20,7 +20,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def test_library_loads_and_exports_every_declared_symbol():
     from sparse_hip import lib
     so = lib.load()
-    assert so.sm_abi_version() == 7
+    assert so.sm_abi_version() == 8
     header = open(os.path.join(ROOT, "include", "sparse_hip.h")).read()
     declared = set(re.findall(r"\b(sm_[a-z0-9_]+)\s*\(", header))
     declared -= {"sm_dropout", "sm_epilogue"}

@@ -1085,6 +1085,41 @@ def test_quantize_fp8_matches_the_torch_conversion(ops, dtype, e5m2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(1000, 3072), (77, 256), (4100, 1536)])
+def test_gelu_quantize_fp8_pass_equals_its_parts(ops, rows, cols):
+    """sm_gelu_quantize_fp8 (ABI 8): forward -- out16 = bf16(gelu(x)) with the bf16 epilogues' erf form (against torch's exact-erf GELU at
+    bf16 rounding), q / scale / next-step maximum byte for byte what sm_quantize_fp8 (delayed scaling) gives on out16, also without the
+    16-bit output; backward -- out16 = bf16(x gelu'(f1)) against the fp64 derivative, in place over x, q as sm_quantize_fp8(e5m2) of it"""
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = (torch.randn(rows, cols, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    f1 = (torch.randn(rows, cols, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    cur = torch.full((1,), 3.0, device="cuda")
+    zero = lambda: torch.zeros(1, device="cuda")
+    nxt = zero()
+    ga, q, sc = ops.gelu_quantize_fp8(x, cur, nxt)
+    want = torch.nn.functional.gelu(x.double())
+    assert float((ga.double() - want).abs().max()) <= 2 ** -8 * float(want.abs().max()) and ga.dtype == torch.bfloat16
+    nref = zero()
+    q_ref, s_ref, _ = ops.quantize_fp8(ga, amax=cur, amax_next=nref)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(sc, s_ref) and torch.equal(nxt, nref)
+    n2 = zero()
+    none16, q2, sc2 = ops.gelu_quantize_fp8(x, cur, n2, want16=False)
+    assert none16 is None and torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(n2, nxt)
+    # backward, in place
+    xb = x.clone()
+    n3 = zero()
+    d, qd, sd = ops.gelu_quantize_fp8(xb, cur, n3, f1=f1, inplace=True)
+    assert d.data_ptr() == xb.data_ptr() and qd.dtype == torch.float8_e5m2
+    f = f1.double()
+    gp = 0.5 * (1 + torch.erf(f / 2 ** 0.5)) + f * torch.exp(-0.5 * f * f) / (2 * torch.pi) ** 0.5
+    wd = x.double() * gp
+    assert float((d.double() - wd).abs().max()) <= 2 ** -7 * float(wd.abs().max())
+    n4 = zero()
+    qd_ref, sd_ref, _ = ops.quantize_fp8(d, e5m2=True, amax=cur, amax_next=n4)
+    assert torch.equal(qd.view(torch.uint8), qd_ref.view(torch.uint8)) and torch.equal(sd, sd_ref) and torch.equal(n3, n4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(200, 136, 128), (4100, 768, 768), (2100, 3072, 768), (1000, 768, 3072)])
 @pytest.mark.parametrize("grad", [False, True])
 def test_gemm_nt_fp8_operands(ops, M, N, K, grad):
