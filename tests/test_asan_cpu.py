@@ -82,6 +82,13 @@ run("sm_infonce_fwd_bwd", P(10), 32, B, 16, 0, P(11), P(12), None)
 run("sm_adamw", P(10), P(11), P(12), P(13), 22700000, 2e-5, 0.9, 0.999, 1e-8, 0.01, 7, 1.0, None)
 run("sm_cast_weights_multi", L.SM_BF16, P(10), 26, 5000, None)
 run("sm_amax", L.SM_BF16, P(10), 1000000, P(11), None)
+run("sm_gelu_quantize_fp8", P(10), P(11), 1000000, 1, P(12), P(10), P(13), P(14), P(15), None)   # ABI 8, backward form, in place
+run("sm_gelu_quantize_fp8", P(10), None, 1000000, 0, P(12), None, P(13), P(14), P(15), None)     # forward form without the 16-bit copy
+# fp8 operands at K = 768 through the weight-stationary launcher (plain epilogue; the fp32-residual one)
+epi8 = L.SmEpilogue(P(1).value, 0, None, nodrop, None, None, 0, 0, None, None, None, None, None, 0, P(3).value, P(4).value)
+run("sm_gemm_nt", L.SM_FP8, P(10), 768, P(11), 768, P(12), 2304, T, 2304, 768, C.byref(epi8), None)
+epi8r = L.SmEpilogue(P(1).value, 0, None, nodrop, P(2).value, None, 1, 1, None, None, None, None, None, 0, P(3).value, P(4).value)
+run("sm_gemm_nt", L.SM_FP8_GRAD, P(10), 768, P(11), 768, P(12), 768, T, 768, 768, C.byref(epi8r), None)
 ptrs = (C.c_void_p * 4)(P(10), P(11), P(12), P(13)); ws = (C.c_float * 4)(1, 1, 1, 1)
 run("sm_loss_combine", ptrs, ws, 4, P(14), 0.05, None, 0.0, P(15), P(16), P(17), 0.01, None)
 assert lib.sm_sparse_head_fwd_scratch_bytes(L.SM_F32, B, S, H, V, 1) > 0
