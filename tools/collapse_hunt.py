@@ -117,8 +117,13 @@ def make_trainer(args, seed=0):
     from scripts.train.loss import LOSS_CLS_MAP
     from scripts.train.trainer import SparseModelTrainer
     from sparse_hip.encoder import BertConfigLite, HipBertMLM
-    cfg = BertConfigLite(hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
-    bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=seed)
+    if getattr(args, "width", "mini") == "base":  # round 6: the bert-base width (configs[3] / [4]); --fp8: fp8 encoder linears -- the weight-stationary
+        # fp8 GEMMs need >= 8192 token rows (e.g. --layout dense --seq 512 --queries 8 --docs 4), the fused GELU + quantise pass a second step
+        cfg = BertConfigLite(hidden_size=768, num_hidden_layers=int(getattr(args, "layers", 0) or 12), num_attention_heads=12, intermediate_size=3072,
+                             hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
+    else:
+        cfg = BertConfigLite(hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
+    bb = HipBertMLM(cfg, compute_dtype=torch.bfloat16, device="cuda", init_seed=seed, fp8=bool(getattr(args, "fp8", False)))
     with torch.no_grad():
         g = torch.Generator().manual_seed(seed + 99)
         bb.view("cls.predictions.bias").copy_(torch.randn(cfg.vocab_size, generator=g) * 0.5)
@@ -148,6 +153,9 @@ def main():
     ap.add_argument("--docs", type=int, default=4)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--width", default="mini", choices=["mini", "base"])
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--trace-ops", action="store_true")
     ap.add_argument("--fresh-gb", type=float, default=0.0,
                     help="before every trial: fill this many GiB with the poison pattern, free them and EMPTY the allocator's cache, so "

@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--docs", type=int, default=4)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--width", default="mini", choices=["mini", "base"])
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--perturb", action="store_true")
     ap.add_argument("--sync-each-op", action="store_true")
     args = ap.parse_args()
